@@ -1,0 +1,372 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference; never on the GPU box,
+and nothing in tests/, smoke() or bench.py imports this file).  It commits data
+only: inputs are re-derivable from seeds (vln_bevbert_amd.synthetic /
+vln_bevbert_amd.weights), outputs are what the reference computed on the CPU.
+
+Shims -- installed before the reference is imported:
+  * torch_scatter (pinned 2.0.9, not installed): stub scatter_mean = index_add sum /
+    clamp(count, 1).  This stub IS the definition of that primitive here.
+  * cv2: empty module (only used under ``viz = False``).
+  * hard .cuda() calls: Tensor.cuda -> identity; build_projector rebuilt on the CPU
+    from the reference's own PointCloud / bevpos_polar.
+  * transformers 5.x: init_weights()/tie_weights() are replaced; weights come from
+    vln_bevbert_amd.weights (key-name seeded) and the MLM decoder is tied by hand.
+
+Usage:  python tests/golden/make_golden.py           (writes tests/golden/*.npz)
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from vln_bevbert_amd import synthetic, weights  # noqa: E402
+from vln_bevbert_amd.config import BevBertConfig  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- shims
+def _install_shims():
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_mean(src, index, dim=0, dim_size=None):
+        assert dim == 0
+        out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+        out.index_add_(0, index, src)
+        cnt = torch.zeros(dim_size, dtype=src.dtype)
+        cnt.index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
+        cnt.clamp_(min=1)
+        return out / cnt.view(-1, *([1] * (src.dim() - 1)))
+
+    ts.scatter_mean = scatter_mean
+    ts.scatter_max = None
+    sys.modules["torch_scatter"] = ts
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def _ref_config(cfg: BevBertConfig):
+    from transformers import PretrainedConfig
+    d = cfg.to_dict()
+    d["pretrain_tasks"] = set(d["pretrain_tasks"])
+    pc = PretrainedConfig()
+    for k, v in d.items():
+        setattr(pc, k, v)
+    pc.output_hidden_states = False
+    return pc
+
+
+def build_ref_pretrain(cfg):
+    sys.path.insert(0, os.path.join(REF, "pretrain_src"))
+    from model import bev_utils, pretrain_cmt, vilmodel
+
+    def build_projector():
+        p = bev_utils.PointCloud(math.radians(90), 1, feature_map_height=14, feature_map_width=14,
+                                 map_dim=cfg.bev_dim, map_res=cfg.bev_res,
+                                 world_shift_origin=torch.zeros(3), z_clip_threshold=0.5,
+                                 device=torch.device("cpu"))
+        bp = bev_utils.bevpos_polar(cfg.bev_dim).reshape(cfg.bev_dim ** 2, 3)[None]
+        return p, bp
+
+    pretrain_cmt.build_projector = build_projector
+    for cls in (vilmodel.GlocalTextPathCMT, pretrain_cmt.GlocalTextPathCMTPreTraining):
+        cls.init_weights = lambda self: None
+        cls.tie_weights = lambda self, *a, **k: None
+    m = pretrain_cmt.GlocalTextPathCMTPreTraining(_ref_config(cfg))
+    load_rule_weights(m)
+    m.mlm_head.predictions.decoder.weight = m.bert.embeddings.word_embeddings.weight
+    return m.eval()
+
+
+def load_rule_weights(m):
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = weights.fill_state_dict(shapes)
+    missing = m.load_state_dict(sd, strict=True)
+    return shapes
+
+
+def build_ref_nav(cfg):
+    sys.path.insert(0, os.path.join(REF, "map_nav_src"))
+    from models import vilmodel as nav_vilmodel
+    nav_vilmodel.GlocalTextPathNavCMT.init_weights = lambda self: None
+    m = nav_vilmodel.GlocalTextPathNavCMT(_ref_config(cfg))
+    load_rule_weights(m)
+    return m.eval()
+
+
+# ----------------------------------------------------------------------------- helpers
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def sub(t, step):
+    """Strided subsample over the flattened tensor (keeps fixtures small)."""
+    return npy(t).reshape(-1)[::step].copy()
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {os.path.relpath(path, ROOT)}  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def edge_case_points():
+    """Hand-built ego-frame points hitting every branch of project_bev (bev_utils.py:393-403):
+    exact .5 rounding (half-to-even), borders, outside, above-threshold, no-depth, shared and empty cells."""
+    pts = [
+        (0.0, 0.0, 0.0), (0.25, 0.0, 0.25), (-0.25, 0.0, -0.25),       # x/0.5+10 = 10.5 / 9.5 -> 10 / 10 (even)
+        (0.75, 0.0, 0.75), (-0.75, 0.0, -0.75),                        # 11.5 -> 12 ; 8.5 -> 8
+        (5.0, 0.0, 5.0), (5.24, 0.0, -5.0), (5.25, 0.0, 0.0),          # 20 (border) ; 20.48 -> 20 ; 20.5 -> 20 (even)
+        (5.26, 0.0, 0.0), (-5.25, 0.0, 0.0), (-5.26, 0.0, 0.0),        # 20.52 -> 21 outside ; -0.5 -> -0 (inside!) ; -0.52 -> -1 outside
+        (0.0, 0.5, 1.0), (0.0, 0.5000001, 1.0), (0.0, 0.6, 1.0),       # y == 0.5 kept ; just above dropped
+        (1.0, -1.0, 1.0), (1.0, -0.2, 1.0), (1.1, 0.1, 0.9),           # three points sharing cell (12,12)
+        (2.0, 0.0, -3.0), (100.0, 0.0, 0.0), (0.0, 0.0, -100.0),
+    ]
+    return torch.tensor(pts, dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------- generators
+def gen_splat(ref, cfg):
+    print("splat / lift_splat")
+    b = synthetic.make_batch(cfg, "sap", 2, seed=11, ragged=True)
+    depths_var = (b["depths"] * 10).reshape(-1, 1, 14, 14)
+    pc_w, nod = ref.projector.forward(depths_var, b["T_c2w"].reshape(-1, 4, 4))
+    rb = dict(b)
+    out = ref.lift_splat(rb)
+    # the ego-frame points exactly as the reference computes them (pretrain_cmt.py:127-137)
+    pc = pc_w.reshape(2, -1, 3) - b["S_w2c"]
+    pc1 = torch.cat([pc, torch.ones(2, pc.shape[1], 1)], -1)
+    pc = torch.matmul(pc1, b["T_w2c"].squeeze(1).transpose(1, 2))[:, :, :3]
+    save("splat_b2",
+         seed=np.int64(11), pc_ego=npy(pc), no_depth=npy(nod.reshape(2, -1)),
+         bev_fts_sub=sub(out["bev_fts"], 7), bev_fts_sum=npy(out["bev_fts"].double().sum((1, 2))),
+         bev_fts_cell_l1=npy(out["bev_fts"].abs().sum(-1)),
+         bev_pos_fts=npy(out["bev_pos_fts"]), bev_masks=npy(out["bev_masks"]),
+         bev_sems=npy(out["bev_sems"]).astype(np.uint8), bev_sem_masks=npy(out["bev_sem_masks"]))
+
+    # hand-built edge cases straight into project_bev
+    pts = edge_case_points()
+    n = pts.shape[0]
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(1, n, 768, generator=g)
+    sem_ids = torch.randint(0, 40, (1, n), generator=g)
+    sem = torch.nn.functional.one_hot(sem_ids, 40).double()
+    nod = torch.zeros(1, n, dtype=torch.bool)
+    nod[0, 0] = True                                                  # the first point has no depth
+    bev, obm, bsem, bsm = ref.projector.project_bev(pts[None], nod, feat, sem)
+    save("splat_edge", pts=npy(pts), no_depth=npy(nod), feat=npy(feat), sem_ids=npy(sem_ids),
+         bev=npy(bev.reshape(1, -1, 768)), ob_mask=npy(obm.reshape(1, -1)),
+         bev_sems=npy(bsem.reshape(1, -1, 40)).astype(np.uint8), bev_sem_masks=npy(bsm.reshape(1, -1)))
+
+    from model import bev_utils
+    save("bevpos_polar", **{f"d{d}": npy(bev_utils.bevpos_polar(d)) for d in (11, 14, 21)})
+    xyzhe = np.array([[1, 2, 3, 0.3, np.pi], [0, 0, 0, -1.2, 0], [-4, 1, 2, 2.5, 0.1]], dtype=np.float32)
+    save("pose_matrix", xyzhe=xyzhe, T=bev_utils.transfrom3D(xyzhe))
+
+
+def gen_tasks(ref, cfg, tag, B, seed, ragged, with_grads):
+    print(f"tasks [{tag}]")
+    arrs = {"seed": np.int64(seed), "B": np.int64(B), "ragged": np.bool_(ragged)}
+    for task in ("mlm", "sap", "masksem"):
+        b = synthetic.make_batch(cfg, task, B, seed=seed, ragged=ragged)
+        with torch.no_grad():
+            loss = ref(dict(b), task, True)
+            outs = ref(dict(b), task, False)
+        arrs[f"{task}_loss"] = npy(loss)
+        if task == "mlm":
+            arrs["mlm_scores_sub"] = sub(outs, 13)
+            arrs["mlm_scores_rowmax"] = npy(outs.max(1).values)
+        elif task == "sap":
+            g, l, f = outs[:3]
+            arrs.update(sap_global=npy(g), sap_local=npy(l), sap_fused=npy(f))
+            rb = ref.lift_splat(dict(b))
+            with torch.no_grad():
+                gm, bev, _, _ = ref.bert(*[rb.get(k) for k in CMT_ARGS])
+            arrs.update(gmap_embeds=npy(gm), bev_embeds_sub=sub(bev, 11),
+                        bev_embeds_center=npy(bev[:, 220]))
+        else:
+            arrs.update(masksem_logits=npy(outs[0]), masksem_labels=npy(outs[1]).astype(np.uint8))
+    # the other two sem_pred_token modes
+    b = synthetic.make_batch(cfg, "sem", B, seed=seed, ragged=ragged)
+    for tok in ("sattn", "embed"):
+        ref.sem_pred_token = tok
+        with torch.no_grad():
+            lg, _ = ref(dict(b), "sem", False)
+        arrs[f"sem_{tok}_logits_sub"] = sub(lg, 3)
+    ref.sem_pred_token = cfg.sem_pred_token
+    with torch.no_grad():
+        lg, lb = ref(dict(b), "sem", False)
+    arrs["sem_cattn_logits_sub"] = sub(lg, 3)
+    arrs["sem_n_rows"] = np.int64(lg.shape[0])
+
+    if with_grads:
+        for task in ("mlm", "sap", "masksem"):
+            ref.zero_grad(set_to_none=True)
+            b = synthetic.make_batch(cfg, task, B, seed=seed, ragged=ragged)
+            ref(dict(b), task, True).mean().backward()          # train_r2r.py:262-273
+            n_with = 0
+            for k, p in ref.named_parameters():
+                if p.grad is None:
+                    continue
+                n_with += 1
+                if k in GRAD_KEYS:
+                    arrs[f"{task}_grad::{k}"] = sub(p.grad, 97 if p.numel() > 4096 else 1)
+                arrs.setdefault(f"{task}_gradnorm_keys", [])
+            arrs[f"{task}_n_params_with_grad"] = np.int64(n_with)
+            arrs[f"{task}_grad_sqnorm"] = np.float64(
+                sum(float((p.grad.double() ** 2).sum()) for p in ref.parameters() if p.grad is not None))
+            arrs.pop(f"{task}_gradnorm_keys")
+        ref.zero_grad(set_to_none=True)
+    save(f"tasks_{tag}", **arrs)
+
+
+CMT_ARGS = ["txt_ids", "txt_lens", "traj_view_img_fts", "traj_obj_img_fts", "traj_loc_fts", "traj_nav_types",
+            "traj_step_lens", "traj_vp_view_lens", "traj_vp_obj_lens", "traj_vpids", "traj_cand_vpids",
+            "gmap_lens", "gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists", "gmap_vpids",
+            "bev_fts", "bev_pos_fts", "bev_masks", "bev_nav_masks"]
+
+GRAD_KEYS = {
+    "bert.embeddings.word_embeddings.weight",
+    "bert.embeddings.token_type_embeddings.weight",
+    "bert.embeddings.LayerNorm.weight",
+    "bert.lang_encoder.layer.0.attention.self.query.weight",
+    "bert.lang_encoder.layer.1.output.dense.bias",
+    "bert.img_embeddings.img_linear.weight",
+    "bert.img_embeddings.pano_encoder.layers.0.self_attn.in_proj_weight",
+    "bert.img_embeddings.pano_encoder.layers.0.norm1.weight",
+    "bert.local_encoder.bev_fts_embeddings.0.weight",
+    "bert.local_encoder.encoder.x_layers.0.visual_attention.att.key.weight",
+    "bert.local_encoder.encoder.x_layers.1.visn_self_att.self.value.bias",
+    "bert.local_encoder.encoder.x_layers.0.lang_inter.dense.weight",
+    "bert.global_encoder.sprel_linear.weight",
+    "bert.global_encoder.sprel_linear.bias",
+    "bert.global_encoder.gmap_step_embeddings.weight",
+    "bert.global_encoder.encoder.x_layers.1.visn_output.LayerNorm.weight",
+    "mlm_head.predictions.bias",
+    "global_sap_head.net.0.weight",
+    "sap_fuse_linear.net.3.weight",
+    "local_sem_head.net.3.bias",
+}
+
+
+def gen_nav(cfg):
+    print("fine-tune API (GlocalTextPathNavCMT)")
+    nav = build_ref_nav(cfg)
+    keys = sorted(nav.state_dict().keys())
+    B = 3
+    pb = synthetic.make_batch(cfg, "sap", B, seed=23, ragged=True)
+    arrs = {"seed": np.int64(23), "n_keys": np.int64(len(keys))}
+    with torch.no_grad():
+        txt_masks = torch.arange(pb["txt_ids"].shape[1])[None] < pb["txt_lens"][:, None]
+        txt = nav("language", {"txt_ids": pb["txt_ids"], "txt_masks": txt_masks})
+        arrs["txt_embeds_sub"] = sub(txt, 7)
+        # panorama: the LAST step of every sample
+        ends = np.cumsum(pb["traj_step_lens"]) - 1
+        pano_in = {"view_img_fts": pb["traj_view_img_fts"][ends], "obj_img_fts": None,
+                   "loc_fts": pb["traj_loc_fts"][ends], "nav_types": pb["traj_nav_types"][ends],
+                   "view_lens": pb["traj_vp_view_lens"][ends], "obj_lens": None}
+        pano, pmask = nav("panorama", pano_in)
+        arrs["pano_embeds_sub"] = sub(pano, 5)
+        arrs["pano_masks"] = npy(pmask)
+        # navigation: gmap_img_embeds are given (GraphMap averages them on the host in the agent)
+        G = int(pb["gmap_lens"].max())
+        g = torch.Generator().manual_seed(99)
+        gimg = torch.randn(B, G, 768, generator=g)
+        gimg[:, 0] = 0
+        gmasks = torch.arange(G)[None] < pb["gmap_lens"][:, None]
+        lifted = build_ref_pretrain_cached["m"].lift_splat(dict(pb))
+        nav_in = {
+            "txt_embeds": txt, "txt_masks": txt_masks, "gmap_img_embeds": gimg,
+            "gmap_step_ids": pb["gmap_step_ids"], "gmap_pos_fts": pb["gmap_pos_fts"], "gmap_masks": gmasks,
+            "gmap_pair_dists": pb["gmap_pair_dists"], "gmap_visited_masks": pb["gmap_visited_masks"],
+            "gmap_vpids": pb["gmap_vpids"],
+            "bev_fts": lifted["bev_fts"], "bev_pos_fts": lifted["bev_pos_fts"], "bev_masks": lifted["bev_masks"],
+            "bev_nav_masks": pb["bev_nav_masks"], "bev_cand_idxs": pb["bev_cand_idxs"],
+            "bev_cand_vpids": [[None] + c[-1] for c in pb["traj_cand_vpids"]],
+            "obj_embeds": None, "obj_masks": None,
+        }
+        out = nav("navigation", nav_in)
+        arrs.update(nav_gmap_embeds=npy(out["gmap_embeds"]), nav_global=npy(out["global_logits"]),
+                    nav_local=npy(out["local_logits"]), nav_fused=npy(out["fused_logits"]))
+    save("nav_tiny", **arrs)
+    with open(os.path.join(OUT, "nav_state_dict_keys.txt"), "w") as f:
+        for k in keys:
+            f.write(f"{k} {tuple(nav.state_dict()[k].shape)}\n")
+
+
+def gen_adamw():
+    print("AdamW trajectory (optim/adamw.py) + lr schedule (optim/sched.py)")
+    sys.path.insert(0, os.path.join(REF, "pretrain_src"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_adamw", os.path.join(REF, "pretrain_src/optim/adamw.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    spec2 = importlib.util.spec_from_file_location("ref_sched", os.path.join(REF, "pretrain_src/optim/sched.py"))
+    sched = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(sched)
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(257, generator=g)
+    grads = [torch.randn(257, generator=g) * (10.0 ** (k - 1)) for k in range(4)]
+    traj = {}
+    for wd in (0.01, 0.0):
+        p = torch.nn.Parameter(p0.clone())
+        opt = mod.AdamW([{"params": [p], "weight_decay": wd}], lr=5e-5, betas=(0.9, 0.98))
+        steps = []
+        for k, gr in enumerate(grads):
+            for grp in opt.param_groups:
+                grp["lr"] = 5e-5 * (k + 1) / 4
+            p.grad = gr.clone()
+            opt.step()
+            steps.append(npy(p).copy())
+        traj[f"wd{wd}"] = np.stack(steps)
+
+    class O:
+        learning_rate, warmup_steps, num_train_steps = 5e-5, 10000, 100000
+    lr_steps = np.array([0, 1, 5000, 9999, 10000, 10001, 55000, 99999, 100000, 100001])
+    lrs = np.array([sched.get_lr_sched(int(s), O) for s in lr_steps])
+    save("adamw", p0=npy(p0), grads=np.stack([npy(x) for x in grads]), lr_steps=lr_steps, lrs=lrs, **traj)
+
+
+def gen_keys(ref, tag):
+    with open(os.path.join(OUT, f"pretrain_state_dict_keys_{tag}.txt"), "w") as f:
+        for k, v in ref.state_dict().items():
+            f.write(f"{k} {tuple(v.shape)}\n")
+
+
+build_ref_pretrain_cached = {}
+
+
+def main():
+    assert os.path.isdir(REF), "the reference is only mounted in the build container"
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    _install_shims()
+
+    tiny = BevBertConfig.tiny()
+    ref = build_ref_pretrain(tiny)
+    build_ref_pretrain_cached["m"] = ref
+    gen_keys(ref, "tiny")
+    gen_splat(ref, tiny)
+    gen_tasks(ref, tiny, "tiny_b3_ragged", B=3, seed=7, ragged=True, with_grads=True)
+    gen_tasks(ref, tiny, "tiny_b2_fixed", B=2, seed=8, ragged=False, with_grads=False)
+    gen_nav(tiny)
+    gen_adamw()
+
+    full = BevBertConfig()
+    ref = build_ref_pretrain(full)
+    gen_keys(ref, "r2r")
+    gen_tasks(ref, full, "r2r_b2", B=2, seed=1000, ragged=False, with_grads=False)
+
+
+if __name__ == "__main__":
+    main()

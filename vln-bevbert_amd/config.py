@@ -1,0 +1,85 @@
+"""Model configuration for the BEVBert cross-modal hot path.
+
+Restates the constants of the reference's JSON configs (configs/r2r_model.json,
+configs/rxr_model.json, configs/rvr_model.json) as a plain attribute bag; the
+reference builds a transformers ``PretrainedConfig`` from those files
+(pretrain_src/train_r2r.py:102-113), here nothing depends on transformers.
+"""
+import json
+
+
+class BevBertConfig:
+    # configs/r2r_model.json (R2R pre-training defaults)
+    _DEFAULTS = dict(
+        hidden_size=768,
+        num_attention_heads=12,
+        intermediate_size=3072,
+        hidden_act="gelu",
+        hidden_dropout_prob=0.1,
+        attention_probs_dropout_prob=0.1,
+        pred_head_dropout_prob=0.1,
+        layer_norm_eps=1e-12,
+        max_position_embeddings=512,
+        type_vocab_size=2,
+        vocab_size=30522,
+        image_feat_size=512,
+        angle_feat_size=4,
+        obj_feat_size=0,
+        obj_prob_size=0,
+        num_l_layers=9,
+        num_x_layers=4,
+        num_pano_layers=2,
+        max_action_steps=100,
+        update_lang_bert=True,
+        use_lang2visn_attn=True,
+        graph_sprels=True,
+        glocal_fuse=True,
+        bev_dim=21,
+        bev_res=0.5,           # pretrain_src/model/pretrain_cmt.py:17
+        grid_feat_size=768,    # hard-coded nn.Linear(768, hidden): vilmodel.py:577
+        grid_hw=14,            # 14x14 ViT patch grid: pretrain_cmt.py:22-23
+        grid_views=12,
+        sem_classes=40,        # pretrain_cmt.py:68
+        feat_dropout=0.4,
+        output_attentions=False,
+        # fine-tune only (map_nav_src/models/vlnbert_init.py:57-76)
+        fix_lang_embedding=False,
+        fix_pano_embedding=False,
+        fix_local_branch=False,
+        # task selection (pretrain_src/train_r2r.py:108-112)
+        pretrain_tasks=("mlm", "sap", "masksem"),
+        sem_pred_token="cattn",
+    )
+
+    def __init__(self, **kw):
+        for k, v in self._DEFAULTS.items():
+            setattr(self, k, v)
+        for k, v in kw.items():
+            setattr(self, k, v)
+        self.pretrain_tasks = set(self.pretrain_tasks)
+
+    @classmethod
+    def from_json_file(cls, path, **kw):
+        with open(path) as f:
+            d = json.load(f)
+        d.update(kw)
+        return cls(**d)
+
+    @classmethod
+    def rxr(cls, **kw):
+        # configs/rxr_model.json: xlm-roberta vocabulary
+        return cls(vocab_size=250002, max_position_embeddings=514, **kw)
+
+    @classmethod
+    def tiny(cls, **kw):
+        """Small depth/vocab for golden fixtures and CPU tests (widths are kept:
+        768 is hard-coded in the reference's BEV embedding)."""
+        d = dict(num_l_layers=2, num_x_layers=2, num_pano_layers=1, vocab_size=1200,
+                 max_position_embeddings=128)
+        d.update(kw)
+        return cls(**d)
+
+    def to_dict(self):
+        d = {k: getattr(self, k) for k in self._DEFAULTS}
+        d["pretrain_tasks"] = sorted(self.pretrain_tasks)
+        return d
