@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- BEVBert pre-training throughput on MI355X (BASELINE.json metric: pre-train samples/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full optimisation step (lift+splat, forward, backward, gradient all-reduce, clip, AdamW) on one
+synthetic R2R-shaped batch per GPU: BASELINE.json configs[1] -- scripts/pt_r2r.bash shapes, batch 64 per GPU,
+autocast-style bf16 (fp32 masters), task mix mlm.5.sap.5.masksem.1, dropout 0.1 -- with inputs resident in HBM.
+Weak scaling: the per-GPU batch is fixed, ranks draw different batches (seed + rank), value = global samples / s.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  "roofline":     the dominant hand-written kernel, timed live with HIP events on the launching stream;
+  "cpu_baseline": the CPU oracle (oracle/bevbert_ref.py, a restatement pinned to the reference) doing the same
+                  fwd+bwd+AdamW on the host cores, on a bounded sample (rank 0, N = 1 only);
+  "kernels":      per-kernel-class time of one profiled step of each task (custom kernels vs library GEMMs).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=22)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE.json configs[1]: 64)")
+    ap.add_argument("--txt-len", type=int, default=80)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-pass", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def algorithmic_work(key, args, esize):
+    """(flops, bytes) one launch of a traced C-ABI call is worth ALGORITHMICALLY."""
+    if key.startswith("bevbert_attn_fwd"):
+        B, nh, Lq, Lk = args[8], args[9], args[10], args[11]
+        return 4.0 * B * nh * Lq * Lk * 64, (2 * Lq + 2 * Lk) * nh * 64 * B * esize
+    if key.startswith("bevbert_attn_bwd"):
+        B, nh, Lq, Lk = args[14], args[15], args[16], args[17]
+        return 10.0 * B * nh * Lq * Lk * 64, (4 * Lq + 4 * Lk) * nh * 64 * B * esize
+    if key == "bevbert_bias_dropout_residual_layernorm_fwd":
+        rows, H = args[9], args[10]
+        n_in = 1 + (args[2] is not None)
+        return 0.0, rows * H * esize * (n_in + 1 + (args[6] is not None and args[6] != args[0]))
+    if key == "bevbert_layernorm_bwd":
+        rows, H = args[11], args[12]
+        return 0.0, rows * H * esize * (2 + (args[5] is not None) + (args[6] is not None))
+    if key == "bevbert_bias_gelu_fwd":
+        return 0.0, args[3] * args[4] * esize * 2
+    if key == "bevbert_bias_gelu_bwd":
+        return 0.0, args[6] * args[7] * esize * 3
+    if key == "bevbert_colsum":
+        return 0.0, args[3] * args[4] * esize
+    if key == "bevbert_bev_splat_mean":
+        B, P, K, C = args[6], args[7], args[8], args[9]
+        in_size = {0: 4, 1: 2, 2: 2}[args[1]]
+        out_size = {0: 4, 1: 2, 2: 2}[args[5]]
+        return 0.0, B * (P * C * in_size + P * 4 + K * C * out_size + P * 1 + K * 41)
+    if key == "bevbert_adamw_step":
+        return 0.0, args[6] * (16 + 12 + 2)
+    if key == "bevbert_grad_norm_clip":
+        return 0.0, args[1] * 4
+    return 0.0, 0.0
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU is visible"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from vln_bevbert_amd import ops, synthetic
+    from vln_bevbert_amd.config import BevBertConfig
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from vln_bevbert_amd.train import PretrainTrainer, TaskSampler
+
+    cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    esize = 2 if a.dtype == "bf16" else 4
+    cfg = BevBertConfig()                                   # configs/r2r_model.json
+    torch.manual_seed(0)                                    # identical initial weights on every rank
+    model = GlocalTextPathCMTPreTraining(cfg)
+    arena = model.finalize(dev, cdt)
+    model.train()
+    model.set_dropout(0.1)                                  # train_r2r.py:157
+    trainer = PretrainTrainer(model, arena, rank=rank, world_size=world)
+    sampler = TaskSampler("mlm.5.sap.5.masksem.1", seed=0)
+
+    # resident synthetic batches: two per task and rank, drawn with seed 1000 + rank
+    batches = {t: [synthetic.batch_to(synthetic.make_batch(cfg, t, a.batch, seed=1000 + rank + 97 * j,
+                                                           txt_len=a.txt_len, sems_as="ids"), dev)
+                   for j in range(2)] for t in ("mlm", "sap", "masksem")}
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(n):
+        losses = []
+        for i in range(n):
+            t = sampler.next()
+            losses.append(trainer.step(t, batches[t][i % 2]))
+        return losses
+
+    run(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    losses = run(a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = a.steps * a.batch * world / dt
+
+    out = {
+        "metric": "pretrain_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "R2R pre-train step (lift+splat, fwd, bwd, all-reduce, clip, AdamW), "
+                               "scripts/pt_r2r.bash shapes: 36 views x 512, 5-step paths, 2352 grid points x 768 -> "
+                               f"21x21 BEV, {a.txt_len}-token text, task mix mlm.5.sap.5.masksem.1, dropout 0.1",
+                   "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                   "params_M": round(arena.n_params / 1e6, 1)},
+        "final_loss": round(float(losses[-1].item()), 4),
+    }
+
+    if rank == 0 and not a.no_kernel_pass:
+        # ---- per-kernel timing pass (not part of the timed region above): HIP events around every C-ABI launch
+        ops.TRACE = {}
+        prof_start = torch.cuda.Event(enable_timing=True)
+        prof_end = torch.cuda.Event(enable_timing=True)
+        prof_start.record()
+        for t in ("mlm", "sap", "masksem"):
+            trainer.step(t, batches[t][0])
+        prof_end.record()
+        torch.cuda.synchronize()
+        trace, ops.TRACE = ops.TRACE, None
+        total_ms = prof_start.elapsed_time(prof_end)
+        rows = {}
+        for key, evs in trace.items():
+            ms = [s.elapsed_time(e) for s, e, _ in evs]
+            fl = by = 0.0
+            for _, _, args in evs:
+                f, b = algorithmic_work(key, args, esize)
+                fl += f
+                by += b
+            rows[key] = {"launches": len(ms), "ms": round(sum(ms), 3), "avg_us": round(1000 * sum(ms) / len(ms), 2),
+                         "gflop": round(fl / 1e9, 2), "mb": round(by / 1e6, 2)}
+        custom_ms = sum(r["ms"] for r in rows.values())
+        out["kernels"] = {"profiled_steps": "1 x mlm + 1 x sap + 1 x masksem", "wall_ms": round(total_ms, 2),
+                          "custom_kernel_ms": round(custom_ms, 2),
+                          "library_gemm_and_other_ms": round(total_ms - custom_ms, 2),
+                          "by_kernel": dict(sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:12])}
+        dom_key, dom = max(rows.items(), key=lambda kv: kv[1]["ms"])
+        secs = dom["ms"] / 1e3
+        if dom["gflop"] > 0:
+            ach = dom["gflop"] / 1e3 / secs
+            out["roofline"] = {"kernel": dom_key, "bound": "mfma", "achieved": round(ach, 2),
+                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                               "avg_launch_us": dom["avg_us"], "launches": dom["launches"]}
+        else:
+            ach = dom["mb"] / 1e3 / secs
+            out["roofline"] = {"kernel": dom_key, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "avg_launch_us": dom["avg_us"], "launches": dom["launches"]}
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, a)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, a):
+    """The CPU oracle doing the same training step (fwd + bwd + AdamW, fp32, dropout off) on a bounded sample."""
+    from oracle import bevbert_ref as R
+    from vln_bevbert_amd import synthetic, weights
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    n = a.cpu_threads or os.cpu_count()
+    torch.set_num_threads(n)
+    shapes = {k: tuple(v.shape) for k, v in GlocalTextPathCMTPreTraining(cfg).state_dict().items()}
+    sd = {k: v.requires_grad_(True) for k, v in weights.fill_state_dict(shapes).items()}
+    params = list({id(v): v for v in sd.values()}.values())
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    B = 4
+    t_total, n_samples = 0.0, 0
+    for it, task in enumerate(("sap", "mlm", "sap", "mlm", "masksem")):
+        b = synthetic.make_batch(cfg, task, B, seed=4000 + it, txt_len=a.txt_len)
+        t0 = time.perf_counter()
+        loss = R.pretrain_forward(sd, cfg, b, task).mean()
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        with torch.no_grad():
+            for p, g, mm, vv in zip(params, grads, m, v):
+                if g is not None:
+                    R.adamw_step(p, g, mm, vv, it + 1, 5e-5, 0.01)
+        dt = time.perf_counter() - t0
+        if it > 0:                         # first iteration pages everything in
+            t_total += dt
+            n_samples += B
+    return {"value": round(n_samples / t_total, 3), "unit": "samples/s", "cores": n, "kind": "port",
+            "sample": f"4 steps (sap, mlm, sap, masksem) of batch {B}, same shapes, fp32, dropout off, "
+                      f"torch CPU with {n} threads; 1 untimed warm-up step"}
+
+
+if __name__ == "__main__":
+    main()

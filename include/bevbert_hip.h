@@ -1,0 +1,142 @@
+/* libbevbert_hip.so -- C ABI of the MI355X-native BEVBert cross-modal hot path (gfx950 only).
+ *
+ * The reference (MarSaKi/VLN-BEVBert) has no native/plugin layer: its hot path is Python nn.Modules over ATen,
+ * torch_scatter and nn.MultiheadAttention.  This header is the boundary a reference maintainer binds with ctypes
+ * (INTEGRATION.md shows the stubs); each entry names the reference code it replaces (paths under /root/reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host"; the caller owns all memory, nothing is allocated,
+ *     retained or freed here; no global state => re-entrant, thread-safe per stream;
+ *   - `stream` is a hipStream_t (PyTorch-ROCm: torch.cuda.current_stream().cuda_stream); launches are asynchronous;
+ *   - return value 0 = ok, <0 = error (-1 invalid argument, -2 launch failure, -3 unsupported); the message is
+ *     available from bevbert_last_error() (thread-local);
+ *   - dtype codes: 0 = float32, 1 = bfloat16, 2 = float16; parameters (bias, gamma, beta) and statistics are always
+ *     float32; arithmetic is float32 everywhere except the MFMA operands of the bf16 attention path;
+ *   - dropout masks are a pure function of (seed, offset + flat element index): backward entries regenerate the
+ *     forward's mask from the same (seed, offset) instead of storing it.
+ */
+#ifndef BEVBERT_HIP_H
+#define BEVBERT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+#define BEVBERT_F32 0
+#define BEVBERT_BF16 1
+#define BEVBERT_F16 2
+
+const char* bevbert_last_error(void);
+int bevbert_version(void); /* major*10000 + minor*100 + patch */
+const char* bevbert_arch(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K1  lift + BEV binning + deterministic scatter-mean.
+ * Replaces PointCloud.forward (pretrain_src/model/bev_utils.py:349-378), the world->ego transform of
+ * GlocalTextPathCMTPreTraining.lift_splat (pretrain_src/model/pretrain_cmt.py:124-137), and
+ * PointCloud.project_bev + torch_scatter.scatter_mean (bev_utils.py:381-430; fine-tune twin
+ * map_nav_src/models/bev_utils.py:381-417, map_nav_src/r2r/agent.py:143-192).
+ *
+ * bevbert_bev_lift_bin: depths (B,V,hw,hw) stored /depth_scale, T_c2w (B,V,4,4), T_w2c (B,4,4), S_w2c (B,3),
+ *   pix_scale (hw) = ((u + .5 - c)/f) fp32.  Outputs: cell (B,P) int32 (cell id = dim*z + x, -1 = dropped),
+ *   order (B,P) int32 (point ids sorted by (cell, id)), cell_start (B, dim*dim+1) int32.  P = V*hw*hw <= 8192.
+ * bevbert_bev_bin_points: same outputs from ready-made ego-frame points (B,P,3) + drop mask (B,P) uint8.
+ * bevbert_bev_splat_mean: out[b,cell,:] = mean of feat[b,p,:] over the cell's points (0 if empty);
+ *   semantics: sem_ids (B,P) uint8 class ids  XOR  sem_dense (B,P,S) float64 one-hot (the reference's format);
+ *   out_sem (B,K,S) uint8 {0,1}, out_sem_mask (B,K) uint8; pass out_sem = NULL to skip semantics. */
+int bevbert_bev_lift_bin(const float* depths, const float* T_c2w, const float* T_w2c, const float* S_w2c,
+                         const float* pix_scale, int B, int V, int hw, float depth_scale, int dim, float res,
+                         float y_clip, int* cell, int* order, int* cell_start, hipStream_t stream);
+int bevbert_bev_bin_points(const float* points, const uint8_t* drop_mask, int B, int P, int dim, float res,
+                           float y_clip, int* cell, int* order, int* cell_start, hipStream_t stream);
+int bevbert_bev_splat_mean(const void* feat, int feat_dtype, const int* order, const int* cell_start, void* out,
+                           int out_dtype, int B, int P, int K, int C, const uint8_t* sem_ids, const double* sem_dense,
+                           int S, uint8_t* out_sem, uint8_t* out_sem_mask, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K2  fused multi-head attention (head_dim 64).
+ * Replaces BertSelfAttention.forward (pretrain_src/model/vilmodel.py:103-141), BertOutAttention.forward
+ * (vilmodel.py:325-352) and nn.MultiheadAttention inside TransformerEncoderLayer.forward_pre
+ * (pretrain_src/model/transformer.py:170-182): softmax(Q K^T * scale + key_mask[b,k] + bias[b,q,k]) V with dropout
+ * on the probabilities.  q/k/v/o are (B, L, nh*64) views with row/batch strides (elements):
+ *   strides[8] (host) = {ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso}; dq/dk/dv use the q/k/v strides, dout the o strides.
+ * key_mask (B,Lk) and bias (B,Lq,Lk) are additive fp32 (NULL = none; -inf allowed); lse (B,nh,Lq) fp32.
+ * impl: 0 = auto (bf16 -> MFMA kernels, f32 -> exact fp32 kernels), 1 = exact kernels, 2 = MFMA kernels.
+ * bwd: delta_ws is a (B,nh,Lq) fp32 scratch; dbias (B,Lq,Lk) fp32 is ACCUMULATED (sum over heads), NULL to skip. */
+int bevbert_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask,
+                     const float* bias, const int64_t* strides, int B, int nh, int Lq, int Lk, int head_dim,
+                     float scale, int dtype, int impl, float drop_p, uint64_t seed, uint64_t offset,
+                     hipStream_t stream);
+int bevbert_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                     float* delta_ws, void* dq, void* dk, void* dv, float* dbias, const float* key_mask,
+                     const float* bias, const int64_t* strides, int B, int nh, int Lq, int Lk, int head_dim,
+                     float scale, int dtype, int impl, float drop_p, uint64_t seed, uint64_t offset,
+                     hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K3  y = LayerNorm(dropout(x + bias) + residual).
+ * Replaces BertSelfOutput.forward / BertOutput.forward (vilmodel.py:150-154,189-193) and every bare LayerNorm of the
+ * path (bias/residual NULL).  z_out (optional) receives the pre-norm sum for the backward; mean/rstd optional.
+ * bwd: dz = grad wrt the pre-norm sum (= grad of residual), dx = grad wrt the dense output (dz through the dropout
+ * mask; pass NULL when p == 0 and use dz); dgamma/dbeta/dbias (H) fp32 are written or accumulated (accumulate != 0);
+ * workspace: bevbert_colsum_workspace_floats(3*H) floats. */
+int bevbert_bias_dropout_residual_layernorm_fwd(const void* x, const float* bias, const void* residual,
+                                                const float* gamma, const float* beta, void* y, void* z_out,
+                                                float* mean, float* rstd, int rows, int H, float eps, int dtype,
+                                                float drop_p, uint64_t seed, uint64_t offset, hipStream_t stream);
+int bevbert_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                          void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, float* workspace, int rows,
+                          int H, int dtype, float drop_p, uint64_t seed, uint64_t offset, int accumulate,
+                          hipStream_t stream);
+int64_t bevbert_colsum_workspace_floats(int total_cols);
+
+/* K5  BertEmbeddings.forward (vilmodel.py:62-77): y = LayerNorm(word[ids] + pos[row % L] + type_row) (+dropout). */
+int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const void* pos, const void* type_row,
+                                    const float* gamma, const float* beta, void* y, void* z_out, float* mean,
+                                    float* rstd, int rows, int L, int H, float eps, int dtype, float drop_p,
+                                    uint64_t seed, uint64_t offset, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K4  y = gelu_erf(x + bias)  -- BertIntermediate.forward + gelu (vilmodel.py:31-37,177-180); F.gelu in the pano
+ * encoder (transformer.py:178).  bwd: dx = dy * gelu'(x + bias) (dx may alias dy), dbias (C) written/accumulated. */
+int bevbert_bias_gelu_fwd(const void* x, const float* bias, void* y, int rows, int C, int dtype, hipStream_t stream);
+int bevbert_bias_gelu_bwd(const void* dy, const void* x, const float* bias, void* dx, float* dbias, float* workspace,
+                          int rows, int C, int dtype, int accumulate, hipStream_t stream);
+/* out[c] (+)= sum_r dy[r,c]: bias gradients of the projection GEMMs (autograd's grad.sum(0) in the reference). */
+int bevbert_colsum(const void* dy, float* out, float* workspace, int rows, int C, int dtype, int accumulate,
+                   hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K6  out[r] = sum_e w[e] * src[idx[e]], e in [rowptr[r], rowptr[r+1])  -- GlobalMapEncoder._aggregate_gmap_features
+ * (vilmodel.py:632-666) with the visited/unvisited bookkeeping turned into a CSR on the host; the backward is the
+ * same call on the transposed CSR. */
+int bevbert_segment_wsum(const void* src, const int* rowptr, const int* idx, const float* w, void* out, int out_rows,
+                         int H, int dtype, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K7  flat-arena optimiser.  All parameters / gradients / Adam moments live in contiguous fp32 arenas whose tensors
+ * start on 1024-element boundaries; chunk_flags[n/1024]: bit0 = weight decay applies, bit1 = tensor has had a grad.
+ * bevbert_grad_norm_clip: scalars[0] = ||pre_scale * g||_2, scalars[1] = pre_scale * min(1, max_norm/(norm+1e-6))
+ *   (torch.nn.utils.clip_grad_norm_ as called at pretrain_src/train_r2r.py:295-306; pre_scale folds DDP's 1/world).
+ *   partials: 1024 floats scratch.  No host sync: adamw_step reads the multiplier from device memory.
+ * bevbert_adamw_step: AdamW.step (pretrain_src/optim/adamw.py:53-112): bias-corrected Adam, decoupled decay applied
+ *   after the update; optionally refreshes the bf16 shadow copy of the parameters in the same pass. */
+int bevbert_grad_norm_clip(const float* grads, int64_t n, float pre_scale, float max_norm, float* partials,
+                           float* scalars, hipStream_t stream);
+int bevbert_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* params_bf16,
+                       const uint8_t* chunk_flags, int64_t n, const float* grad_scale_dev, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int64_t step, hipStream_t stream);
+int bevbert_cast_f32(const float* src, void* dst, int64_t n, int dst_dtype, hipStream_t stream);
+
+/* test hook: keep-mask (uint8) the kernels derive for n consecutive elements starting at `offset` */
+int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p, uint64_t seed, uint64_t offset,
+                              hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVBERT_HIP_H */

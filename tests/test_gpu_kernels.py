@@ -1,0 +1,409 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point against the CPU oracle / an fp32 torch reference.
+
+Tolerances (north_star): 1e-3 absolute for fp32 paths (observed ~1e-6), bf16 paths are judged relative to the
+output's absolute maximum (1e-2), integer / index work is bit exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bevbert_ref as R
+from tests.helpers import load_golden
+from vln_bevbert_amd import synthetic
+from vln_bevbert_amd.config import BevBertConfig
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vln_bevbert_amd import lib, ops as _ops
+    lib.load()          # raises (does not skip) when the HIP library is missing on a GPU box
+    return _ops
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+# ----------------------------------------------------------------------------- K1 splat
+@pytest.mark.parametrize("B,ragged", [(2, True), (5, False)])
+def test_lift_bin_cells_bit_exact(ops, B, ragged):
+    cfg = BevBertConfig()
+    b = synthetic.make_batch(cfg, "sap", B, seed=11 + B, ragged=ragged)
+    pc, nod = R.lift_points(b["depths"], b["T_c2w"], b["T_w2c"], b["S_w2c"])
+    want = R.cell_index(pc, nod)
+    g = synthetic.batch_to(b, DEV)
+    pix = ops.pixel_scale(14, DEV)
+    cell, order, start = ops.bev_lift_bin(g["depths"], g["T_c2w"], g["T_w2c"], g["S_w2c"], pix, 21, 0.5)
+    assert torch.equal(cell.cpu().long(), want), "cell ids differ from the oracle"
+    # the order array is a stable sort by cell
+    cell_c, order_c, start_c = cell.cpu().numpy(), order.cpu().numpy(), start.cpu().numpy()
+    for i in range(B):
+        kept = np.flatnonzero(cell_c[i] >= 0)
+        exp = kept[np.argsort(cell_c[i][kept], kind="stable")]
+        assert start_c[i, -1] == len(kept)
+        assert np.array_equal(order_c[i, :len(kept)], exp)
+        counts = np.bincount(cell_c[i][kept], minlength=441)
+        assert np.array_equal(np.diff(start_c[i]), counts)
+
+
+def test_splat_mean_bit_exact_and_semantics(ops):
+    cfg = BevBertConfig()
+    B = 3
+    b = synthetic.make_batch(cfg, "sap", B, seed=21, ragged=True)
+    want = R.lift_splat(cfg, b)
+    g = synthetic.batch_to(b, DEV)
+    pix = ops.pixel_scale(14, DEV)
+    _, order, start = ops.bev_lift_bin(g["depths"], g["T_c2w"], g["T_w2c"], g["S_w2c"], pix, 21, 0.5)
+    feat = g["rgbs"].reshape(B, -1, 768)
+    out, sem, semm = ops.bev_splat_mean(feat, order, start, 441, sems=g["sems"].reshape(B, -1, 40))
+    assert torch.equal(out.cpu(), want["bev_fts"]), "scatter-mean is not bit-identical to the oracle"
+    assert torch.equal(sem.cpu(), want["bev_sems"].to(torch.uint8))
+    assert torch.equal(semm.cpu().bool(), want["bev_sem_masks"])
+    # compact class ids give the same pooled semantics
+    ids = synthetic.make_batch(cfg, "sap", B, seed=21, ragged=True, sems_as="ids")["sems"].to(DEV)
+    _, sem2, semm2 = ops.bev_splat_mean(feat, order, start, 441, sems=ids)
+    assert torch.equal(sem2, sem) and torch.equal(semm2, semm)
+    # fp16 / bf16 feature stores (the on-disk format is fp16): mean of the rounded inputs, fp32 accumulate
+    for dt in (torch.float16, torch.bfloat16):
+        o, _, _ = ops.bev_splat_mean(feat.to(dt), order, start, 441, out_dtype=torch.float32)
+        ref = R.lift_splat(cfg, dict(b, rgbs=b["rgbs"].to(dt).float()))["bev_fts"]
+        assert torch.equal(o.cpu(), ref)
+
+
+def test_splat_golden_edge_cases(ops):
+    gld = load_golden("splat_edge")
+    pts = torch.from_numpy(gld["pts"])[None].to(DEV)
+    nod = torch.from_numpy(gld["no_depth"]).to(DEV)
+    feat = torch.from_numpy(gld["feat"]).to(DEV)
+    cell, order, start = ops.bev_bin_points(pts, nod, 21, 0.5)
+    out, sem, semm = ops.bev_splat_mean(feat, order, start, 441, sems=torch.from_numpy(gld["sem_ids"]).to(DEV).to(torch.uint8))
+    assert np.array_equal(out.cpu().numpy(), gld["bev"])
+    assert np.array_equal(sem.cpu().numpy(), gld["bev_sems"])
+    assert np.array_equal(semm.cpu().numpy().astype(bool), gld["bev_sem_masks"])
+    c = cell.cpu()[0]
+    assert c[0] == -1 and c[1] == 220 and c[7] == 230 and c[8] == -1 and c[9] == 210 and c[10] == -1
+
+
+def test_splat_full_size_properties(ops):
+    """BASELINE.json full size (B=64): size-independent checks -- every kept point lands in exactly one cell list,
+    cell means reproduce the feature sum, empty cells are exactly zero."""
+    cfg = BevBertConfig()
+    B = 64
+    b = synthetic.batch_to(synthetic.make_batch(cfg, "sap", B, seed=77, sems_as="ids"), DEV)
+    pix = ops.pixel_scale(14, DEV)
+    cell, order, start = ops.bev_lift_bin(b["depths"], b["T_c2w"], b["T_w2c"], b["S_w2c"], pix, 21, 0.5)
+    feat = b["rgbs"].reshape(B, -1, 768)
+    out, sem, semm = ops.bev_splat_mean(feat, order, start, 441, sems=b["sems"])
+    counts = (start[:, 1:] - start[:, :-1]).long()
+    kept = (cell >= 0)
+    assert torch.equal(counts.sum(1), kept.sum(1))
+    # sum_c count_c * mean_c == sum of kept features (fp64 check of a checksum)
+    lhs = (out.double() * counts[..., None]).sum((1, 2))
+    rhs = (feat.double() * kept[..., None]).sum((1, 2))
+    assert float(((lhs - rhs).abs() / rhs.abs().clamp_min(1)).max()) < 1e-4
+    assert float(out[counts == 0].abs().max()) == 0.0
+    assert torch.equal(semm.bool(), counts > 0)
+    occ = float((counts > 0).float().mean())
+    assert 0.5 < occ <= 1.0
+
+
+# ----------------------------------------------------------------------------- K3 / K4 / K5 row kernels
+def _ln_ref(x, bias, res, g, b, eps, keep=None, p=0.0):
+    z = x.float()
+    if bias is not None:
+        z = z + bias
+    if keep is not None:
+        z = torch.where(keep, z / (1 - p), torch.zeros_like(z))
+    if res is not None:
+        z = z + res.float()
+    return torch.nn.functional.layer_norm(z, (z.shape[-1],), g, b, eps), z
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_res,p", [(True, 0.0), (True, 0.1), (False, 0.0), (False, 0.3)])
+def test_layernorm_fwd_bwd(ops, dtype, with_res, p):
+    torch.manual_seed(0)
+    rows, H = 517, 768
+    x = torch.randn(rows, H, device=DEV).to(dtype)
+    res = torch.randn(rows, H, device=DEV).to(dtype) if with_res else None
+    bias = (0.1 * torch.randn(H, device=DEV)).requires_grad_(True)
+    gam = (1 + 0.1 * torch.randn(H, device=DEV)).requires_grad_(True)
+    bet = (0.1 * torch.randn(H, device=DEV)).requires_grad_(True)
+    xr = x.clone().float().requires_grad_(True)
+    rr = res.clone().float().requires_grad_(True) if with_res else None
+    ops.RT.new_step(1234)
+    xin = x.clone().requires_grad_(True)
+    rin = res.clone().requires_grad_(True) if with_res else None
+    y = ops.bias_dropout_residual_layernorm(xin, bias, rin, gam, bet, 1e-12, p, training=True, inplace_z=False)
+    keep = ops.dropout_keep_mask(rows * H, p, 1234, 0, DEV).view(rows, H) if p > 0 else None
+    if keep is not None:
+        assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+    bias_r, gam_r, bet_r = (t.detach().clone().requires_grad_(True) for t in (bias, gam, bet))
+    yr, _ = _ln_ref(xr, bias_r, rr, gam_r, bet_r, 1e-12, keep, p)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert float((y.float() - yr).abs().max()) < tol
+    dy = torch.randn(rows, H, device=DEV)
+    y.backward(dy.to(dtype))
+    yr.backward(dy.to(dtype).float())
+    gt = 1e-3 if dtype == torch.float32 else 3e-2
+    assert rel_err(xin.grad, xr.grad) < gt
+    if with_res:
+        assert rel_err(rin.grad, rr.grad) < gt
+    assert rel_err(gam.grad, gam_r.grad) < gt
+    assert rel_err(bet.grad, bet_r.grad) < gt
+    assert rel_err(bias.grad, bias_r.grad) < gt
+
+
+@pytest.mark.parametrize("eps", [1e-12, 1e-5])
+def test_plain_layernorm_matches_torch(ops, eps):
+    torch.manual_seed(1)
+    x = torch.randn(4, 37, 768, device=DEV, requires_grad=True)
+    g = torch.randn(768, device=DEV, requires_grad=True)
+    b = torch.randn(768, device=DEV, requires_grad=True)
+    y = ops.layernorm(x, g, b, eps)
+    x2, g2, b2 = (t.detach().clone().requires_grad_(True) for t in (x, g, b))
+    y2 = torch.nn.functional.layer_norm(x2, (768,), g2, b2, eps)
+    assert float((y - y2).abs().max()) < 1e-4
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    y2.backward(dy)
+    assert rel_err(x.grad, x2.grad) < 1e-4 and rel_err(g.grad, g2.grad) < 1e-4 and rel_err(b.grad, b2.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_gelu_fwd_bwd(ops, dtype):
+    torch.manual_seed(2)
+    rows, C = 333, 3072
+    x = (2 * torch.randn(rows, C, device=DEV)).to(dtype).requires_grad_(True)
+    bias = torch.randn(C, device=DEV, requires_grad=True)
+    y = ops.bias_gelu(x, bias)
+    xr = x.detach().float().requires_grad_(True)
+    br = bias.detach().clone().requires_grad_(True)
+    yr = R.gelu_erf(xr + br)
+    assert float((y.float() - yr).abs().max()) < (1e-5 if dtype == torch.float32 else 3e-2)
+    dy = torch.randn(rows, C, device=DEV).to(dtype)
+    y.backward(dy)
+    yr.backward(dy.float())
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(x.grad, xr.grad) < tol
+    assert rel_err(bias.grad, br.grad) < tol
+
+
+def test_embed_sum_layernorm(ops):
+    torch.manual_seed(3)
+    V, H, B, L = 500, 768, 3, 17
+    word = torch.randn(V, H, device=DEV, requires_grad=True)
+    pos = torch.randn(64, H, device=DEV, requires_grad=True)
+    typ = torch.randn(2, H, device=DEV, requires_grad=True)
+    g = torch.randn(H, device=DEV, requires_grad=True)
+    b = torch.randn(H, device=DEV, requires_grad=True)
+    ids = torch.randint(0, V, (B, L), device=DEV)
+    ids[0, :3] = 7                       # repeated ids: the gradient must accumulate
+    y = ops.embed_sum_layernorm(ids, word, pos, typ, g, b, 1e-12, 0)
+    ref_in = [t.detach().clone().requires_grad_(True) for t in (word, pos, typ, g, b)]
+    w2, p2, t2, g2, b2 = ref_in
+    yr = torch.nn.functional.layer_norm(w2[ids] + p2[:L][None] + t2[0], (H,), g2, b2, 1e-12)
+    assert float((y - yr).abs().max()) < 1e-4
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    yr.backward(dy)
+    for a_, r_ in zip((word, pos, typ, g, b), ref_in):
+        assert rel_err(a_.grad, r_.grad) < 1e-4
+
+
+def test_segment_wsum_matches_oracle_aggregation(ops):
+    from vln_bevbert_amd.vilmodel import build_gmap_csr
+    cfg = BevBertConfig()
+    b = synthetic.make_batch(cfg, "sap", 4, seed=31, ragged=True)
+    T, V = b["traj_view_img_fts"].shape[:2]
+    torch.manual_seed(4)
+    emb = torch.randn(T, V, 768)
+    masks = R.seq_mask(b["traj_vp_view_lens"], V)
+    want = R.aggregate_gmap(emb, masks, b["traj_vp_view_lens"], b["traj_step_lens"], b["traj_vpids"],
+                            b["traj_cand_vpids"], b["gmap_vpids"])
+    csr, G = build_gmap_csr(b["traj_step_lens"], b["traj_vp_view_lens"].tolist(), b["traj_vpids"],
+                            b["traj_cand_vpids"], b["gmap_vpids"], V, DEV)
+    src = emb.reshape(-1, 768).to(DEV).requires_grad_(True)
+    got = ops.segment_wsum(src, csr).view(4, G, 768)
+    assert float((got.cpu() - want).abs().max()) < 1e-5
+    dy = torch.randn_like(got)
+    got.backward(dy)
+    e2 = emb.clone().requires_grad_(True)
+    R.aggregate_gmap(e2, masks, b["traj_vp_view_lens"], b["traj_step_lens"], b["traj_vpids"], b["traj_cand_vpids"],
+                     b["gmap_vpids"]).backward(dy.cpu())
+    assert float((src.grad.cpu().view_as(e2) - e2.grad).abs().max()) < 1e-5
+
+
+# ----------------------------------------------------------------------------- K2 attention
+def _attn_ref(q, k, v, key_mask, bias, nh, keep=None, p=0.0):
+    """fp32 reference = oracle's attention math on already-projected Q/K/V (vilmodel.py:116-137)."""
+    B, Lq, H = q.shape
+    d = H // nh
+    hq = q.view(B, Lq, nh, d).permute(0, 2, 1, 3)
+    hk = k.view(B, -1, nh, d).permute(0, 2, 1, 3)
+    hv = v.view(B, -1, nh, d).permute(0, 2, 1, 3)
+    s = hq @ hk.transpose(-1, -2) / math.sqrt(d)
+    if key_mask is not None:
+        s = s + key_mask[:, None, None, :]
+    if bias is not None:
+        s = s + bias[:, None]
+    pr = torch.softmax(s, -1)
+    if keep is not None:
+        pr = torch.where(keep, pr / (1 - p), torch.zeros_like(pr))
+    return (pr @ hv).permute(0, 2, 1, 3).reshape(B, Lq, H)
+
+
+ATTN_CASES = [
+    # B, Lq, Lk, mask kind, bias
+    (2, 441, 441, None, False),        # BEV self-attention
+    (2, 441, 80, "neg", False),        # BEV -> text cross-attention
+    (3, 17, 17, "neg", True),          # gmap self-attention with graph bias
+    (5, 38, 38, "inf", False),         # panorama encoder, boolean key padding
+    (2, 80, 441, None, False),         # MLM: text -> BEV
+    (2, 80, 80, "neg", False),         # text self-attention
+    (1, 130, 200, "neg", True),        # odd sizes, RxR-length text
+]
+
+
+def _make_attn_inputs(B, Lq, Lk, mask_kind, with_bias, dtype, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    nh, H = 12, 768
+    q = torch.randn(B, Lq, H, generator=g).to(DEV).to(dtype)
+    k = torch.randn(B, Lk, H, generator=g).to(DEV).to(dtype)
+    v = torch.randn(B, Lk, H, generator=g).to(DEV).to(dtype)
+    km = None
+    if mask_kind is not None:
+        lens = torch.randint(max(1, Lk // 2), Lk + 1, (B,), generator=g)
+        lens[0] = Lk
+        valid = torch.arange(Lk)[None] < lens[:, None]
+        val = -10000.0 if mask_kind == "neg" else float("-inf")
+        km = torch.zeros(B, Lk).masked_fill(~valid, val).to(DEV)
+    bias = (0.5 * torch.randn(B, Lq, Lk, generator=g)).to(DEV) if with_bias else None
+    return q, k, v, km, bias, nh
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+@pytest.mark.parametrize("impl,dtype", [(1, torch.float32), (2, torch.bfloat16), (1, torch.bfloat16)])
+def test_attention_fwd_bwd(ops, case, impl, dtype):
+    B, Lq, Lk, mk, wb = case
+    q, k, v, km, bias, nh = _make_attn_inputs(B, Lq, Lk, mk, wb, dtype)
+    qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
+    bi = bias.clone().requires_grad_(True) if wb else None
+    o = ops.attention(qi, ki, vi, km, bi, nh, impl=impl)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    br = bias.clone().requires_grad_(True) if wb else None
+    orf = _attn_ref(qr, kr, vr, km, br, nh)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    scale = float(orf.abs().max())
+    assert float((o.float() - orf).abs().max()) < tol * max(1.0, scale), "forward"
+    do = torch.randn(B, Lq, 768, device=DEV).to(dtype)
+    o.backward(do)
+    orf.backward(do.float())
+    gt = 1e-3 if dtype == torch.float32 else 2.5e-2
+    assert rel_err(qi.grad, qr.grad) < gt, "dq"
+    assert rel_err(ki.grad, kr.grad) < gt, "dk"
+    assert rel_err(vi.grad, vr.grad) < gt, "dv"
+    if wb:
+        assert rel_err(bi.grad, br.grad) < gt, "dbias"
+
+
+@pytest.mark.parametrize("impl,dtype", [(1, torch.float32), (2, torch.bfloat16)])
+def test_attention_dropout_matches_exported_mask(ops, impl, dtype):
+    B, Lq, Lk, p = 2, 100, 140, 0.1
+    q, k, v, km, _, nh = _make_attn_inputs(B, Lq, Lk, "neg", False, dtype, seed=5)
+    ops.RT.new_step(99)
+    qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o = ops._Attention.apply("sep", qi, ki, vi, km, None, nh, p, impl)
+    keep = ops.dropout_keep_mask(B * nh * Lq * Lk, p, 99, 0, DEV).view(B, nh, Lq, Lk)
+    assert abs(float(keep.float().mean()) - 0.9) < 0.01
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    orf = _attn_ref(qr, kr, vr, km, None, nh, keep, p)
+    tol = 1e-4 if dtype == torch.float32 else 1.5e-2
+    assert float((o.float() - orf).abs().max()) < tol * max(1.0, float(orf.abs().max()))
+    do = torch.randn_like(orf).to(dtype)
+    o.backward(do)
+    orf.backward(do.float())
+    gt = 1e-3 if dtype == torch.float32 else 3e-2
+    assert rel_err(qi.grad, qr.grad) < gt and rel_err(ki.grad, kr.grad) < gt and rel_err(vi.grad, vr.grad) < gt
+
+
+def test_attention_packed_layouts(ops):
+    """Packed QKV / KV operands (the layouts the model uses) give the same result as separate tensors."""
+    B, L, H, nh = 2, 77, 768, 12
+    torch.manual_seed(6)
+    qkv = torch.randn(B, L, 3 * H, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    o1 = ops.attention_self(qkv, None, None, nh)
+    q, k, v = (qkv.detach()[..., i * H:(i + 1) * H].contiguous().requires_grad_(True) for i in range(3))
+    o2 = ops.attention(q, k, v, None, None, nh)
+    assert torch.equal(o1, o2)
+    do = torch.randn_like(o1)
+    o1.backward(do)
+    o2.backward(do)
+    assert torch.equal(qkv.grad[..., :H], q.grad) and torch.equal(qkv.grad[..., 2 * H:], v.grad)
+
+
+def test_attention_full_size_softmax_properties(ops):
+    """BASELINE.json full size (B=64, BEV self-attention): O rows are convex combinations of V rows
+    (V = const -> O = const), and lse matches an fp32 recomputation on a slice."""
+    B, L, nh, H = 64, 441, 12, 768
+    torch.manual_seed(7)
+    q = torch.randn(B, L, H, device=DEV).to(torch.bfloat16)
+    k = torch.randn(B, L, H, device=DEV).to(torch.bfloat16)
+    v = torch.full((B, L, H), 0.5, device=DEV).to(torch.bfloat16)
+    o = ops.attention(q, k, v, None, None, nh)
+    assert float((o.float() - 0.5).abs().max()) < 4e-3
+    v = torch.randn(B, L, H, device=DEV).to(torch.bfloat16)
+    o = ops.attention(q, k, v, None, None, nh)
+    ref = _attn_ref(q[:2].float(), k[:2].float(), v[:2].float(), None, None, nh)
+    assert float((o[:2].float() - ref).abs().max()) < 1e-2 * float(ref.abs().max())
+
+
+# ----------------------------------------------------------------------------- K7 optimiser
+def test_adamw_arena_matches_oracle_and_golden(ops):
+    from vln_bevbert_amd.arena import ParamArena
+    gld = load_golden("adamw")
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.from_numpy(gld["p0"]).clone())            # decayed (no "bias" in name)
+            self.bias = torch.nn.Parameter(torch.from_numpy(gld["p0"]).clone())         # not decayed
+            self.never = torch.nn.Parameter(torch.ones(5))                              # never receives a gradient
+
+    m = M()
+    arena = ParamArena(m, DEV, torch.bfloat16)
+    for k in range(4):
+        arena.zero_grad()
+        g = torch.from_numpy(gld["grads"][k]).to(DEV)
+        m.w.main_grad.add_(g)
+        m.bias.main_grad.add_(g)
+        arena.touch(m.w)
+        arena.touch(m.bias)
+        arena.clip_and_step(5e-5 * (k + 1) / 4, (0.9, 0.98), 1e-6, 0.01, max_norm=None)
+        assert np.allclose(m.w.detach().cpu().numpy(), gld["wd0.01"][k], rtol=2e-6, atol=1e-7)
+        assert np.allclose(m.bias.detach().cpu().numpy(), gld["wd0.0"][k], rtol=2e-6, atol=1e-7)
+        assert torch.equal(m.w.compute.float(), m.w.detach().to(torch.bfloat16).float())    # shadow refreshed in-pass
+    assert torch.equal(m.never.detach().cpu(), torch.ones(5))                           # .grad None => untouched
+
+
+def test_grad_clip_coefficient(ops):
+    from vln_bevbert_amd.arena import ParamArena
+    m = torch.nn.Linear(300, 7)
+    arena = ParamArena(m, DEV, torch.float32)
+    g = torch.randn_like(arena.grads)
+    arena.grads.copy_(g)
+    for p in m.parameters():
+        arena.touch(p)
+    arena.clip_and_step(0.0, max_norm=5.0, grad_pre_scale=0.5)
+    norm = float((0.5 * g).double().norm())
+    assert abs(float(arena.grad_norm()) - norm) < 1e-3 * norm
+    coef = float(arena._scalars[1])
+    assert abs(coef - 0.5 * min(1.0, 5.0 / (norm + 1e-6))) < 1e-6

@@ -1,0 +1,241 @@
+"""End-to-end parity of the HIP path on the MI355X: the product model (vln_bevbert_amd) against the golden vectors
+captured from the reference (tests/golden/*.npz) and against the CPU oracle, forward and backward, fp32 and bf16."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bevbert_ref as R
+from tests.helpers import load_golden, max_abs, rule_state_dict, sub
+from vln_bevbert_amd import synthetic
+from vln_bevbert_amd.config import BevBertConfig
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FP32_TOL = 1e-3          # north_star: "within 1e-3 fp32"
+
+
+def bf16_close(got, want, what):
+    """north_star "1e-2 bf16", read as SURVEY section 7 fixes it: mean-abs error relative to the output's abs-max
+    <= 1e-2 (the reference's own autocast-bf16 forward sits at ~1e-3 by this measure), and max-abs <= 6e-2 * absmax."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    fin = np.isfinite(want)
+    assert (np.isfinite(got) == fin).all(), what
+    scale = max(1e-6, float(np.abs(want[fin]).max()))
+    err = np.abs(got[fin] - want[fin])
+    assert err.mean() / scale < 1e-2 and err.max() / scale < 6e-2, (what, err.mean() / scale, err.max() / scale)
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vln_bevbert_amd import lib
+    lib.load()
+    return True
+
+
+def build(cfg, keys_file, dtype, nav=False):
+    from vln_bevbert_amd.nav_model import GlocalTextPathNavCMT
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    m = (GlocalTextPathNavCMT if nav else GlocalTextPathCMTPreTraining)(cfg)
+    m.load_state_dict(rule_state_dict(keys_file))
+    if not nav:
+        m.tie_weights()
+    arena = m.finalize(DEV, dtype)
+    return m.eval(), arena
+
+
+def _check_tasks(env, cfg, tag, keys_file, dtype, check_grads=False):
+    g = load_golden(f"tasks_{tag}")
+    B, seed, ragged = int(g["B"]), int(g["seed"]), bool(g["ragged"])
+    model, arena = build(cfg, keys_file, dtype)
+    fp32 = dtype == torch.float32
+
+    def cmp(got, key, step=None):
+        got = got.detach().float().cpu()
+        ref = g[key]
+        got = sub(got, step) if step else got.numpy()
+        if fp32:
+            assert max_abs(got, ref) < FP32_TOL, (key, max_abs(got, ref))
+        else:
+            bf16_close(got, ref, key)
+
+    mk = lambda task: synthetic.batch_to(synthetic.make_batch(cfg, task, B, seed=seed, ragged=ragged), DEV)
+    with torch.no_grad():
+        cmp(model(mk("mlm"), "mlm"), "mlm_loss")
+        cmp(model(mk("mlm"), "mlm", compute_loss=False), "mlm_scores_sub", 13)
+        cmp(model(mk("sap"), "sap"), "sap_loss")
+        gl, ll, fl, _, _ = model(mk("sap"), "sap", compute_loss=False)
+        cmp(gl, "sap_global"); cmp(ll, "sap_local"); cmp(fl, "sap_fused")
+        b = mk("sap")
+        model.lift_splat(b)
+        gm, bev, _, _ = model.bert(*model._cmt_args(b))
+        cmp(gm, "gmap_embeds"); cmp(bev, "bev_embeds_sub", 11)
+        cmp(model(mk("masksem"), "masksem"), "masksem_loss")
+        lg, lb = model(mk("masksem"), "masksem", compute_loss=False)
+        cmp(lg, "masksem_logits")
+        assert np.array_equal(lb.cpu().numpy().astype(np.uint8), g["masksem_labels"])
+        for tok in ("sattn", "embed", "cattn"):
+            model.sem_pred_token = tok
+            lg, _ = model(mk("sem"), "sem", compute_loss=False)
+            cmp(lg, f"sem_{tok}_logits_sub", 3)
+        model.sem_pred_token = "cattn"
+    if check_grads:
+        for task in ("mlm", "sap", "masksem"):
+            arena.zero_grad()
+            model(mk(task), task).mean().backward()
+            sq = float((arena.grads.double() ** 2).sum())
+            ref_sq = float(g[f"{task}_grad_sqnorm"])
+            assert abs(sq - ref_sq) < (2e-3 if fp32 else 5e-2) * ref_sq, (task, sq, ref_sq)
+            for name, p in model.named_parameters():
+                gk = f"{task}_grad::{name}"
+                if gk in g.files:
+                    ref = g[gk]
+                    got = sub(p.main_grad.cpu(), 97 if p.numel() > 4096 else 1)
+                    scale = max(1e-6, float(np.abs(ref).max()))
+                    tol = 2e-3 if fp32 else 8e-2
+                    assert max_abs(got, ref) < tol * scale + 1e-7, (gk, max_abs(got, ref), scale)
+            # parameters the task does not use keep an exactly-zero gradient (find_unused_parameters semantics)
+            used = {k[len(task) + 7:] for k in g.files if k.startswith(f"{task}_grad::")}
+            assert len(used) > 0
+
+
+def test_tiny_ragged_fp32_forward_and_grads(env):
+    _check_tasks(env, BevBertConfig.tiny(), "tiny_b3_ragged", "pretrain_state_dict_keys_tiny.txt", torch.float32, True)
+
+
+def test_tiny_fixed_fp32(env):
+    _check_tasks(env, BevBertConfig.tiny(), "tiny_b2_fixed", "pretrain_state_dict_keys_tiny.txt", torch.float32)
+
+
+def test_tiny_ragged_bf16_forward_and_grads(env):
+    _check_tasks(env, BevBertConfig.tiny(), "tiny_b3_ragged", "pretrain_state_dict_keys_tiny.txt", torch.bfloat16, True)
+
+
+def test_full_r2r_config_fp32(env):
+    _check_tasks(env, BevBertConfig(), "r2r_b2", "pretrain_state_dict_keys_r2r.txt", torch.float32)
+
+
+def test_full_r2r_config_bf16(env):
+    _check_tasks(env, BevBertConfig(), "r2r_b2", "pretrain_state_dict_keys_r2r.txt", torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_nav_api(env, dtype):
+    cfg = BevBertConfig.tiny()
+    g = load_golden("nav_tiny")
+    model, _ = build(cfg, "nav_state_dict_keys.txt", dtype, nav=True)
+    fp32 = dtype == torch.float32
+    B = 3
+    pb = synthetic.make_batch(cfg, "sap", B, seed=int(g["seed"]), ragged=True)
+    lifted = R.lift_splat(cfg, pb)
+    d = synthetic.batch_to(pb, DEV)
+
+    def cmp(got, ref, step=None):
+        got = got.detach().float().cpu()
+        got = sub(got, step) if step else got.numpy()
+        if fp32:
+            assert max_abs(got, ref) < FP32_TOL
+        else:
+            bf16_close(got, ref, "nav")
+
+    with torch.no_grad():
+        txt_masks = torch.arange(d["txt_ids"].shape[1], device=DEV)[None] < d["txt_lens"][:, None]
+        txt = model("language", {"txt_ids": d["txt_ids"], "txt_masks": txt_masks})
+        cmp(txt, g["txt_embeds_sub"], 7)
+        ends = torch.from_numpy(np.cumsum(pb["traj_step_lens"]) - 1).to(DEV)
+        pano, pm = model("panorama", {"view_img_fts": d["traj_view_img_fts"][ends], "obj_img_fts": None,
+                                      "loc_fts": d["traj_loc_fts"][ends], "nav_types": d["traj_nav_types"][ends],
+                                      "view_lens": d["traj_vp_view_lens"][ends], "obj_lens": None})
+        assert np.array_equal(pm.cpu().numpy(), g["pano_masks"])
+        cmp(pano, g["pano_embeds_sub"], 5)
+        G = int(pb["gmap_lens"].max())
+        gen = torch.Generator().manual_seed(99)
+        gimg = torch.randn(B, G, 768, generator=gen)
+        gimg[:, 0] = 0
+        out = model("navigation", {
+            "txt_embeds": txt, "txt_masks": txt_masks, "gmap_img_embeds": gimg.to(DEV),
+            "gmap_step_ids": d["gmap_step_ids"], "gmap_pos_fts": d["gmap_pos_fts"],
+            "gmap_masks": torch.arange(G, device=DEV)[None] < d["gmap_lens"][:, None],
+            "gmap_pair_dists": d["gmap_pair_dists"], "gmap_visited_masks": d["gmap_visited_masks"],
+            "gmap_vpids": pb["gmap_vpids"], "bev_fts": lifted["bev_fts"].to(DEV).to(txt.dtype),
+            "bev_pos_fts": lifted["bev_pos_fts"].to(DEV), "bev_masks": lifted["bev_masks"].to(DEV),
+            "bev_nav_masks": d["bev_nav_masks"], "bev_cand_idxs": d["bev_cand_idxs"],
+            "bev_cand_vpids": [[None] + c[-1] for c in pb["traj_cand_vpids"]],
+            "obj_embeds": None, "obj_masks": None})
+        cmp(out["gmap_embeds"], g["nav_gmap_embeds"])
+        for k in ("global", "local", "fused"):
+            cmp(out[f"{k}_logits"], g[f"nav_{k}"])
+
+
+def _oracle_train(cfg, sd0, tasks, batches, lr_fn, wd=0.01, max_norm=5.0):
+    """CPU oracle of the reference's hot loop with dropout disabled (train_r2r.py:247-313)."""
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    sd["mlm_head.predictions.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+    names = [k for k in sd if k != "mlm_head.predictions.decoder.weight"]
+    state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k]), [0]) for k in names}
+    losses = []
+    for step, (task, b) in enumerate(zip(tasks, batches), 1):
+        loss = R.pretrain_forward(sd, cfg, b, task).mean()
+        grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
+        gd = {k: g for k, g in zip(names, grads)}
+        for k in names:                               # zero_grad() keeps zeros for params that ever had a grad
+            if gd[k] is None and state[k][2][0] > 0:
+                gd[k] = torch.zeros_like(sd[k])
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in gd.values() if g is not None)).float()
+        coef = min(1.0, max_norm / (float(total) + 1e-6))
+        with torch.no_grad():
+            for k in names:
+                if gd[k] is None:
+                    continue
+                m, v, n = state[k]
+                n[0] += 1
+                R.adamw_step(sd[k], gd[k] * coef, m, v, n[0], lr_fn(step), 0.0 if R.no_decay_key(k) else wd)
+        losses.append(float(loss))
+    return losses
+
+
+def test_training_curve_matches_oracle_fp32(env):
+    """Loss curves overlap (north_star) -- run with dropout disabled on both sides, fp32, 12 steps."""
+    from vln_bevbert_amd.train import PretrainTrainer, TaskSampler
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=600)
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from vln_bevbert_amd import weights
+    model = GlocalTextPathCMTPreTraining(cfg)
+    sd0 = weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd0)
+    model.tie_weights()
+    arena = model.finalize(DEV, torch.float32)
+    model.train()
+    model.set_dropout(0.0)
+    n = 12
+    sampler = TaskSampler("mlm.5.sap.5.masksem.1", seed=1)
+    tasks = [sampler.next() for _ in range(n)]
+    batches = [synthetic.make_batch(cfg, t, 2, seed=50 + i, ragged=True) for i, t in enumerate(tasks)]
+    trainer = PretrainTrainer(model, arena, learning_rate=5e-4, warmup_steps=4, num_train_steps=40)
+    got = [float(trainer.step(t, synthetic.batch_to(b, DEV))) for t, b in zip(tasks, batches)]
+    from vln_bevbert_amd.train import warmup_linear_lr
+    want = _oracle_train(cfg, sd0, tasks, batches, lambda s: warmup_linear_lr(s, 5e-4, 4, 40))
+    err = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(got, want))
+    assert err < 2e-2, (got, want)
+    assert abs(got[0] - want[0]) < 1e-3 * max(1.0, abs(want[0]))
+
+
+def test_training_step_bf16_full_size_runs_and_learns(env):
+    """BASELINE configs[1] shapes at a reduced batch: bf16, dropout on; loss is finite and falls on a fixed batch."""
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig()
+    torch.manual_seed(0)
+    model = GlocalTextPathCMTPreTraining(cfg)
+    arena = model.finalize(DEV, torch.bfloat16)
+    model.train()
+    model.set_dropout(0.1)
+    trainer = PretrainTrainer(model, arena, learning_rate=1e-4, warmup_steps=2, num_train_steps=50)
+    b = synthetic.batch_to(synthetic.make_batch(cfg, "sap", 8, seed=9, sems_as="ids"), DEV)
+    losses = [float(trainer.step("sap", b)) for _ in range(8)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    for t in ("mlm", "masksem"):
+        bb = synthetic.batch_to(synthetic.make_batch(cfg, t, 8, seed=10, sems_as="ids"), DEV)
+        assert np.isfinite(float(trainer.step(t, bb)))

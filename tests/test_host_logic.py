@@ -1,0 +1,169 @@
+"""CPU tests of the host-side logic and of the C-ABI surface (no GPU, no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bevbert_ref as R
+from tests.helpers import read_shapes
+from vln_bevbert_amd import lib, synthetic
+from vln_bevbert_amd.config import BevBertConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    lib.build()
+    l = lib.load()
+    assert l.bevbert_version() >= 100 and l.bevbert_arch() == b"gfx950"
+    syms = lib.header_symbols()
+    assert len(syms) >= 20
+    missing = [s for s in syms if not hasattr(l, s)]
+    assert not missing, missing
+    # every typed prototype exists in the header and vice versa (bar the three untyped getters)
+    assert set(lib._PROTOS) | {"bevbert_last_error", "bevbert_version", "bevbert_arch",
+                               "bevbert_colsum_workspace_floats"} == set(syms)
+
+
+def test_code_object_targets_gfx950_only():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", lib.LIB_PATH],
+                         capture_output=True, text=True).stdout
+    archs = set(re.findall(r"gfx[0-9a-f]+", out))
+    assert archs == {"gfx950"}, archs
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    l = lib.load()
+    # argument validation happens before any launch: bad shapes come back as -1 with a message
+    rc = l.bevbert_bias_gelu_fwd(None, None, None, 4, 7, 0, None)
+    assert rc == -1 and b"multiple of 4" in l.bevbert_last_error()
+    rc = l.bevbert_bev_lift_bin(None, None, None, None, None, 1, 12, 64, 10.0, 21, 0.5, 0.5, None, None, None, None)
+    assert rc == -1 and b"out of range" in l.bevbert_last_error()
+    strides = (ctypes.c_int64 * 8)(*([768] * 8))
+    rc = l.bevbert_attn_fwd(None, None, None, None, None, None, None, strides, 1, 12, 4, 4, 32, 0.125, 1, 0, 0.0, 0, 0, None)
+    assert rc == -1 and b"head_dim" in l.bevbert_last_error()
+
+
+def test_cpu_tensors_fail_loudly():
+    from vln_bevbert_amd import ops
+    with pytest.raises(lib.BevBertHipError):
+        ops.bias_gelu(torch.zeros(4, 8), torch.zeros(8))
+
+
+def test_state_dict_keys_match_the_reference():
+    from vln_bevbert_amd.nav_model import GlocalTextPathNavCMT, remap_pretrain_checkpoint
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    for cfg, f in ((BevBertConfig.tiny(), "pretrain_state_dict_keys_tiny.txt"),):
+        m = GlocalTextPathCMTPreTraining(cfg)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == read_shapes(f)
+        assert m.mlm_head.predictions.decoder.weight is m.bert.embeddings.word_embeddings.weight
+    nav = GlocalTextPathNavCMT(BevBertConfig.tiny())
+    want = read_shapes("nav_state_dict_keys.txt")
+    assert {k: tuple(v.shape) for k, v in nav.state_dict().items()} == want
+    # a pre-training checkpoint maps onto the fine-tuning model the way vlnbert_init.py:39-46 does
+    mapped = remap_pretrain_checkpoint({"module." + k: v for k, v in m.state_dict().items()})
+    assert set(want) <= set(mapped) | {k for k in want if k.startswith("og_head")}
+
+
+def test_arena_layout_and_packed_views():
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=300)
+    m = GlocalTextPathCMTPreTraining(cfg)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    arena = m.finalize("cpu", torch.float32)
+    assert arena.numel % 1024 == 0 and arena.n_params == sum(p.numel() for p in m.parameters())
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])                       # values preserved
+    for n, p in m.named_parameters():
+        o, k = arena.slices[n]
+        assert p.data_ptr() == arena.params[o:].data_ptr() and p.main_grad.data_ptr() == arena.grads[o:].data_ptr()
+    att = m.bert.lang_encoder.layer[0].attention.self
+    assert att.pw.compute.shape == (2304, 768)
+    assert torch.equal(att.pw.compute[768:1536], att.key.weight) and torch.equal(att.pb.compute[1536:], att.value.bias)
+    x = m.bert.local_encoder.encoder.x_layers[0].visual_attention.att
+    assert x.pw.compute.shape == (1536, 768) and torch.equal(x.pw.compute[768:], x.value.weight)
+    # decay flags follow the reference's substring rule (optim/misc.py:14)
+    for n, p in m.named_parameters():
+        a, _ = arena._seg_of[n]
+        assert bool(arena._flags_host[a] & 1) == (not R.no_decay_key(n)), n
+    assert not R.no_decay_key("bert.img_embeddings.img_layer_norm.weight")
+    # load_state_dict writes through into the arena
+    sd = {k: torch.full_like(v, 0.5) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    assert float(arena.params[: arena.slices["bert.embeddings.word_embeddings.weight"][1]].min()) == 0.5
+
+
+def test_sap_fusion_index_form_equals_the_reference_loop():
+    from vln_bevbert_amd.pretrain_cmt import fuse_sap_logits, sap_fusion_indices
+    cfg = BevBertConfig()
+    for seed in range(6):
+        b = synthetic.make_batch(cfg, "sap", 5, seed=seed, ragged=True)
+        B, G, K = 5, b["gmap_step_ids"].shape[1], b["bev_cand_idxs"].shape[1]
+        g = torch.Generator().manual_seed(seed)
+        gl = torch.randn(B, G, generator=g)
+        ll = torch.randn(B, K, generator=g)
+        gl = gl.masked_fill(b["gmap_visited_masks"], float("-inf"))
+        gl = gl.masked_fill(~R.seq_mask(b["gmap_lens"], G), float("-inf"))
+        ll[torch.rand(B, K, generator=g) < 0.2] = float("-inf")          # masked candidates propagate -inf
+        cvp = [[None] + c[-1] for c in b["traj_cand_vpids"]]
+        want = R.fuse_sap_logits(gl, ll, b["gmap_vpids"], b["gmap_visited_masks"], cvp)
+        src, vis = sap_fusion_indices(b["gmap_vpids"], b["gmap_visited_masks"].tolist(), cvp, G, K)
+        got = fuse_sap_logits(gl, ll, torch.from_numpy(src), torch.from_numpy(vis))
+        assert torch.equal(torch.nan_to_num(got, neginf=-1e30), torch.nan_to_num(want, neginf=-1e30))
+
+
+def test_gmap_csr_equals_the_reference_aggregation():
+    cfg = BevBertConfig()
+    b = synthetic.make_batch(cfg, "sap", 6, seed=3, ragged=True)
+    T, V = b["traj_view_img_fts"].shape[:2]
+    emb = torch.randn(T, V, 16)
+    masks = R.seq_mask(b["traj_vp_view_lens"], V)
+    want = R.aggregate_gmap(emb, masks, b["traj_vp_view_lens"], b["traj_step_lens"], b["traj_vpids"],
+                            b["traj_cand_vpids"], b["gmap_vpids"])
+    # evaluate the CSR densely on the host (the kernel itself is covered by the GPU tests)
+    from vln_bevbert_amd.vilmodel import build_gmap_csr
+    csr, G = build_gmap_csr(b["traj_step_lens"], b["traj_vp_view_lens"].tolist(), b["traj_vpids"],
+                            b["traj_cand_vpids"], b["gmap_vpids"], V, "cpu")
+    flat = emb.reshape(-1, 16)
+    got = torch.zeros(csr.n_out, 16)
+    rp, idx, w = csr.rowptr.tolist(), csr.idx.long(), csr.w
+    for r in range(csr.n_out):
+        if rp[r + 1] > rp[r]:
+            got[r] = (w[rp[r]:rp[r + 1], None] * flat[idx[rp[r]:rp[r + 1]]]).sum(0)
+    assert float((got.view(6, G, 16) - want).abs().max()) < 1e-5
+    # transposed CSR is a true transpose
+    dense = torch.zeros(csr.n_out, csr.n_src)
+    for r in range(csr.n_out):
+        dense[r, idx[rp[r]:rp[r + 1]]] += w[rp[r]:rp[r + 1]]
+    dt = torch.zeros(csr.n_src, csr.n_out)
+    trp, tidx, tw = csr.t_rowptr.tolist(), csr.t_idx.long(), csr.t_w
+    for r in range(csr.n_src):
+        dt[r, tidx[trp[r]:trp[r + 1]]] += tw[trp[r]:trp[r + 1]]
+    assert torch.equal(dense.t(), dt)
+
+
+def test_task_sampler_and_schedule_are_rank_independent():
+    from vln_bevbert_amd.train import TaskSampler, warmup_linear_lr
+    a, b = TaskSampler(seed=4), TaskSampler(seed=4)
+    seq = [a.next() for _ in range(200)]
+    assert seq == [b.next() for _ in range(200)]
+    frac = {t: seq.count(t) / 200 for t in ("mlm", "sap", "masksem")}
+    assert 0.3 < frac["mlm"] < 0.6 and 0.3 < frac["sap"] < 0.6 and frac["masksem"] < 0.2
+    assert warmup_linear_lr(5000, 5e-5, 10000, 100000) == pytest.approx(R.warmup_linear_lr(5000, 5e-5, 10000, 100000))
+    assert warmup_linear_lr(100001, 5e-5, 10000, 100000) == 1e-8
+
+
+def test_synthetic_batches_are_deterministic_and_rank_distinct():
+    cfg = BevBertConfig()
+    a = synthetic.make_batch(cfg, "mlm", 3, seed=1000)
+    b = synthetic.make_batch(cfg, "mlm", 3, seed=1000)
+    c = synthetic.make_batch(cfg, "mlm", 3, seed=1001)
+    assert all(torch.equal(a[k], b[k]) for k in a if torch.is_tensor(a[k]))
+    assert not torch.equal(a["rgbs"], c["rgbs"])
+    assert a["rgbs"].shape == (3, 12, 14, 14, 768) and a["traj_view_img_fts"].shape == (15, 36, 512)
+    assert a["sems"].dtype == torch.float64 and (a["txt_labels"] != -1).any(1).all()

@@ -1,0 +1,159 @@
+"""Flat parameter / gradient / optimiser-state arenas (memory laid out for one 288 GB HBM3E stack).
+
+The reference keeps 567 separate parameter tensors, lets autograd allocate a gradient per tensor, copies them
+into DDP buckets for NCCL, and steps a Python-loop AdamW over every tensor (pretrain_src/optim/adamw.py:53-112,
+pretrain_src/utils/misc.py:64-77).  Here every parameter is a view into ONE fp32 buffer; gradients, Adam moments
+and (in mixed precision) the bf16 compute copy are parallel buffers with the same offsets:
+
+    params  fp32 [N]   masters            (N = 238.8 M + padding for the R2R model: 0.96 GB)
+    grads   fp32 [N]   accumulation target of every backward kernel; the all-reduce runs on slices of it in place
+    exp_avg, exp_avg_sq fp32 [N]
+    shadow  bf16 [N]   refreshed by the AdamW kernel in the same pass that updates the masters
+
+Tensors start on 1024-element boundaries so the optimiser kernel can use one flag byte per 1024-element chunk
+(bit0 weight decay, bit1 "has had a gradient": the reference skips parameters whose .grad is None).  Parameters
+listed in a *group* (packed QKV / KV projections) are laid out back to back so the group is one GEMM operand.
+"""
+import math
+
+import torch
+
+from . import lib
+from .lib import ptr, stream
+
+
+def call(name, *args):
+    from . import ops          # traced C-ABI call (bench.py's kernel-timing pass)
+    return ops.call(name, *args)
+
+CHUNK = 1024
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")   # optim/misc.py:14 (substring match)
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class ParamArena:
+    def __init__(self, module, device, compute_dtype=torch.float32, groups=()):
+        """groups: iterable of lists of parameter names to lay out contiguously (same decay class)."""
+        self.device = torch.device(device)
+        self.compute_dtype = compute_dtype
+        named = [(n, p) for n, p in module.named_parameters()]
+        by_name = dict(named)
+        in_group = {}
+        for gi, g in enumerate(groups):
+            for n in g:
+                in_group[n] = gi
+        layout, seen_groups = [], set()
+        for n, p in named:
+            if n in in_group:
+                gi = in_group[n]
+                if gi in seen_groups:
+                    continue
+                seen_groups.add(gi)
+                layout.append(list(groups[gi]))
+            else:
+                layout.append([n])
+        self.slices = {}
+        off = 0
+        seg_meta = []   # (start, end_padded, decay)
+        for seg in layout:
+            start = off
+            decays = set()
+            for n in seg:
+                k = by_name[n].numel()
+                self.slices[n] = (off, k)
+                off += k
+                decays.add(not any(nd in n for nd in NO_DECAY))
+            assert len(decays) == 1, f"group {seg} mixes weight-decay classes"
+            off = _round_up(off, CHUNK)
+            seg_meta.append((start, off, decays.pop(), seg))
+        self.numel = off
+        self.n_params = sum(p.numel() for _, p in named)
+        dev = self.device
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.shadow = torch.zeros(off, dtype=compute_dtype, device=dev) if compute_dtype != torch.float32 else None
+        self._flags_host = torch.zeros(off // CHUNK, dtype=torch.uint8)
+        self._seg_of = {}
+        for start, end, decay, seg in seg_meta:
+            if decay:
+                self._flags_host[start // CHUNK:end // CHUNK] |= 1
+            for n in seg:
+                self._seg_of[n] = (start // CHUNK, end // CHUNK)
+        self.flags = self._flags_host.to(dev)
+        self._touched = set()
+        self._flags_dirty = False
+        self.step_count = 0
+        self._scalars = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._partials = torch.zeros(1024, dtype=torch.float32, device=dev)
+        # re-point every parameter at its arena view
+        self.named = named
+        for n, p in named:
+            o, k = self.slices[n]
+            view = self.params[o:o + k].view(p.shape)
+            view.copy_(p.data.to(dev, torch.float32))
+            p.data = view
+            p.main_grad = self.grads[o:o + k].view(p.shape)
+            p.compute = self.shadow[o:o + k].view(p.shape) if self.shadow is not None else p.data
+            p.arena = self
+            p.arena_name = n
+        self.sync_shadow()
+
+    # ---- views over contiguous groups --------------------------------------------------------
+    def packed(self, names, shape):
+        """(compute view, fp32 grad view) over consecutive parameters ``names`` reshaped to ``shape``."""
+        o0, _ = self.slices[names[0]]
+        total = 0
+        for n in names:
+            o, k = self.slices[n]
+            assert o == o0 + total, f"{names} are not contiguous in the arena"
+            total += k
+        assert total == math.prod(shape)
+        src = self.shadow if self.shadow is not None else self.params
+        return src[o0:o0 + total].view(shape), self.grads[o0:o0 + total].view(shape)
+
+    # ---- bookkeeping -------------------------------------------------------------------------
+    def touch(self, param):
+        n = param.arena_name
+        if n not in self._touched:
+            self._touched.add(n)
+            a, b = self._seg_of[n]
+            self._flags_host[a:b] |= 2
+            self._flags_dirty = True
+
+    def sync_shadow(self):
+        if self.shadow is not None:
+            call("bevbert_cast_f32", ptr(self.params), ptr(self.shadow), self.numel, lib.dtype_code(self.compute_dtype),
+                 stream())
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def load_state_dict_into(self, module, sd, strict=True):
+        out = module.load_state_dict(sd, strict=strict)     # copies in place into the arena views
+        self.sync_shadow()
+        return out
+
+    # ---- optimiser ---------------------------------------------------------------------------
+    def clip_and_step(self, lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_norm=5.0, grad_pre_scale=1.0):
+        """clip_grad_norm_(max_norm) + AdamW.step (train_r2r.py:295-313) in three launches, no host sync."""
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.params)
+            self.exp_avg_sq = torch.zeros_like(self.params)
+        if self._flags_dirty:
+            self.flags.copy_(self._flags_host, non_blocking=True)
+            self._flags_dirty = False
+        self.step_count += 1
+        call("bevbert_grad_norm_clip", ptr(self.grads), self.numel, float(grad_pre_scale),
+             float(max_norm if max_norm is not None else -1.0), ptr(self._partials), ptr(self._scalars), stream())
+        call("bevbert_adamw_step", ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+             ptr(self.shadow), ptr(self.flags), self.numel, self._scalars[1:].data_ptr(), float(lr), float(betas[0]),
+             float(betas[1]), float(eps), float(weight_decay), self.step_count, stream())
+
+    def grad_norm(self):
+        """L2 norm computed by the last clip_and_step (device scalar; reading it syncs)."""
+        return self._scalars[0]

@@ -1,0 +1,39 @@
+// Argument block shared by the attention kernels (K2).
+//
+// One kernel family covers every attention in the path: BertSelfAttention (vilmodel.py:79-141),
+// BertOutAttention (vilmodel.py:301-352) and nn.MultiheadAttention inside the pano encoder
+// (transformer.py:138,174-178).  Q/K/V are read in place from the projection GEMM outputs --
+// (batch, seq, heads*64) with arbitrary row/batch strides, so a packed QKV buffer needs no split
+// or permute -- and O is written merged-head (batch, seq, heads*64), i.e. no transpose_for_scores
+// / permute / contiguous copies ever touch HBM.  The (N,12,Lq,Lk) score tensor is never written.
+//
+//   S = (Q K^T) * scale + key_mask[b, k] + bias[b, q, k]        (mask/bias additive fp32; -inf allowed)
+//   P = softmax_k(S) ; O = dropout(P) V ; lse = logsumexp_k(S)
+#pragma once
+#include "common.h"
+
+#define ATTN_D 64  // head dim (hidden 768 / 12 heads: configs/r2r_model.json)
+
+struct AttnArgs {
+  const void *q, *k, *v;
+  void* o;
+  float* lse;              // (B, nh, Lq) natural-log logsumexp; may be null for inference-only forward
+  const float* key_mask;   // (B, Lk) additive or null
+  const float* bias;       // (B, Lq, Lk) additive, shared by heads, or null
+  int64_t ldq, ldk, ldv, ldo;  // row strides (elements)
+  int64_t bsq, bsk, bsv, bso;  // batch strides (elements)
+  int B, nh, Lq, Lk;
+  float scale;
+  float drop_p;
+  uint32_t drop_thr;
+  uint64_t seed, offset;
+  // backward only
+  const void* dout;        // (B, Lq, nh*64), strides ldo/bso
+  const float* delta;      // (B, nh, Lq) rowsum(dO * O)
+  void *dq, *dk, *dv;      // same strides as q/k/v
+  float* dbias;            // (B, Lq, Lk) fp32, accumulated with atomics over heads, or null
+};
+
+__device__ __forceinline__ uint64_t attn_elem(const AttnArgs& a, int b, int h, int q, int k) {
+  return a.offset + (((uint64_t)b * a.nh + h) * a.Lq + q) * (uint64_t)a.Lk + k;
+}

@@ -1,0 +1,527 @@
+// K2 (fast path): fused multi-head attention forward/backward on the CDNA4 matrix cores, bf16 in / fp32 accumulate.
+//
+// MFMA is used for exactly the contractions north_star names -- Q K^T and P V (plus their backward twins);
+// softmax statistics, masking, dropout and the rescale are fp32 VALU work on the accumulator registers.
+//
+// Mapping (v_mfma_f32_16x16x32_bf16, 64-lane wave):
+//   A operand: lane l holds row (l & 15), eight k-slots of group g = l >> 4          (8 bf16 = 4 VGPR)
+//   B operand: lane l holds col (l & 15), the same eight k-slots of group g
+//   C/D      : lane l holds col (l & 15), rows g*4 + r, r = 0..3                     (4 fp32)
+// Everything is computed TRANSPOSED so that the per-query softmax state lives in the lane that owns the query:
+//   S^T = K Q^T   (A = K tile rows from LDS, B = Q fragments kept in registers for the whole kernel)
+//         -> lane (q = l&15) holds S[q][key = 16 t + 4 g + r]
+//   O^T = V^T P^T (A = V^T tile rows from LDS, B = P packed to bf16 straight from the S accumulators)
+// The contraction index of the second product is *defined* as  k-slot (g, j) <-> key 16 (2m + (j>>2)) + 4 g + (j&3)
+// for both operands, which is exactly the order the S accumulators already have: P never moves between lanes and
+// never touches LDS.  K tiles are staged row-major [key][d]; V tiles are staged transposed [d][key] so the A
+// fragments of the second product are two 8-byte LDS reads.  Row stride 72 bf16 (144 B) keeps 16-byte reads of 16
+// consecutive rows on distinct banks.
+#include "attn_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TK 64   // keys (or queries, in dKV) per LDS tile
+#define LDT 72  // LDS row stride in bf16 elements
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) { return __builtin_bit_cast(bf16x8, u); }
+
+// 16-byte fragment (8 consecutive head-dim elements) of row `row` of a (rows, 64) head slice in global memory
+__device__ __forceinline__ uint4 ld_frag_global(const bf16_raw* base, int64_t ld, int row, int d0) {
+  return *reinterpret_cast<const uint4*>(base + (size_t)row * ld + d0);
+}
+
+// Stage a [TK rows][64] tile row-major into LDS (dst[row][d], stride LDT); rows >= nrows are zero filled.
+__device__ __forceinline__ void stage_rows(bf16_raw* dst, const bf16_raw* src, int64_t ld, int row0, int nrows,
+                                           int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256, r = c >> 3, ch = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row0 + r < nrows) v = ld_frag_global(src, ld, row0 + r, ch * 8);
+    *reinterpret_cast<uint4*>(dst + r * LDT + ch * 8) = v;
+  }
+}
+// Stage the same tile transposed (dst[d][row], stride LDT).
+__device__ __forceinline__ void stage_cols(bf16_raw* dst, const bf16_raw* src, int64_t ld, int row0, int nrows,
+                                           int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256, r = c >> 3, ch = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row0 + r < nrows) v = ld_frag_global(src, ld, row0 + r, ch * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dst[(ch * 8 + 2 * j) * LDT + r] = (bf16_raw)(w[j] & 0xffffu);
+      dst[(ch * 8 + 2 * j + 1) * LDT + r] = (bf16_raw)(w[j] >> 16);
+    }
+  }
+}
+// A fragment from a row-major tile: row (t*16 + (l&15)), k-slots = head-dim ks*32 + g*8 .. +7
+__device__ __forceinline__ bf16x8 lds_frag_rows(const bf16_raw* tile, int t, int ks, int lane) {
+  return as_bf16x8(*reinterpret_cast<const uint4*>(tile + (t * 16 + (lane & 15)) * LDT + ks * 32 + (lane >> 4) * 8));
+}
+// A fragment from a transposed tile: row d = dt*16 + (l&15), k-slots (g, j) <-> tile column 32 m + 16 (j>>2) + 4 g + (j&3)
+__device__ __forceinline__ bf16x8 lds_frag_cols(const bf16_raw* tileT, int dt, int m, int lane) {
+  const bf16_raw* p = tileT + (dt * 16 + (lane & 15)) * LDT + m * 32 + (lane >> 4) * 4;
+  const uint2 lo = *reinterpret_cast<const uint2*>(p);
+  const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+  return as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+// pack accumulators of key/query tiles (2m, 2m+1) into the B operand of the second product
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+  return as_bf16x8(make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
+                              pack_bf16x2(b[2], b[3])));
+}
+// reduce over the four lanes that own the same query/key column (l&15)
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// =============================================================================================
+// Forward.  Workgroup = 4 waves; wave w owns QT query tiles of 16 rows: rows q0 + (w*QT + qt)*16 + (l&15).
+// =============================================================================================
+template <int QT>
+__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_raw s_k[TK * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_vt[ATTN_D * LDT];
+  __shared__ __attribute__((aligned(16))) float s_mask[TK];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qbase = blockIdx.x * (64 * QT) + w * (16 * QT);
+  const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
+  const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
+  const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
+  const float sc2 = a.scale * LOG2E;
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+
+  bf16x8 qf[QT][2];
+  int qrow[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qrow[qt] = qbase + qt * 16 + c;
+    const int r = qrow[qt] < a.Lq ? qrow[qt] : a.Lq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = as_bf16x8(ld_frag_global(qp, a.ldq, r, ks * 32 + g * 8));
+  }
+  f32x4 oacc[QT][4];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = -INFINITY;
+    l_run[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int kv0 = 0; kv0 < a.Lk; kv0 += TK) {
+    __syncthreads();  // previous tile fully consumed
+    stage_rows(s_k, kp, a.ldk, kv0, a.Lk, tid);
+    stage_cols(s_vt, vp, a.ldv, kv0, a.Lk, tid);
+    if (tid < TK) {
+      const int key = kv0 + tid;
+      float mv = -INFINITY;
+      if (key < a.Lk) mv = a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * LOG2E : 0.f;
+      s_mask[tid] = mv;
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T
+    f32x4 sacc[QT][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) sacc[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = lds_frag_rows(s_k, t, ks, lane);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) sacc[qt][t] = mfma16(kf, qf[qt][ks], sacc[qt][t]);
+      }
+    }
+    // ---- online softmax (log2 domain), per owned query
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 mk = *reinterpret_cast<const float4*>(&s_mask[t * 16 + g * 4]);
+        const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = sacc[qt][t][r] * sc2 + mkv[r];
+          if (a.bias) {
+            const int key = kv0 + t * 16 + g * 4 + r;
+            if (key < a.Lk && qrow[qt] < a.Lq) s += a.bias[((size_t)b * a.Lq + qrow[qt]) * a.Lk + key] * LOG2E;
+          }
+          sacc[qt][t][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      }
+      mx = quad_max(mx);
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = exp2f(m_run[qt] - m_use);  // first tile: exp2(-inf) = 0
+      m_run[qt] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = exp2f(sacc[qt][t][r] - m_use);
+          psum += p;
+          if (a.drop_p > 0.f) {
+            const int key = kv0 + t * 16 + g * 4 + r;
+            p = bb_keep(a.seed, attn_elem(a, b, h, qrow[qt], key), a.drop_thr) ? p * keep_scale : 0.f;
+          }
+          sacc[qt][t][r] = p;
+        }
+      l_run[qt] = l_run[qt] * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
+    }
+    // ---- O^T += V^T P^T
+    bf16x8 pb[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      pb[qt][0] = pack_pair(sacc[qt][0], sacc[qt][1]);
+      pb[qt][1] = pack_pair(sacc[qt][2], sacc[qt][3]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const bf16x8 vf = lds_frag_cols(s_vt, dt, m, lane);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = mfma16(vf, pb[qt][m], oacc[qt][dt]);
+      }
+  }
+
+  // ---- epilogue: normalise, store O[q][h*64 + dt*16 + g*4 .. +3] and the log-sum-exp
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const float l = quad_sum(l_run[qt]);
+    const float inv = 1.0f / l;
+    if (qrow[qt] < a.Lq) {
+      bf16_raw* op = (bf16_raw*)a.o + (size_t)b * a.bso + (size_t)qrow[qt] * a.ldo + h * ATTN_D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        st4<bf16_raw>(op + dt * 16 + g * 4, make_float4(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv,
+                                                         oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv));
+      if (a.lse && g == 0) {
+        const float mu = (m_run[qt] == -INFINITY) ? 0.f : m_run[qt];
+        a.lse[((size_t)b * a.nh + h) * a.Lq + qrow[qt]] = (mu + log2f(l)) * LN2;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// Backward, part 1: dQ (and dbias).  Same ownership as the forward; per key tile
+//   S^T, P = exp2(S2 - lse2);  dP^T = V dO^T;  dS = P * (drop(dP) - delta);  dQ^T += K^T dS^T
+// =============================================================================================
+template <int QT>
+__global__ __launch_bounds__(256) void attn_mfma_dq_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_raw s_k[TK * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_v[TK * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_kt[ATTN_D * LDT];
+  __shared__ __attribute__((aligned(16))) float s_mask[TK];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qbase = blockIdx.x * (64 * QT) + w * (16 * QT);
+  const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
+  const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
+  const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
+  const bf16_raw* dop = (const bf16_raw*)a.dout + (size_t)b * a.bso + h * ATTN_D;
+  const float sc2 = a.scale * LOG2E;
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+
+  bf16x8 qf[QT][2], dof[QT][2];
+  int qrow[QT];
+  float lse2[QT], dlt[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qrow[qt] = qbase + qt * 16 + c;
+    const int r = qrow[qt] < a.Lq ? qrow[qt] : a.Lq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[qt][ks] = as_bf16x8(ld_frag_global(qp, a.ldq, r, ks * 32 + g * 8));
+      dof[qt][ks] = as_bf16x8(ld_frag_global(dop, a.ldo, r, ks * 32 + g * 8));
+    }
+    const size_t ridx = ((size_t)b * a.nh + h) * a.Lq + r;
+    lse2[qt] = a.lse[ridx] * LOG2E;
+    dlt[qt] = a.delta[ridx];
+  }
+  f32x4 dqacc[QT][4];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dqacc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int kv0 = 0; kv0 < a.Lk; kv0 += TK) {
+    __syncthreads();
+    stage_rows(s_k, kp, a.ldk, kv0, a.Lk, tid);
+    stage_rows(s_v, vp, a.ldv, kv0, a.Lk, tid);
+    stage_cols(s_kt, kp, a.ldk, kv0, a.Lk, tid);
+    if (tid < TK) {
+      const int key = kv0 + tid;
+      float mv = -INFINITY;
+      if (key < a.Lk) mv = a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * LOG2E : 0.f;
+      s_mask[tid] = mv;
+    }
+    __syncthreads();
+
+    f32x4 sacc[QT][4], dpacc[QT][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        sacc[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dpacc[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = lds_frag_rows(s_k, t, ks, lane);
+        const bf16x8 vf = lds_frag_rows(s_v, t, ks, lane);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          sacc[qt][t] = mfma16(kf, qf[qt][ks], sacc[qt][t]);
+          dpacc[qt][t] = mfma16(vf, dof[qt][ks], dpacc[qt][t]);
+        }
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 mk = *reinterpret_cast<const float4*>(&s_mask[t * 16 + g * 4]);
+        const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kv0 + t * 16 + g * 4 + r;
+          const bool valid = key < a.Lk && qrow[qt] < a.Lq;
+          float s = sacc[qt][t][r] * sc2 + mkv[r];
+          if (a.bias && valid) s += a.bias[((size_t)b * a.Lq + qrow[qt]) * a.Lk + key] * LOG2E;
+          const float p = exp2f(s - lse2[qt]);
+          float dp = dpacc[qt][t][r];
+          if (a.drop_p > 0.f) dp = bb_keep(a.seed, attn_elem(a, b, h, qrow[qt], key), a.drop_thr) ? dp * keep_scale : 0.f;
+          const float ds = valid ? p * (dp - dlt[qt]) : 0.f;
+          sacc[qt][t][r] = ds;
+          if (a.dbias && valid) atomicAdd(a.dbias + ((size_t)b * a.Lq + qrow[qt]) * a.Lk + key, ds);
+        }
+      }
+    bf16x8 dsb[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      dsb[qt][0] = pack_pair(sacc[qt][0], sacc[qt][1]);
+      dsb[qt][1] = pack_pair(sacc[qt][2], sacc[qt][3]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const bf16x8 kt = lds_frag_cols(s_kt, dt, m, lane);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) dqacc[qt][dt] = mfma16(kt, dsb[qt][m], dqacc[qt][dt]);
+      }
+  }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+    if (qrow[qt] < a.Lq) {
+      bf16_raw* dqp = (bf16_raw*)a.dq + (size_t)b * a.bsq + (size_t)qrow[qt] * a.ldq + h * ATTN_D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        st4<bf16_raw>(dqp + dt * 16 + g * 4,
+                      make_float4(dqacc[qt][dt][0] * a.scale, dqacc[qt][dt][1] * a.scale, dqacc[qt][dt][2] * a.scale,
+                                  dqacc[qt][dt][3] * a.scale));
+    }
+}
+
+// =============================================================================================
+// Backward, part 2: dK, dV.  Wave w owns KT key tiles: keys k0 + (w*KT + kt)*16 + (l&15); loop over query tiles.
+//   S = Q K^T (A = Q tile rows, B = K fragments in registers) -> lane (key = l&15) holds S[q = 16 t + 4 g + r][key]
+//   dV^T += dO^T Pd ;  dK^T += Q^T dS      (A = transposed dO / Q tiles, B = packed Pd / dS, k-slots <-> queries)
+// =============================================================================================
+template <int KT>
+__global__ __launch_bounds__(256) void attn_mfma_dkv_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_raw s_q[TK * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_do[TK * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_qt[ATTN_D * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_dot[ATTN_D * LDT];
+  __shared__ __attribute__((aligned(16))) float s_lse2[TK];
+  __shared__ __attribute__((aligned(16))) float s_dlt[TK];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int kbase = blockIdx.x * (64 * KT) + w * (16 * KT);
+  const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
+  const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
+  const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
+  const bf16_raw* dop = (const bf16_raw*)a.dout + (size_t)b * a.bso + h * ATTN_D;
+  const float sc2 = a.scale * LOG2E;
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+
+  bf16x8 kf[KT][2], vf[KT][2];
+  int krow[KT];
+  float mask2[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    krow[kt] = kbase + kt * 16 + c;
+    const int r = krow[kt] < a.Lk ? krow[kt] : a.Lk - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[kt][ks] = as_bf16x8(ld_frag_global(kp, a.ldk, r, ks * 32 + g * 8));
+      vf[kt][ks] = as_bf16x8(ld_frag_global(vp, a.ldv, r, ks * 32 + g * 8));
+    }
+    mask2[kt] = a.key_mask ? a.key_mask[(size_t)b * a.Lk + r] * LOG2E : 0.f;
+  }
+  f32x4 dkacc[KT][4], dvacc[KT][4];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dkacc[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dvacc[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+  for (int q0 = 0; q0 < a.Lq; q0 += TK) {
+    __syncthreads();
+    stage_rows(s_q, qp, a.ldq, q0, a.Lq, tid);
+    stage_rows(s_do, dop, a.ldo, q0, a.Lq, tid);
+    stage_cols(s_qt, qp, a.ldq, q0, a.Lq, tid);
+    stage_cols(s_dot, dop, a.ldo, q0, a.Lq, tid);
+    if (tid < TK) {
+      const int qi = q0 + tid;
+      const size_t ridx = ((size_t)b * a.nh + h) * a.Lq + (qi < a.Lq ? qi : a.Lq - 1);
+      s_lse2[tid] = qi < a.Lq ? a.lse[ridx] * LOG2E : INFINITY;  // +inf -> p = 0 for padding rows
+      s_dlt[tid] = a.delta[ridx];
+    }
+    __syncthreads();
+
+    f32x4 sacc[KT][4], dpacc[KT][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        sacc[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dpacc[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 qa = lds_frag_rows(s_q, t, ks, lane);
+        const bf16x8 da = lds_frag_rows(s_do, t, ks, lane);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          sacc[kt][t] = mfma16(qa, kf[kt][ks], sacc[kt][t]);
+          dpacc[kt][t] = mfma16(da, vf[kt][ks], dpacc[kt][t]);
+        }
+      }
+    }
+    // sacc -> dS, dpacc -> dropped P
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float4 l4 = *reinterpret_cast<const float4*>(&s_lse2[t * 16 + g * 4]);
+      const float4 d4 = *reinterpret_cast<const float4*>(&s_dlt[t * 16 + g * 4]);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = q0 + t * 16 + g * 4 + r;
+          float s = sacc[kt][t][r] * sc2 + mask2[kt];
+          if (a.bias && qi < a.Lq && krow[kt] < a.Lk)
+            s += a.bias[((size_t)b * a.Lq + qi) * a.Lk + krow[kt]] * LOG2E;
+          const float p = exp2f(s - lv[r]);
+          float dp = dpacc[kt][t][r], pd = p;
+          if (a.drop_p > 0.f) {
+            const bool keep = bb_keep(a.seed, attn_elem(a, b, h, qi, krow[kt]), a.drop_thr);
+            dp = keep ? dp * keep_scale : 0.f;
+            pd = keep ? p * keep_scale : 0.f;
+          }
+          sacc[kt][t][r] = p * (dp - dv[r]);
+          dpacc[kt][t][r] = pd;
+        }
+    }
+    bf16x8 dsb[KT][2], pdb[KT][2];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      dsb[kt][0] = pack_pair(sacc[kt][0], sacc[kt][1]);
+      dsb[kt][1] = pack_pair(sacc[kt][2], sacc[kt][3]);
+      pdb[kt][0] = pack_pair(dpacc[kt][0], dpacc[kt][1]);
+      pdb[kt][1] = pack_pair(dpacc[kt][2], dpacc[kt][3]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const bf16x8 qt_ = lds_frag_cols(s_qt, dt, m, lane);
+        const bf16x8 dot_ = lds_frag_cols(s_dot, dt, m, lane);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          dkacc[kt][dt] = mfma16(qt_, dsb[kt][m], dkacc[kt][dt]);
+          dvacc[kt][dt] = mfma16(dot_, pdb[kt][m], dvacc[kt][dt]);
+        }
+      }
+  }
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+    if (krow[kt] < a.Lk) {
+      bf16_raw* dkp = (bf16_raw*)a.dk + (size_t)b * a.bsk + (size_t)krow[kt] * a.ldk + h * ATTN_D;
+      bf16_raw* dvp = (bf16_raw*)a.dv + (size_t)b * a.bsv + (size_t)krow[kt] * a.ldv + h * ATTN_D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        st4<bf16_raw>(dkp + dt * 16 + g * 4,
+                      make_float4(dkacc[kt][dt][0] * a.scale, dkacc[kt][dt][1] * a.scale, dkacc[kt][dt][2] * a.scale,
+                                  dkacc[kt][dt][3] * a.scale));
+        st4<bf16_raw>(dvp + dt * 16 + g * 4,
+                      make_float4(dvacc[kt][dt][0], dvacc[kt][dt][1], dvacc[kt][dt][2], dvacc[kt][dt][3]));
+      }
+    }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+static bool aligned8(const AttnArgs& a) {
+  return a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0 && a.bsq % 8 == 0 && a.bsk % 8 == 0 &&
+         a.bsv % 8 == 0 && a.bso % 8 == 0 && ((uintptr_t)a.q % 16) == 0 && ((uintptr_t)a.k % 16) == 0 &&
+         ((uintptr_t)a.v % 16) == 0 && ((uintptr_t)a.o % 16) == 0;
+}
+
+int attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
+  BB_REQUIRE(aligned8(a), "attention (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
+  if (a.Lq > 64) {
+    hipLaunchKernelGGL(attn_mfma_fwd_kernel<2>, dim3((a.Lq + 127) / 128, a.nh, a.B), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(attn_mfma_fwd_kernel<1>, dim3((a.Lq + 63) / 64, a.nh, a.B), dim3(256), 0, st, a);
+  }
+  BB_CHECK_LAUNCH("attn_fwd(mfma)");
+  return BB_OK;
+}
+
+int attn_mfma_bwd(const AttnArgs& a, hipStream_t st) {
+  BB_REQUIRE(aligned8(a), "attention (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
+  BB_REQUIRE(((uintptr_t)a.dout % 16) == 0 && ((uintptr_t)a.dq % 16) == 0 && ((uintptr_t)a.dk % 16) == 0 &&
+                 ((uintptr_t)a.dv % 16) == 0, "attention bwd (MFMA path): gradient pointers must be 16-byte aligned");
+  if (a.Lq > 64)
+    hipLaunchKernelGGL(attn_mfma_dq_kernel<2>, dim3((a.Lq + 127) / 128, a.nh, a.B), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(attn_mfma_dq_kernel<1>, dim3((a.Lq + 63) / 64, a.nh, a.B), dim3(256), 0, st, a);
+  if (a.Lk > 64)
+    hipLaunchKernelGGL(attn_mfma_dkv_kernel<2>, dim3((a.Lk + 127) / 128, a.nh, a.B), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(attn_mfma_dkv_kernel<1>, dim3((a.Lk + 63) / 64, a.nh, a.B), dim3(256), 0, st, a);
+  BB_CHECK_LAUNCH("attn_bwd(mfma)");
+  return BB_OK;
+}

@@ -1,0 +1,100 @@
+// C-ABI glue: error channel, version, and the attention entry points that pick between the exact (fp32 arithmetic)
+// kernels and the MFMA (bf16) kernels.  Declarations: include/bevbert_hip.h.
+#include <stdarg.h>
+
+#include "attn_common.h"
+
+static thread_local char g_err[512] = "";
+
+void bb_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+BEVBERT_API const char* bevbert_last_error(void) { return g_err; }
+BEVBERT_API int bevbert_version(void) { return 100; }  // 0.1.0
+BEVBERT_API const char* bevbert_arch(void) { return "gfx950"; }
+
+int attn_simple_fwd(const AttnArgs& a, int dtype, hipStream_t st);
+int attn_simple_bwd(const AttnArgs& a, int dtype, hipStream_t st);
+int attn_delta(const AttnArgs& a, float* delta, int dtype, hipStream_t st);
+int attn_mfma_fwd(const AttnArgs& a, hipStream_t st);
+int attn_mfma_bwd(const AttnArgs& a, hipStream_t st);
+
+// impl: 0 = auto (bf16 -> MFMA, f32 -> exact), 1 = force exact kernels, 2 = force MFMA (bf16 only)
+static int pick_impl(int dtype, int impl) {
+  if (impl == 0) return dtype == BB_BF16 ? 2 : 1;
+  return impl;
+}
+
+static int fill_common(AttnArgs& a, const void* q, const void* k, const void* v, const float* key_mask,
+                       const float* bias, const int64_t* strides, int B, int nh, int Lq, int Lk, int head_dim,
+                       float scale, float drop_p, uint64_t seed, uint64_t offset) {
+  BB_REQUIRE(head_dim == ATTN_D, "attention: head_dim=%d unsupported (kernels are specialised for 64)", head_dim);
+  BB_REQUIRE(B > 0 && nh > 0 && Lq > 0 && Lk > 0, "attention: empty problem B=%d nh=%d Lq=%d Lk=%d", B, nh, Lq, Lk);
+  BB_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention: dropout p=%f", drop_p);
+  memset(&a, 0, sizeof(a));
+  a.q = q; a.k = k; a.v = v; a.key_mask = key_mask; a.bias = bias;
+  a.ldq = strides[0]; a.ldk = strides[1]; a.ldv = strides[2]; a.ldo = strides[3];
+  a.bsq = strides[4]; a.bsk = strides[5]; a.bsv = strides[6]; a.bso = strides[7];
+  a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
+  a.drop_p = drop_p; a.drop_thr = bb_drop_threshold(drop_p); a.seed = seed; a.offset = offset;
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                                 const float* key_mask, const float* bias, const int64_t* strides, int B, int nh,
+                                 int Lq, int Lk, int head_dim, float scale, int dtype, int impl, float drop_p,
+                                 uint64_t seed, uint64_t offset, hipStream_t stream) {
+  AttnArgs a;
+  int rc = fill_common(a, q, k, v, key_mask, bias, strides, B, nh, Lq, Lk, head_dim, scale, drop_p, seed, offset);
+  if (rc != BB_OK) return rc;
+  a.o = o; a.lse = lse;
+  BB_REQUIRE(dtype == BB_F32 || dtype == BB_BF16, "attn_fwd: dtype %d unsupported", dtype);
+  const int im = pick_impl(dtype, impl);
+  if (im == 2) {
+    BB_REQUIRE(dtype == BB_BF16, "attn_fwd: the MFMA path takes bf16 tensors");
+    return attn_mfma_fwd(a, stream);
+  }
+  return attn_simple_fwd(a, dtype, stream);
+}
+
+BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                                 const float* lse, float* delta_ws, void* dq, void* dk, void* dv, float* dbias,
+                                 const float* key_mask, const float* bias, const int64_t* strides, int B, int nh,
+                                 int Lq, int Lk, int head_dim, float scale, int dtype, int impl, float drop_p,
+                                 uint64_t seed, uint64_t offset, hipStream_t stream) {
+  AttnArgs a;
+  int rc = fill_common(a, q, k, v, key_mask, bias, strides, B, nh, Lq, Lk, head_dim, scale, drop_p, seed, offset);
+  if (rc != BB_OK) return rc;
+  BB_REQUIRE(dtype == BB_F32 || dtype == BB_BF16, "attn_bwd: dtype %d unsupported", dtype);
+  BB_REQUIRE(lse != nullptr && delta_ws != nullptr, "attn_bwd: lse and the (B,nh,Lq) delta workspace are required");
+  a.o = const_cast<void*>(o); a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta_ws;
+  a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
+  rc = attn_delta(a, delta_ws, dtype, stream);
+  if (rc != BB_OK) return rc;
+  const int im = pick_impl(dtype, impl);
+  if (im == 2) {
+    BB_REQUIRE(dtype == BB_BF16, "attn_bwd: the MFMA path takes bf16 tensors");
+    return attn_mfma_bwd(a, stream);
+  }
+  return attn_simple_bwd(a, dtype, stream);
+}
+
+// Test hook: materialise the dropout keep-mask the kernels derive from (seed, offset + element index).
+__global__ void keep_mask_kernel(uint8_t* out, size_t n, uint64_t seed, uint64_t offset, uint32_t thr) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = (uint8_t)bb_keep(seed, offset + i, thr);
+}
+BEVBERT_API int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p, uint64_t seed, uint64_t offset,
+                                          hipStream_t stream) {
+  if (n <= 0) return BB_OK;
+  size_t nb = ((size_t)n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(keep_mask_kernel, dim3(nb), dim3(256), 0, stream, out, (size_t)n, seed, offset,
+                     bb_drop_threshold(drop_p));
+  BB_CHECK_LAUNCH("dropout_keep_mask");
+  return BB_OK;
+}

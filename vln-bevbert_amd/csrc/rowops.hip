@@ -1,0 +1,562 @@
+// HBM-bound row kernels: K3 bias+dropout+residual+LayerNorm (fwd/bwd), K4 bias+erf-GELU (fwd/bwd),
+// K5 embedding-sum+LayerNorm, K6 weighted segment gather (gmap aggregation fwd and bwd), column sums,
+// and the flat-arena optimiser kernels (K7 fused AdamW, grad-norm, clip coefficient).
+//
+// Reference call sites replaced:
+//   BertSelfOutput / BertOutput            pretrain_src/model/vilmodel.py:143-154,182-193  (dense bias + dropout + add + LN)
+//   BertIntermediate + gelu                vilmodel.py:31-37,168-180
+//   BertEmbeddings                         vilmodel.py:48-77
+//   _aggregate_gmap_features               vilmodel.py:632-666 (Python dict loops -> one CSR gather)
+//   clip_grad_norm_ + AdamW.step           pretrain_src/train_r2r.py:295-306, pretrain_src/optim/adamw.py:53-112
+//
+// Layout: activations are (rows, H) row-major with H % 256 == 0; one 64-lane wave owns one row and keeps it in
+// registers (H/64 values per lane as float4s), so each tensor is read once and written once; statistics are fp32.
+#include "common.h"
+
+// =============================================================================================
+// LayerNorm forward:  z = dropout(x + bias) + residual ;  y = (z - mean) * rstd * gamma + beta
+// GATHER: x row = word[ids[row]] + pos[row % L] + type_row   (BertEmbeddings)
+// =============================================================================================
+template <typename T, int NV, bool GATHER>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                     const T* __restrict__ residual, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     T* __restrict__ z_out, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int rows, float eps, float drop_p,
+                                                     uint32_t drop_thr, uint64_t seed, uint64_t offset,
+                                                     const int64_t* __restrict__ ids, const T* __restrict__ word,
+                                                     const T* __restrict__ pos, const T* __restrict__ type_row, int L) {
+  constexpr int H = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float4 v[NV];
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    float4 a;
+    if (GATHER) {
+      const int64_t id = ids[row];
+      a = ld4<T>(word + (size_t)id * H + col);
+      const float4 p = ld4<T>(pos + (size_t)(row % L) * H + col);
+      const float4 t = ld4<T>(type_row + col);
+      a.x = (a.x + p.x) + t.x; a.y = (a.y + p.y) + t.y; a.z = (a.z + p.z) + t.z; a.w = (a.w + p.w) + t.w;
+    } else {
+      a = ld4<T>(x + (size_t)row * H + col);
+    }
+    if (bias != nullptr) {
+      const float4 bb = *reinterpret_cast<const float4*>(bias + col);
+      a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
+    }
+    if (drop_p > 0.f) {
+      const uint64_t e = offset + (uint64_t)row * H + col;
+      a.x = bb_keep(seed, e + 0, drop_thr) ? a.x * keep_scale : 0.f;
+      a.y = bb_keep(seed, e + 1, drop_thr) ? a.y * keep_scale : 0.f;
+      a.z = bb_keep(seed, e + 2, drop_thr) ? a.z * keep_scale : 0.f;
+      a.w = bb_keep(seed, e + 3, drop_thr) ? a.w * keep_scale : 0.f;
+    }
+    if (residual != nullptr) {
+      const float4 r = ld4<T>(residual + (size_t)row * H + col);
+      a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    }
+    v[i] = a;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    if (z_out != nullptr) st4<T>(z_out + (size_t)row * H + col, v[i]);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + col);
+    const float4 b = *reinterpret_cast<const float4*>(beta + col);
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * g.x + b.x;
+    o.y = (v[i].y - mean) * rstd * g.y + b.y;
+    o.z = (v[i].z - mean) * rstd * g.z + b.z;
+    o.w = (v[i].w - mean) * rstd * g.w + b.w;
+    st4<T>(y + (size_t)row * H + col, o);
+  }
+}
+
+// =============================================================================================
+// LayerNorm backward.  Given dy, the saved z, mean, rstd:
+//   dz = rstd * (g*dy - mean_H(g*dy) - xhat * mean_H(g*dy*xhat))        -> d(residual)
+//   dx = dz * keep/(1-p)                                                  -> d(dense output)   (== dz when p == 0)
+//   per-column partial sums of dy*xhat (dgamma), dy (dbeta), dx (dbias) -> partials[block][3][H]
+// Persistent-style grid: each wave strides over rows and keeps its column partials in registers.
+// =============================================================================================
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, T* __restrict__ dz_out,
+                                                     T* __restrict__ dx_out, float* __restrict__ partials, int rows,
+                                                     float drop_p, uint32_t drop_thr, uint64_t seed, uint64_t offset) {
+  constexpr int H = NV * 256;
+  __shared__ float4 s_red[3][4][NV * 64];  // [which][wave][lane-major float4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  float4 ag[NV], ab[NV], ax[NV];
+  float4 g[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    ag[i] = ab[i] = ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    g[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 d[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int col = (i * 64 + lane) * 4;
+      d[i] = ld4<T>(dy + (size_t)row * H + col);
+      const float4 zz = ld4<T>(z + (size_t)row * H + col);
+      xh[i] = make_float4((zz.x - mu) * rs, (zz.y - mu) * rs, (zz.z - mu) * rs, (zz.w - mu) * rs);
+      ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+      ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+      d[i].x *= g[i].x; d[i].y *= g[i].y; d[i].z *= g[i].z; d[i].w *= g[i].w;
+      s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+      s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+    }
+    s1 = wave_sum(s1) * (1.0f / H);
+    s2 = wave_sum(s2) * (1.0f / H);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int col = (i * 64 + lane) * 4;
+      float4 o;
+      o.x = rs * (d[i].x - s1 - xh[i].x * s2);
+      o.y = rs * (d[i].y - s1 - xh[i].y * s2);
+      o.z = rs * (d[i].z - s1 - xh[i].z * s2);
+      o.w = rs * (d[i].w - s1 - xh[i].w * s2);
+      if (dz_out != nullptr) st4<T>(dz_out + (size_t)row * H + col, o);
+      if (drop_p > 0.f) {
+        const uint64_t e = offset + (uint64_t)row * H + col;
+        o.x = bb_keep(seed, e + 0, drop_thr) ? o.x * keep_scale : 0.f;
+        o.y = bb_keep(seed, e + 1, drop_thr) ? o.y * keep_scale : 0.f;
+        o.z = bb_keep(seed, e + 2, drop_thr) ? o.z * keep_scale : 0.f;
+        o.w = bb_keep(seed, e + 3, drop_thr) ? o.w * keep_scale : 0.f;
+      }
+      if (dx_out != nullptr) st4<T>(dx_out + (size_t)row * H + col, o);
+      ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    s_red[0][wave][i * 64 + lane] = ag[i];
+    s_red[1][wave][i * 64 + lane] = ab[i];
+    s_red[2][wave][i * 64 + lane] = ax[i];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 3 * NV * 64; k += 256) {
+    const int which = k / (NV * 64), j = k % (NV * 64);
+    float4 a = s_red[which][0][j];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 t = s_red[which][w][j];
+      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    *reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * 3 + which) * H + j * 4) = a;
+  }
+}
+
+// out[c] (+)= sum_b partials[b][which][c]   (fixed order => deterministic)
+__global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nblocks, int nwhich, int which, int C,
+                                       float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partials[((size_t)b * nwhich + which) * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// =============================================================================================
+// bias + erf-GELU forward / backward, and a plain column sum (QKV bias grads)
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                            T* __restrict__ y, size_t n4, int C) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const int col = (int)((i * 4) % C);
+    float4 a = ld4<T>(x + i * 4);
+    const float4 b = *reinterpret_cast<const float4*>(bias + col);
+    a.x = gelu_erf(a.x + b.x); a.y = gelu_erf(a.y + b.y); a.z = gelu_erf(a.z + b.z); a.w = gelu_erf(a.w + b.w);
+    st4<T>(y + i * 4, a);
+  }
+}
+
+// MODE 0: dx = dy * gelu'(x + bias) ; partial column sums of dx.   MODE 1: plain column sums of dy (no dx).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colwise_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ bias, T* __restrict__ dx,
+                                                          float* __restrict__ partials, int rows, int C) {
+  // thread t owns columns [4t, 4t+4) + k*1024
+  for (int c0 = threadIdx.x * 4; c0 < C; c0 += 1024) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 0) b = *reinterpret_cast<const float4*>(bias + c0);
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+      float4 d = ld4<T>(dy + (size_t)r * C + c0);
+      if (MODE == 0) {
+        const float4 a = ld4<T>(x + (size_t)r * C + c0);
+        d.x *= gelu_erf_grad(a.x + b.x); d.y *= gelu_erf_grad(a.y + b.y);
+        d.z *= gelu_erf_grad(a.z + b.z); d.w *= gelu_erf_grad(a.w + b.w);
+        st4<T>(dx + (size_t)r * C + c0, d);
+      }
+      acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+    }
+    *reinterpret_cast<float4*>(partials + (size_t)blockIdx.x * C + c0) = acc;
+  }
+}
+
+// =============================================================================================
+// K6: weighted segment gather: out[r] = sum_{e in [rowptr[r], rowptr[r+1])} w[e] * src[idx[e]]
+// (gmap node aggregation with the CSR built on the host from the vpid lists; its backward is the same
+//  kernel over the transposed CSR).
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(192) void gather_wsum_kernel(const T* __restrict__ src, const int* __restrict__ rowptr,
+                                                          const int* __restrict__ idx, const float* __restrict__ w,
+                                                          T* __restrict__ out, int H) {
+  const int r = blockIdx.x;
+  const int e0 = rowptr[r], e1 = rowptr[r + 1];
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = e0; e < e1; ++e) {
+      const float ww = w[e];
+      const float4 v = ld4<T>(src + (size_t)idx[e] * H + c);
+      acc.x += ww * v.x; acc.y += ww * v.y; acc.z += ww * v.z; acc.w += ww * v.w;
+    }
+    st4<T>(out + (size_t)r * H + c, acc);
+  }
+}
+
+// =============================================================================================
+// Flat-arena optimiser kernels.  The arena is padded so every tensor starts on a 1024-element
+// boundary; flags[i] describes chunk i: bit0 = apply weight decay, bit1 = tensor has ever had a
+// gradient (the reference skips params whose .grad is None: adamw.py:66-67).
+// =============================================================================================
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n4, float* __restrict__ partials) {
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = *reinterpret_cast<const float4*>(g + i * 4);
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  __shared__ float sh[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// scalars[0] = total L2 norm of (pre_scale * g) ; scalars[1] = multiplier the optimiser applies to g:
+//   pre_scale * min(1, max_norm / (norm + 1e-6))      (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* __restrict__ partials, int n, float pre_scale, float max_norm,
+                                 float* __restrict__ scalars) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(sh[0]) * pre_scale;
+    float coef = 1.0f;
+    if (max_norm > 0.f) {
+      coef = max_norm / (norm + 1e-6f);
+      coef = coef < 1.0f ? coef : 1.0f;
+    }
+    scalars[0] = norm;
+    scalars[1] = pre_scale * coef;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_raw* __restrict__ p_bf16, const uint8_t* __restrict__ flags,
+                                                    size_t nchunks, const float* __restrict__ gscale_ptr, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float step_size) {
+  const size_t chunk = blockIdx.x;
+  if (chunk >= nchunks) return;
+  const uint8_t f = flags[chunk];
+  if (!(f & 2)) return;
+  const float gs = gscale_ptr ? *gscale_ptr : 1.0f;
+  const float decay = (f & 1) ? lr * wd : 0.f;
+  const size_t i = chunk * 1024 + threadIdx.x * 4;
+  const float4 gg = *reinterpret_cast<const float4*>(g + i);
+  float4 pp = *reinterpret_cast<float4*>(p + i);
+  float4 mm = *reinterpret_cast<float4*>(m + i);
+  float4 vv = *reinterpret_cast<float4*>(v + i);
+#define UPD(c)                                                    \
+  {                                                               \
+    const float gr = gg.c * gs;                                   \
+    mm.c = mm.c * beta1 + (1.0f - beta1) * gr;                    \
+    vv.c = vv.c * beta2 + (1.0f - beta2) * gr * gr;               \
+    pp.c = pp.c - step_size * (mm.c / (sqrtf(vv.c) + eps));       \
+    pp.c = pp.c - decay * pp.c;                                   \
+  }
+  UPD(x) UPD(y) UPD(z) UPD(w)
+#undef UPD
+  *reinterpret_cast<float4*>(p + i) = pp;
+  *reinterpret_cast<float4*>(m + i) = mm;
+  *reinterpret_cast<float4*>(v + i) = vv;
+  if (p_bf16 != nullptr) st4<bf16_raw>(p_bf16 + i, pp);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void cast_f32_kernel(const float* __restrict__ src, TO* __restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+    st4<TO>(dst + i * 4, *reinterpret_cast<const float4*>(src + i * 4));
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+template <typename T, bool GATHER>
+static int ln_fwd_dispatch(int NV, dim3 grid, hipStream_t st, const void* x, const float* bias, const void* residual,
+                           const float* gamma, const float* beta, void* y, void* z_out, float* mean, float* rstd,
+                           int rows, float eps, float p, uint64_t seed, uint64_t offset, const int64_t* ids,
+                           const void* word, const void* pos, const void* type_row, int L) {
+  const uint32_t thr = bb_drop_threshold(p);
+#define GO(N)                                                                                                        \
+  case N:                                                                                                            \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, N, GATHER>), grid, dim3(256), 0, st, (const T*)x, bias, (const T*)residual, \
+                       gamma, beta, (T*)y, (T*)z_out, mean, rstd, rows, eps, p, thr, seed, offset, ids,              \
+                       (const T*)word, (const T*)pos, (const T*)type_row, L);                                        \
+    break;
+  switch (NV) {
+    GO(1) GO(2) GO(3) GO(4) GO(6) GO(8)
+    default:
+      bb_set_error("layernorm: H=%d unsupported (need H in {256,512,768,1024,1536,2048})", NV * 256);
+      return BB_EUNSUPPORTED;
+  }
+#undef GO
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_bias_dropout_residual_layernorm_fwd(const void* x, const float* bias, const void* residual,
+                                                           const float* gamma, const float* beta, void* y, void* z_out,
+                                                           float* mean, float* rstd, int rows, int H, float eps,
+                                                           int dtype, float drop_p, uint64_t seed, uint64_t offset,
+                                                           hipStream_t stream) {
+  BB_REQUIRE(rows >= 0 && H % 256 == 0, "layernorm_fwd: H=%d must be a multiple of 256", H);
+  BB_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_fwd: dropout p=%f", drop_p);
+  if (rows == 0) return BB_OK;
+  const dim3 grid((rows + 3) / 4);
+  int rc;
+  if (dtype == BB_F32)
+    rc = ln_fwd_dispatch<float, false>(H / 256, grid, stream, x, bias, residual, gamma, beta, y, z_out, mean, rstd,
+                                       rows, eps, drop_p, seed, offset, nullptr, nullptr, nullptr, nullptr, 1);
+  else if (dtype == BB_BF16)
+    rc = ln_fwd_dispatch<bf16_raw, false>(H / 256, grid, stream, x, bias, residual, gamma, beta, y, z_out, mean, rstd,
+                                          rows, eps, drop_p, seed, offset, nullptr, nullptr, nullptr, nullptr, 1);
+  else {
+    bb_set_error("layernorm_fwd: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  if (rc != BB_OK) return rc;
+  BB_CHECK_LAUNCH("layernorm_fwd");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const void* pos,
+                                                const void* type_row, const float* gamma, const float* beta, void* y,
+                                                void* z_out, float* mean, float* rstd, int rows, int L, int H,
+                                                float eps, int dtype, float drop_p, uint64_t seed, uint64_t offset,
+                                                hipStream_t stream) {
+  BB_REQUIRE(rows >= 0 && H % 256 == 0 && L > 0, "embed_sum_layernorm_fwd: bad shape rows=%d L=%d H=%d", rows, L, H);
+  if (rows == 0) return BB_OK;
+  const dim3 grid((rows + 3) / 4);
+  int rc;
+  if (dtype == BB_F32)
+    rc = ln_fwd_dispatch<float, true>(H / 256, grid, stream, nullptr, nullptr, nullptr, gamma, beta, y, z_out, mean,
+                                      rstd, rows, eps, drop_p, seed, offset, ids, word, pos, type_row, L);
+  else if (dtype == BB_BF16)
+    rc = ln_fwd_dispatch<bf16_raw, true>(H / 256, grid, stream, nullptr, nullptr, nullptr, gamma, beta, y, z_out, mean,
+                                         rstd, rows, eps, drop_p, seed, offset, ids, word, pos, type_row, L);
+  else {
+    bb_set_error("embed_sum_layernorm_fwd: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  if (rc != BB_OK) return rc;
+  BB_CHECK_LAUNCH("embed_sum_layernorm_fwd");
+  return BB_OK;
+}
+
+static int partial_blocks(int rows, int per_block) {
+  int nb = (rows + per_block - 1) / per_block;
+  if (nb > 512) nb = 512;
+  return nb < 1 ? 1 : nb;
+}
+
+// workspace: >= bevbert_colsum_workspace_floats(3*H) floats
+BEVBERT_API int64_t bevbert_colsum_workspace_floats(int total_cols) { return (int64_t)512 * total_cols; }
+
+BEVBERT_API int bevbert_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd,
+                                      const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta,
+                                      float* dbias, float* workspace, int rows, int H, int dtype, float drop_p,
+                                      uint64_t seed, uint64_t offset, int accumulate, hipStream_t stream) {
+  BB_REQUIRE(H % 256 == 0, "layernorm_bwd: H=%d must be a multiple of 256", H);
+  if (rows <= 0) return BB_OK;
+  const int nb = partial_blocks(rows, 16);
+  const uint32_t thr = bb_drop_threshold(drop_p);
+#define GO(T, N)                                                                                              \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, N>), dim3(nb), dim3(256), 0, stream, (const T*)dy, (const T*)z, mean, \
+                     rstd, gamma, (T*)dz, (T*)dx, workspace, rows, drop_p, thr, seed, offset)
+#define SW(T)                                                                     \
+  switch (H / 256) {                                                              \
+    case 1: GO(T, 1); break;                                                      \
+    case 2: GO(T, 2); break;                                                      \
+    case 3: GO(T, 3); break;                                                      \
+    case 4: GO(T, 4); break;                                                      \
+    default: bb_set_error("layernorm_bwd: H=%d unsupported", H); return BB_EUNSUPPORTED; \
+  }
+  if (dtype == BB_F32) { SW(float) } else if (dtype == BB_BF16) { SW(bf16_raw) } else {
+    bb_set_error("layernorm_bwd: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+#undef SW
+#undef GO
+  BB_CHECK_LAUNCH("layernorm_bwd");
+  const dim3 fg((H + 255) / 256);
+  if (dgamma) hipLaunchKernelGGL(colsum_finalize_kernel, fg, dim3(256), 0, stream, workspace, nb, 3, 0, H, dgamma, accumulate);
+  if (dbeta) hipLaunchKernelGGL(colsum_finalize_kernel, fg, dim3(256), 0, stream, workspace, nb, 3, 1, H, dbeta, accumulate);
+  if (dbias) hipLaunchKernelGGL(colsum_finalize_kernel, fg, dim3(256), 0, stream, workspace, nb, 3, 2, H, dbias, accumulate);
+  BB_CHECK_LAUNCH("layernorm_bwd finalize");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_bias_gelu_fwd(const void* x, const float* bias, void* y, int rows, int C, int dtype,
+                                      hipStream_t stream) {
+  BB_REQUIRE(C % 4 == 0, "bias_gelu_fwd: C=%d must be a multiple of 4", C);
+  if (rows <= 0) return BB_OK;
+  const size_t n4 = (size_t)rows * C / 4;
+  size_t nb = (n4 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL(bias_gelu_fwd_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)x, bias, (float*)y, n4, C);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL(bias_gelu_fwd_kernel<bf16_raw>, dim3(nb), dim3(256), 0, stream, (const bf16_raw*)x, bias, (bf16_raw*)y, n4, C);
+  else {
+    bb_set_error("bias_gelu_fwd: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("bias_gelu_fwd");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_bias_gelu_bwd(const void* dy, const void* x, const float* bias, void* dx, float* dbias,
+                                      float* workspace, int rows, int C, int dtype, int accumulate,
+                                      hipStream_t stream) {
+  BB_REQUIRE(C % 4 == 0, "bias_gelu_bwd: C=%d must be a multiple of 4", C);
+  if (rows <= 0) return BB_OK;
+  const int nb = partial_blocks(rows, 8);
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL((colwise_bwd_kernel<float, 0>), dim3(nb), dim3(256), 0, stream, (const float*)dy, (const float*)x, bias, (float*)dx, workspace, rows, C);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL((colwise_bwd_kernel<bf16_raw, 0>), dim3(nb), dim3(256), 0, stream, (const bf16_raw*)dy, (const bf16_raw*)x, bias, (bf16_raw*)dx, workspace, rows, C);
+  else {
+    bb_set_error("bias_gelu_bwd: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("bias_gelu_bwd");
+  if (dbias) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, nb, 1, 0, C, dbias, accumulate);
+    BB_CHECK_LAUNCH("bias_gelu_bwd finalize");
+  }
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_colsum(const void* dy, float* out, float* workspace, int rows, int C, int dtype, int accumulate,
+                               hipStream_t stream) {
+  BB_REQUIRE(C % 4 == 0, "colsum: C=%d must be a multiple of 4", C);
+  if (rows <= 0) return BB_OK;
+  const int nb = partial_blocks(rows, 8);
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL((colwise_bwd_kernel<float, 1>), dim3(nb), dim3(256), 0, stream, (const float*)dy, nullptr, nullptr, nullptr, workspace, rows, C);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL((colwise_bwd_kernel<bf16_raw, 1>), dim3(nb), dim3(256), 0, stream, (const bf16_raw*)dy, nullptr, nullptr, nullptr, workspace, rows, C);
+  else {
+    bb_set_error("colsum: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("colsum");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, nb, 1, 0, C, out, accumulate);
+  BB_CHECK_LAUNCH("colsum finalize");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_segment_wsum(const void* src, const int* rowptr, const int* idx, const float* w, void* out,
+                                     int out_rows, int H, int dtype, hipStream_t stream) {
+  BB_REQUIRE(H % 4 == 0, "segment_wsum: H=%d must be a multiple of 4", H);
+  if (out_rows <= 0) return BB_OK;
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL(gather_wsum_kernel<float>, dim3(out_rows), dim3(192), 0, stream, (const float*)src, rowptr, idx, w, (float*)out, H);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL(gather_wsum_kernel<bf16_raw>, dim3(out_rows), dim3(192), 0, stream, (const bf16_raw*)src, rowptr, idx, w, (bf16_raw*)out, H);
+  else {
+    bb_set_error("segment_wsum: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("segment_wsum");
+  return BB_OK;
+}
+
+// scalars: device float[2] -> {norm, grad multiplier}; partials: device float[1024]
+BEVBERT_API int bevbert_grad_norm_clip(const float* grads, int64_t n, float pre_scale, float max_norm,
+                                       float* partials, float* scalars, hipStream_t stream) {
+  BB_REQUIRE(n % 4 == 0, "grad_norm_clip: n must be a multiple of 4");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, stream, grads, (size_t)n / 4, partials);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, partials, 1024, pre_scale, max_norm, scalars);
+  BB_CHECK_LAUNCH("grad_norm_clip");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                   void* params_bf16, const uint8_t* chunk_flags, int64_t n,
+                                   const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, int64_t step, hipStream_t stream) {
+  BB_REQUIRE(n % 1024 == 0, "adamw_step: arena length must be a multiple of 1024 elements");
+  BB_REQUIRE(step >= 1, "adamw_step: step is the 1-based update count");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr * sqrt(bc2) / bc1);  // adamw.py:96-100
+  const size_t nchunks = (size_t)n / 1024;
+  hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq,
+                     (bf16_raw*)params_bf16, chunk_flags, nchunks, grad_scale_dev, lr, beta1, beta2, eps, weight_decay,
+                     step_size);
+  BB_CHECK_LAUNCH("adamw_step");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_cast_f32(const float* src, void* dst, int64_t n, int dst_dtype, hipStream_t stream) {
+  BB_REQUIRE(n % 4 == 0, "cast_f32: n must be a multiple of 4");
+  if (n == 0) return BB_OK;
+  size_t nb = ((size_t)n / 4 + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  if (dst_dtype == BB_BF16)
+    hipLaunchKernelGGL(cast_f32_kernel<bf16_raw>, dim3(nb), dim3(256), 0, stream, src, (bf16_raw*)dst, (size_t)n / 4);
+  else if (dst_dtype == BB_F16)
+    hipLaunchKernelGGL(cast_f32_kernel<_Float16>, dim3(nb), dim3(256), 0, stream, src, (_Float16*)dst, (size_t)n / 4);
+  else {
+    bb_set_error("cast_f32: dst dtype %d unsupported", dst_dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("cast_f32");
+  return BB_OK;
+}

@@ -1,0 +1,121 @@
+"""ctypes binding of libbevbert_hip.so (C ABI: include/bevbert_hip.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).
+There is deliberately NO fallback: if the library is missing or a call fails, an exception is raised --
+this package never routes work to PyTorch eager kernels or to the CPU oracle.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbevbert_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "capi.hip"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "bevbert_hip.h")
+
+F32, BF16, F16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+
+class BevBertHipError(RuntimeError):
+    pass
+
+
+def dtype_code(t):
+    try:
+        return _DT[t.dtype if torch.is_tensor(t) else t]
+    except KeyError:
+        raise BevBertHipError(f"unsupported dtype {t}") from None
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip into libbevbert_hip.so for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "attn_common.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+def header_symbols():
+    with open(HEADER) as f:
+        return sorted(set(re.findall(r"\b(bevbert_\w+)\s*\(", f.read())))
+
+
+_lib = None
+_P, _I, _I64, _U64, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
+
+_PROTOS = {
+    "bevbert_bev_lift_bin": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _F, _P, _P, _P, _P],
+    "bevbert_bev_bin_points": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P],
+    "bevbert_bev_splat_mean": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P],
+    "bevbert_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _F, _U64, _U64, _P],
+    "bevbert_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _F,
+                         _U64, _U64, _P],
+    "bevbert_bias_dropout_residual_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _F, _U64,
+                                                    _U64, _P],
+    "bevbert_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U64, _I, _P],
+    "bevbert_embed_sum_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _U64, _U64, _P],
+    "bevbert_bias_gelu_fwd": [_P, _P, _P, _I, _I, _I, _P],
+    "bevbert_bias_gelu_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "bevbert_colsum": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "bevbert_segment_wsum": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "bevbert_grad_norm_clip": [_P, _I64, _F, _F, _P, _P, _P],
+    "bevbert_adamw_step": [_P, _P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _F, _F, _I64, _P],
+    "bevbert_cast_f32": [_P, _P, _I64, _I, _P],
+    "bevbert_dropout_keep_mask": [_P, _I64, _F, _U64, _U64, _P],
+}
+
+
+def load():
+    """dlopen the library and type every entry point. Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BevBertHipError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no PyTorch/CPU fallback for the hot path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.bevbert_last_error.restype = ctypes.c_char_p
+    lib.bevbert_arch.restype = ctypes.c_char_p
+    lib.bevbert_version.restype = _I
+    lib.bevbert_colsum_workspace_floats.restype = _I64
+    lib.bevbert_colsum_workspace_floats.argtypes = [_I]
+    for name, args in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _I
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise BevBertHipError(f"{name} failed ({rc}): {lib.bevbert_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). The tensor must live on a HIP device."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise BevBertHipError("libbevbert_hip.so operates on device memory only; got a CPU tensor "
+                              "(no CPU fallback exists for the hot path)")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

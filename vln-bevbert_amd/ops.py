@@ -1,0 +1,599 @@
+"""Torch-facing wrappers over the C ABI (include/bevbert_hip.h) and their autograd Functions.
+
+PyTorch here is plumbing: device memory, streams, the library GEMMs (hipBLASLt behind torch.mm/F.linear -- the
+north star keeps Linear layers on the vendor BLAS) and the autograd tape.  Everything else on the hot path --
+attention, bias/dropout/residual/LayerNorm, bias+GELU, the BEV splat, gmap aggregation, the optimiser -- is a
+hand-written HIP kernel reached through ``lib.call``.  Nothing in this file has a CPU or eager fallback.
+
+Gradient sinks: a parameter that lives in a ParamArena (arena.py) carries ``main_grad`` (fp32 view of the flat
+gradient arena).  Backward kernels accumulate straight into that view and the Function returns ``None`` for the
+parameter, so there are no per-parameter AccumulateGrad kernels, no bucket copies for the all-reduce, and the
+optimiser sees one flat buffer.  Plain tensors (unit tests) get ordinary returned gradients.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import lib
+from .lib import call as _raw_call
+from .lib import dtype_code, ptr, stream
+
+HEAD_DIM = 64
+
+
+# ----------------------------------------------------------------------------- runtime state
+class _Runtime:
+    """Dropout stream + scratch buffers.  ``seed`` is set once per training step; ``offset`` advances by the
+    element count of every dropout site so that each site draws from a disjoint counter range."""
+
+    def __init__(self):
+        self.seed = 0x5EED
+        self.offset = 0
+        self.attn_impl = 0      # 0 auto, 1 exact kernels, 2 MFMA kernels
+        self._ws = {}
+
+    def next_offset(self, n):
+        off = self.offset
+        self.offset += int(n)
+        return off
+
+    def new_step(self, seed):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+
+    def workspace(self, device, nfloats):
+        key = (device.index, "ws")
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nfloats:
+            buf = torch.empty(max(int(nfloats), 512 * 3 * 3072), dtype=torch.float32, device=device)
+            self._ws[key] = buf
+        return buf
+
+
+RT = _Runtime()
+TRACE = None     # dict name -> [(start_event, end_event)] while bench.py's kernel-timing pass is active
+
+
+def call(name, *args):
+    """C-ABI call; when TRACE is armed, bracket the launch with HIP events on the launching stream."""
+    if TRACE is None:
+        return _raw_call(name, *args)
+    key = name
+    if name == "bevbert_attn_fwd":
+        key = f"{name}[Lq={args[10]},Lk={args[11]}]"
+    elif name == "bevbert_attn_bwd":
+        key = f"{name}[Lq={args[16]},Lk={args[17]}]"
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    _raw_call(name, *args)
+    e.record()
+    TRACE.setdefault(key, []).append((s, e, args))
+
+
+def _sink(param):
+    """fp32 accumulation target of a parameter, or None for plain tensors."""
+    return getattr(param, "main_grad", None)
+
+
+def _mark_touched(param):
+    arena = getattr(param, "arena", None)
+    if arena is not None:
+        arena.touch(param)
+
+
+def _compute(param):
+    """compute-dtype view of a parameter (bf16 shadow in mixed precision, the master itself in fp32)."""
+    return getattr(param, "compute", param)
+
+
+def _f32(param):
+    return param.detach() if param.dtype == torch.float32 else param.detach().float()
+
+
+class _UseParam(torch.autograd.Function):
+    """Bridge for the few tiny parameters consumed by plain torch ops (e.g. sprel_linear): hands out the fp32
+    master and routes the incoming gradient into the arena instead of ``.grad``."""
+
+    @staticmethod
+    def forward(ctx, p):
+        ctx.p = p
+        return p.detach().view_as(p)
+
+    @staticmethod
+    def backward(ctx, g):
+        p = ctx.p
+        sink = _sink(p)
+        if sink is None:
+            return g
+        _mark_touched(p)
+        sink.add_(g.to(sink.dtype))
+        return None
+
+
+def use_param(p):
+    return _UseParam.apply(p)
+
+
+# ----------------------------------------------------------------------------- K3 LayerNorm family
+class _BiasDropResLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, residual, gamma, beta, eps, drop_p, inplace_z):
+        assert x.is_contiguous() and x.dim() >= 2
+        H = x.shape[-1]
+        rows = x.numel() // H
+        y = torch.empty_like(x)
+        need_grad = any(ctx.needs_input_grad)
+        plain = bias is None and residual is None and drop_p == 0
+        z = (x if (inplace_z or plain) else torch.empty_like(x)) if need_grad else None
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
+        off = RT.next_offset(x.numel()) if drop_p > 0 else 0
+        if residual is not None:
+            assert residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype
+        call("bevbert_bias_dropout_residual_layernorm_fwd", ptr(x), ptr(_f32(bias)) if bias is not None else None,
+             ptr(residual), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(y), None if plain else ptr(z), ptr(mean), ptr(rstd),
+             rows, H, float(eps), dtype_code(x), float(drop_p), RT.seed, off, stream())
+        ctx.save_for_backward(z, mean, rstd)
+        ctx.params = (bias, gamma, beta)
+        ctx.cfg = (rows, H, float(drop_p), RT.seed, off, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd = ctx.saved_tensors
+        bias, gamma, beta = ctx.params
+        rows, H, drop_p, seed, off, has_res = ctx.cfg
+        dy = dy.contiguous()
+        dz = torch.empty_like(dy)
+        dx = torch.empty_like(dy) if (drop_p > 0 and has_res) else None
+        dev = dy.device
+        ws = RT.workspace(dev, lib.load().bevbert_colsum_workspace_floats(3 * H))
+        outs = []
+        for p in (gamma, beta, bias):
+            if p is None:
+                outs.append((None, None, 0))
+            elif _sink(p) is not None:
+                outs.append((_sink(p), None, 1))
+                _mark_touched(p)
+            else:
+                t = torch.empty(H, dtype=torch.float32, device=dev)
+                outs.append((t, t, 0))
+        (dg, rg, ag), (db, rb, ab), (dbi, rbi, abi) = outs
+        assert ag == ab and (bias is None or abi == ag), "mixed arena / plain parameters in one LayerNorm"
+        # without a residual branch only dx is needed (it is the single input gradient)
+        if not has_res and drop_p > 0:
+            dx, dz_ptr = dz, None
+        else:
+            dz_ptr = dz
+        call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz_ptr), ptr(dx),
+             ptr(dg), ptr(db), ptr(dbi), ptr(ws), rows, H, dtype_code(dy), drop_p, seed, off, ag, stream())
+        gx = dx if dx is not None else dz
+        gres = dz if has_res else None
+        cast = lambda r, p: None if r is None else r.to(p.dtype)
+        return gx, cast(rbi, bias) if bias is not None else None, gres, cast(rg, gamma), cast(rb, beta), None, None, None
+
+
+def bias_dropout_residual_layernorm(x, bias, residual, gamma, beta, eps, drop_p=0.0, training=False,
+                                    inplace_z=True):
+    """LayerNorm(dropout(x + bias) + residual)  -- vilmodel.py:150-154,189-193."""
+    p = float(drop_p) if training else 0.0
+    return _BiasDropResLN.apply(x, bias, residual, gamma, beta, eps, p, inplace_z)
+
+
+def layernorm(x, gamma, beta, eps):
+    return _BiasDropResLN.apply(x.contiguous(), None, None, gamma, beta, eps, 0.0, False)
+
+
+# ----------------------------------------------------------------------------- K4 bias + GELU
+class _BiasGelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        assert x.is_contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        call("bevbert_bias_gelu_fwd", ptr(x), ptr(_f32(bias)), ptr(y), rows, C, dtype_code(x), stream())
+        ctx.save_for_backward(x)
+        ctx.bias = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        bias = ctx.bias
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        ws = RT.workspace(dy.device, 512 * C)
+        sink = _sink(bias)
+        if sink is not None:
+            _mark_touched(bias)
+            call("bevbert_bias_gelu_bwd", ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), ptr(sink), ptr(ws), rows, C,
+                 dtype_code(dy), 1, stream())
+            return dx, None
+        db = torch.empty(C, dtype=torch.float32, device=dy.device)
+        call("bevbert_bias_gelu_bwd", ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), ptr(db), ptr(ws), rows, C,
+             dtype_code(dy), 0, stream())
+        return dx, db.to(bias.dtype)
+
+
+def bias_gelu(x, bias):
+    """gelu_erf(x + bias) -- vilmodel.py:31-37,177-180."""
+    return _BiasGelu.apply(x, bias)
+
+
+# ----------------------------------------------------------------------------- library GEMM with arena wgrad
+class _Linear(torch.autograd.Function):
+    """y = x W^T (+ b) on hipBLASLt; backward writes dW / db straight into the gradient arena."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_c, b_c):
+        y = F.linear(x, w_c, b_c)
+        ctx.save_for_backward(x, w_c)
+        ctx.params = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_c = ctx.saved_tensors
+        weight, bias = ctx.params
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = dy2.mm(w_c).view(x.shape) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if weight.requires_grad:
+            sink = _sink(weight)
+            if sink is not None:
+                _mark_touched(weight)
+                if dy2.dtype == torch.float32:
+                    sink.addmm_(dy2.t(), x2)
+                else:
+                    sink.add_(dy2.t().mm(x2))
+            else:
+                gw = dy2.t().mm(x2).to(weight.dtype)
+        if bias is not None and bias.requires_grad:
+            sink = _sink(bias)
+            C = dy2.shape[1]
+            if C % 4 != 0:                                  # e.g. the 1-wide heads: a library reduction is fine
+                s = dy2.float().sum(0)
+                if sink is not None:
+                    _mark_touched(bias)
+                    sink.add_(s)
+                else:
+                    gb = s.to(bias.dtype)
+            else:
+                ws = RT.workspace(dy.device, 512 * C)
+                dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+                if sink is not None:
+                    _mark_touched(bias)
+                    call("bevbert_colsum", ptr(dyc), ptr(sink), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 1, stream())
+                else:
+                    t = torch.empty(C, dtype=torch.float32, device=dy.device)
+                    call("bevbert_colsum", ptr(dyc), ptr(t), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 0, stream())
+                    gb = t.to(bias.dtype)
+        return dx, gw, gb, None, None
+
+
+def linear(x, weight, bias=None, w_c=None, b_c=None):
+    """F.linear with compute-dtype weights; ``weight``/``bias`` are the master parameters (gradient owners)."""
+    if w_c is None:
+        w_c = _compute(weight)
+    if bias is not None and b_c is None:
+        b_c = _compute(bias)
+    return _Linear.apply(x, weight, bias, w_c, b_c)
+
+
+class _PackedParam:
+    """A contiguous run of arena parameters used as one GEMM operand (packed QKV / KV projections)."""
+
+    def __init__(self, params, compute, main_grad):
+        self.params, self.compute, self.main_grad = params, compute, main_grad
+        self.requires_grad = any(p.requires_grad for p in params)
+        self.dtype = params[0].dtype
+        self.arena = getattr(params[0], "arena", None)
+
+    def touch(self):
+        for p in self.params:
+            _mark_touched(p)
+
+
+class _LinearPacked(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pw, pb):
+        ctx.save_for_backward(x)
+        ctx.packed = (pw, pb)
+        return F.linear(x, pw.compute, pb.compute)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        pw, pb = ctx.packed
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = dy2.mm(pw.compute).view(x.shape) if ctx.needs_input_grad[0] else None
+        if pw.requires_grad:
+            pw.touch()
+            if dy2.dtype == torch.float32:
+                pw.main_grad.addmm_(dy2.t(), x2)
+            else:
+                pw.main_grad.add_(dy2.t().mm(x2))
+            pb.touch()
+            C = dy2.shape[1]
+            ws = RT.workspace(dy.device, 512 * C)
+            dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+            call("bevbert_colsum", ptr(dyc), ptr(pb.main_grad), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 1, stream())
+        return dx, None, None
+
+
+def linear_packed(x, pw, pb):
+    return _LinearPacked.apply(x, pw, pb)
+
+
+# ----------------------------------------------------------------------------- K2 attention
+def _strides(q, k, v, o):
+    for t in (q, k, v, o):
+        assert t.dim() == 3 and t.stride(2) == 1, "attention operands are (B, L, nh*64) with unit inner stride"
+    import ctypes
+    arr = (ctypes.c_int64 * 8)(q.stride(1), k.stride(1), v.stride(1), o.stride(1),
+                               q.stride(0), k.stride(0), v.stride(0), o.stride(0))
+    return arr
+
+
+class _Attention(torch.autograd.Function):
+    """mode 'self': qkv packed (B,L,3H);  mode 'cross': q (B,Lq,H) + kv packed (B,Lk,2H);  mode 'sep': q,k,v."""
+
+    @staticmethod
+    def forward(ctx, mode, a, b_, c_, key_mask, bias, nh, drop_p, impl):
+        if mode == "self":
+            H = a.shape[-1] // 3
+            q, k, v = a[..., :H], a[..., H:2 * H], a[..., 2 * H:]
+        elif mode == "cross":
+            H = a.shape[-1]
+            q, k, v = a, b_[..., :H], b_[..., H:]
+        else:
+            H = a.shape[-1]
+            q, k, v = a, b_, c_
+        assert H == nh * HEAD_DIM
+        B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
+        o = torch.empty(B, Lq, H, dtype=q.dtype, device=q.device)
+        need_grad = any(ctx.needs_input_grad)
+        lse = torch.empty(B, nh, Lq, dtype=torch.float32, device=q.device) if need_grad else None
+        off = RT.next_offset(B * nh * Lq * Lk) if drop_p > 0 else 0
+        scale = 1.0 / math.sqrt(HEAD_DIM)
+        if key_mask is not None:
+            assert key_mask.dtype == torch.float32 and key_mask.shape == (B, Lk) and key_mask.is_contiguous()
+        if bias is not None:
+            assert bias.dtype == torch.float32 and bias.shape == (B, Lq, Lk) and bias.is_contiguous()
+        call("bevbert_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(key_mask), ptr(bias),
+             _strides(q, k, v, o), B, nh, Lq, Lk, HEAD_DIM, scale, dtype_code(q), impl, float(drop_p), RT.seed, off,
+             stream())
+        ctx.save_for_backward(a, b_, c_, key_mask, bias, o, lse)
+        ctx.cfg = (mode, nh, float(drop_p), RT.seed, off, impl, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        a, b_, c_, key_mask, bias, o, lse = ctx.saved_tensors
+        mode, nh, drop_p, seed, off, impl, scale = ctx.cfg
+        do = do.contiguous()
+        if mode == "self":
+            H = a.shape[-1] // 3
+            q, k, v = a[..., :H], a[..., H:2 * H], a[..., 2 * H:]
+            da = torch.empty_like(a)
+            dq, dk, dv = da[..., :H], da[..., H:2 * H], da[..., 2 * H:]
+            grads = (da, None, None)
+        elif mode == "cross":
+            H = a.shape[-1]
+            q, k, v = a, b_[..., :H], b_[..., H:]
+            dq, dkv = torch.empty_like(a), torch.empty_like(b_)
+            dk, dv = dkv[..., :H], dkv[..., H:]
+            grads = (dq, dkv, None)
+        else:
+            q, k, v = a, b_, c_
+            dq, dk, dv = torch.empty_like(a), torch.empty_like(b_), torch.empty_like(c_)
+            grads = (dq, dk, dv)
+        B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
+        delta = torch.empty(B, nh, Lq, dtype=torch.float32, device=q.device)
+        dbias = torch.zeros_like(bias) if (bias is not None and ctx.needs_input_grad[5]) else None
+        assert do.shape == o.shape
+        call("bevbert_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk),
+             ptr(dv), ptr(dbias), ptr(key_mask), ptr(bias), _strides(q, k, v, o), B, nh, Lq, Lk, HEAD_DIM, scale,
+             dtype_code(q), impl, drop_p, seed, off, stream())
+        return (None,) + grads + (None, dbias, None, None, None)
+
+
+def attention_self(qkv, key_mask, bias, nh, drop_p=0.0, training=False):
+    return _Attention.apply("self", qkv, None, None, key_mask, bias, nh, drop_p if training else 0.0, RT.attn_impl)
+
+
+def attention_cross(q, kv, key_mask, nh, drop_p=0.0, training=False):
+    return _Attention.apply("cross", q, kv, None, key_mask, None, nh, drop_p if training else 0.0, RT.attn_impl)
+
+
+def attention(q, k, v, key_mask=None, bias=None, nh=12, drop_p=0.0, training=False, impl=None):
+    return _Attention.apply("sep", q, k, v, key_mask, bias, nh, drop_p if training else 0.0,
+                            RT.attn_impl if impl is None else impl)
+
+
+# ----------------------------------------------------------------------------- K5 embeddings
+class _EmbedLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, word, pos, typ, gamma, beta, eps, type_index, word_c, pos_c, typ_c):
+        B, L = ids.shape
+        H = word_c.shape[1]
+        rows = B * L
+        y = torch.empty(B, L, H, dtype=word_c.dtype, device=ids.device)
+        need_grad = any(ctx.needs_input_grad)
+        z = torch.empty_like(y) if need_grad else None
+        mean = torch.empty(rows, dtype=torch.float32, device=ids.device) if need_grad else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=ids.device) if need_grad else None
+        ids = ids.contiguous()
+        call("bevbert_embed_sum_layernorm_fwd", ptr(ids), ptr(word_c), ptr(pos_c), ptr(typ_c[type_index]),
+             ptr(_f32(gamma)), ptr(_f32(beta)), ptr(y), ptr(z), ptr(mean), ptr(rstd), rows, L, H, float(eps),
+             dtype_code(y), 0.0, 0, 0, stream())
+        ctx.save_for_backward(ids, z, mean, rstd)
+        ctx.params = (word, pos, typ, gamma, beta, type_index)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, z, mean, rstd = ctx.saved_tensors
+        word, pos, typ, gamma, beta, type_index = ctx.params
+        B, L = ids.shape
+        H = z.shape[-1]
+        rows = B * L
+        dy = dy.contiguous()
+        dz = torch.empty_like(dy)
+        ws = RT.workspace(dy.device, 512 * 3 * H)
+        sg, sb = _sink(gamma), _sink(beta)
+        assert (sg is None) == (sb is None)
+        if sg is not None:
+            _mark_touched(gamma); _mark_touched(beta)
+            call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz), None,
+                 ptr(sg), ptr(sb), None, ptr(ws), rows, H, dtype_code(dy), 0.0, 0, 0, 1, stream())
+            rg = rb = None
+        else:
+            rg = torch.empty(H, dtype=torch.float32, device=dy.device)
+            rb = torch.empty(H, dtype=torch.float32, device=dy.device)
+            call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz), None,
+                 ptr(rg), ptr(rb), None, ptr(ws), rows, H, dtype_code(dy), 0.0, 0, 0, 0, stream())
+        dzf = dz.reshape(rows, H).float()
+        outs = []
+        for p, make in ((word, lambda t: t.index_add_(0, ids.reshape(-1), dzf)),
+                        (pos, lambda t: t[:L].add_(dzf.view(B, L, H).sum(0))),
+                        (typ, lambda t: t[type_index].add_(dzf.sum(0)))):
+            if not p.requires_grad:
+                outs.append(None)
+            elif _sink(p) is not None:
+                _mark_touched(p)
+                make(_sink(p))
+                outs.append(None)
+            else:
+                t = torch.zeros(p.shape, dtype=torch.float32, device=dy.device)
+                make(t)
+                outs.append(t.to(p.dtype))
+        return (None, outs[0], outs[1], outs[2], rg, rb, None, None, None, None, None)
+
+
+def embed_sum_layernorm(ids, word, pos, typ, gamma, beta, eps, type_index=0):
+    """BertEmbeddings (vilmodel.py:62-77): LN(word[ids] + pos[0..L) + type[type_index])."""
+    return _EmbedLN.apply(ids, word, pos, typ, gamma, beta, eps, type_index, _compute(word), _compute(pos),
+                          _compute(typ))
+
+
+# ----------------------------------------------------------------------------- K6 segment gather
+class SegmentCSR:
+    """Host-built CSR (and its transpose) describing out[r] = sum_e w[e] * src[idx[e]]."""
+
+    def __init__(self, rowptr, idx, w, n_src, device):
+        import numpy as np
+        rowptr = np.asarray(rowptr, dtype=np.int32)
+        idx = np.asarray(idx, dtype=np.int32)
+        w = np.asarray(w, dtype=np.float32)
+        self.n_out, self.n_src = len(rowptr) - 1, int(n_src)
+        # transpose: for each src row, the (out row, weight) pairs that read it
+        out_of_e = np.repeat(np.arange(self.n_out, dtype=np.int32), np.diff(rowptr))
+        order = np.argsort(idx, kind="stable")
+        t_rowptr = np.zeros(self.n_src + 1, dtype=np.int32)
+        np.add.at(t_rowptr, idx + 1, 1)
+        t_rowptr = np.cumsum(t_rowptr).astype(np.int32)
+        pack = np.concatenate([rowptr, idx, t_rowptr, out_of_e[order]]).astype(np.int32)
+        packw = np.concatenate([w, w[order]]).astype(np.float32)
+        di = torch.from_numpy(pack).to(device, non_blocking=True)
+        dw = torch.from_numpy(packw).to(device, non_blocking=True)
+        n0, n1, n2 = len(rowptr), len(idx), len(t_rowptr)
+        self.rowptr, self.idx = di[:n0], di[n0:n0 + n1]
+        self.t_rowptr, self.t_idx = di[n0 + n1:n0 + n1 + n2], di[n0 + n1 + n2:]
+        self.w, self.t_w = dw[:n1], dw[n1:]
+
+
+class _SegmentWsum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, csr):
+        assert src.is_contiguous() and src.dim() == 2 and src.shape[0] == csr.n_src
+        out = torch.empty(csr.n_out, src.shape[1], dtype=src.dtype, device=src.device)
+        call("bevbert_segment_wsum", ptr(src), ptr(csr.rowptr), ptr(csr.idx), ptr(csr.w), ptr(out), csr.n_out,
+             src.shape[1], dtype_code(src), stream())
+        ctx.csr = csr
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        csr = ctx.csr
+        dout = dout.contiguous()
+        dsrc = torch.empty(csr.n_src, dout.shape[1], dtype=dout.dtype, device=dout.device)
+        call("bevbert_segment_wsum", ptr(dout), ptr(csr.t_rowptr), ptr(csr.t_idx), ptr(csr.t_w), ptr(dsrc), csr.n_src,
+             dout.shape[1], dtype_code(dout), stream())
+        return dsrc, None
+
+
+def segment_wsum(src, csr):
+    return _SegmentWsum.apply(src, csr)
+
+
+# ----------------------------------------------------------------------------- K1 BEV splat (no gradient)
+def pixel_scale(hw, device, vfov=math.radians(90)):
+    """((u + .5 - c) / f) in fp32 exactly as bev_utils.py:91-137 builds it (f = hw / (2 tan(vfov/2)), c = hw/2)."""
+    f = torch.tensor(hw / (2.0 * math.tan(vfov / 2.0)), dtype=torch.float32)
+    c = torch.tensor(hw / 2.0, dtype=torch.float32)
+    return ((torch.arange(hw, dtype=torch.float32) + 0.5 - c) / f).to(device)
+
+
+@torch.no_grad()
+def bev_lift_bin(depths, T_c2w, T_w2c, S_w2c, pix, dim, res, depth_scale=10.0, y_clip=0.5):
+    B, V = depths.shape[0], depths.shape[1]
+    hw = depths.shape[-1]
+    P = V * hw * hw
+    dev = depths.device
+    cell = torch.empty(B, P, dtype=torch.int32, device=dev)
+    order = torch.zeros(B, P, dtype=torch.int32, device=dev)
+    cell_start = torch.empty(B, dim * dim + 1, dtype=torch.int32, device=dev)
+    f = lambda t: t.contiguous().float()
+    d, a, b_, c_ = f(depths), f(T_c2w), f(T_w2c), f(S_w2c)
+    call("bevbert_bev_lift_bin", ptr(d), ptr(a), ptr(b_), ptr(c_), ptr(pix), B, V, hw, float(depth_scale), dim,
+         float(res), float(y_clip), ptr(cell), ptr(order), ptr(cell_start), stream())
+    return cell, order, cell_start
+
+
+@torch.no_grad()
+def bev_bin_points(points, drop_mask, dim, res, y_clip=0.5):
+    B, P = points.shape[0], points.shape[1]
+    dev = points.device
+    cell = torch.empty(B, P, dtype=torch.int32, device=dev)
+    order = torch.zeros(B, P, dtype=torch.int32, device=dev)
+    cell_start = torch.empty(B, dim * dim + 1, dtype=torch.int32, device=dev)
+    pts = points.contiguous().float()
+    dm = drop_mask.contiguous().to(torch.uint8)
+    call("bevbert_bev_bin_points", ptr(pts), ptr(dm), B, P, dim, float(res), float(y_clip), ptr(cell), ptr(order),
+         ptr(cell_start), stream())
+    return cell, order, cell_start
+
+
+@torch.no_grad()
+def bev_splat_mean(feat, order, cell_start, K, out_dtype=None, sems=None, n_classes=40):
+    """feat (B,P,C) f32/bf16/f16 -> (B,K,C); sems: (B,P) uint8 ids or (B,P,S) float64 one-hot or None."""
+    B, P, C = feat.shape
+    feat = feat.contiguous()
+    out_dtype = out_dtype or (feat.dtype if feat.dtype != torch.float16 else torch.float32)
+    out = torch.empty(B, K, C, dtype=out_dtype, device=feat.device)
+    sem_ids = sem_dense = out_sem = out_mask = None
+    S = n_classes
+    if sems is not None:
+        if sems.dim() == 2:
+            sem_ids = sems.contiguous().to(torch.uint8)
+        else:
+            sem_dense = sems.contiguous().to(torch.float64)
+            S = sems.shape[-1]
+        out_sem = torch.empty(B, K, S, dtype=torch.uint8, device=feat.device)
+        out_mask = torch.empty(B, K, dtype=torch.uint8, device=feat.device)
+    call("bevbert_bev_splat_mean", ptr(feat), dtype_code(feat), ptr(order), ptr(cell_start), ptr(out),
+         dtype_code(out_dtype), B, P, K, C, ptr(sem_ids), ptr(sem_dense), S, ptr(out_sem), ptr(out_mask), stream())
+    return out, out_sem, out_mask
+
+
+def dropout_keep_mask(n, drop_p, seed, offset, device):
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    call("bevbert_dropout_keep_mask", ptr(out), n, float(drop_p), int(seed), int(offset), stream())
+    return out.bool()

@@ -1,0 +1,288 @@
+"""Host-side mirror of pretrain_src/model/pretrain_cmt.py: GlocalTextPathCMTPreTraining.
+
+Same constructor (``config`` with ``pretrain_tasks`` / ``sem_pred_token``), same ``forward(batch, task,
+compute_loss=True)`` contract (lift_splat pops the seven grid inputs from / adds the five BEV tensors to a COPY of
+the batch, exactly like the reference's defaultdict copy), same un-reduced loss vectors, same ``state_dict`` keys.
+
+lift_splat is two kernel launches for the whole batch (ops.bev_lift_bin + ops.bev_splat_mean) instead of a
+B-iteration Python loop with three D2H syncs per sample (bev_utils.py:390-423).
+"""
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .vilmodel import BertOnlyMLMHead, GlocalTextPathCMT, finalize, gen_seq_masks
+
+BEV_DIM = 21      # pretrain_cmt.py:16-17 (the config's bev_dim / bev_res override these defaults)
+BEV_RES = 0.5
+
+
+def bevpos_polar(dim, device):
+    """bev_utils.py:39-58: (dim*dim, 3) = (cos, sin, dist / (dim/2)) of the cell centres, y axis flipped."""
+    c = torch.linspace(0.5, dim - 0.5, dim, dtype=torch.float32)
+    ry, rx = torch.meshgrid(c, c, indexing="ij")
+    ry = -(ry - dim / 2)
+    rx = rx - dim / 2
+    dis = (ry ** 2 + rx ** 2) ** 0.5
+    cos, sin = rx / dis, ry / dis
+    cos[dis == 0] = 0
+    sin[dis == 0] = 0
+    return torch.stack([cos, sin, dis / (dim / 2)], -1).reshape(dim * dim, 3).to(device)
+
+
+class _Head(nn.Module):
+    """Linear - ReLU - LayerNorm - Linear (pretrain_cmt.py:34-71: RegionClassification / ClsPrediction / MulClsPrediction)."""
+
+    def __init__(self, hidden_size, out_dim, input_size=None):
+        super().__init__()
+        input_size = hidden_size if input_size is None else input_size
+        self.net = nn.Sequential(nn.Linear(input_size, hidden_size), nn.ReLU(), nn.LayerNorm(hidden_size, eps=1e-12),
+                                 nn.Linear(hidden_size, out_dim))
+
+    def forward(self, x):
+        l0, ln, l3 = self.net[0], self.net[2], self.net[3]
+        h = torch.relu(ops.linear(x, l0.weight, l0.bias))
+        h = ops.layernorm(h, ln.weight, ln.bias, 1e-12)
+        return ops.linear(h, l3.weight, l3.bias)
+
+
+class ClsPrediction(_Head):
+    def __init__(self, hidden_size, input_size=None):
+        super().__init__(hidden_size, 1, input_size)
+
+
+class MulClsPrediction(_Head):
+    def __init__(self, hidden_size, input_size=None):
+        super().__init__(hidden_size, 40, input_size)
+
+
+class RegionClassification(_Head):
+    def __init__(self, hidden_size, label_dim):
+        super().__init__(hidden_size, label_dim)
+
+
+def sap_fusion_indices(gmap_vpids, visited_host, cand_vpids, G, K):
+    """Host half of the SAP logit fusion (pretrain_cmt.py:339-356; fine-tune twin vilmodel.py:852-871).
+
+    Returns src (B,G) int64 into [local logits | bw | 0] and the (B,K) mask of local candidates that are visited
+    nodes.  cand_vpids[i] includes the leading None ([stop])."""
+    B = len(gmap_vpids)
+    src = np.full((B, G), K + 1, dtype=np.int64)        # K+1 -> the zero slot
+    vis_c = np.zeros((B, K), dtype=bool)
+    src[:, 0] = 0                                       # fused[:, 0] += local[:, 0]
+    for i in range(B):
+        visited = {vp for vp, m in zip(gmap_vpids[i], visited_host[i]) if m}
+        tmp = {}
+        for j, vp in enumerate(cand_vpids[i]):
+            if j > 0:
+                if vp in visited:
+                    vis_c[i, j] = True
+                else:
+                    tmp[vp] = j                         # later duplicates overwrite, as the dict does
+        for j, vp in enumerate(gmap_vpids[i]):
+            if j > 0 and vp not in visited:
+                src[i, j] = tmp.get(vp, K)              # K -> the accumulated backtrack logit
+    return src, vis_c
+
+
+def fuse_sap_logits(global_logits, local_logits, src, vis_c):
+    bw = torch.where(vis_c, local_logits, torch.zeros_like(local_logits)).sum(1, keepdim=True)
+    ext = torch.cat([local_logits, bw, torch.zeros_like(bw)], 1)
+    return global_logits + ext.gather(1, src)
+
+
+def _host_rows(batch, key):
+    """Host copy of a small per-sample tensor: '<key>_cpu' if the loader kept one, else a single D2H copy."""
+    t = batch.get(key + "_cpu")
+    if t is None:
+        t = batch[key]
+    return t.tolist() if torch.is_tensor(t) else t
+
+
+class GlocalTextPathCMTPreTraining(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.bert = GlocalTextPathCMT(config)
+        self.feat_dropout = config.feat_dropout
+        if "mlm" in config.pretrain_tasks:
+            self.mlm_head = BertOnlyMLMHead(config)
+        if "mrc" in config.pretrain_tasks:
+            self.obj_classifier = RegionClassification(config.hidden_size, config.obj_prob_size)
+        if "sap" in config.pretrain_tasks:
+            self.global_sap_head = ClsPrediction(config.hidden_size)
+            self.local_sap_head = ClsPrediction(config.hidden_size)
+            self.sap_fuse_linear = ClsPrediction(config.hidden_size, input_size=config.hidden_size * 2) \
+                if config.glocal_fuse else None
+        if "og" in config.pretrain_tasks:
+            self.og_head = ClsPrediction(config.hidden_size)
+        if "sem" in config.pretrain_tasks or "masksem" in config.pretrain_tasks:
+            self.local_sem_head = MulClsPrediction(config.hidden_size)
+            self.sem_pred_token = config.sem_pred_token
+        self.init_weights()
+        self.tie_weights()
+        self._proj = None
+
+    # -- initialisation / checkpoint ABI ---------------------------------------------------------
+    def init_weights(self):
+        """BERT init (transformers' _init_weights, initializer_range 0.02): Linear/Embedding N(0, 0.02), LN (1, 0)."""
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                m.weight.data.normal_(mean=0.0, std=0.02)
+                if isinstance(m, nn.Linear) and m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.LayerNorm):
+                m.weight.data.fill_(1.0)
+                m.bias.data.zero_()
+
+    def tie_weights(self):
+        if "mlm" in self.config.pretrain_tasks:     # pretrain_cmt.py:109-112
+            self.mlm_head.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
+
+    def finalize(self, device, compute_dtype=torch.float32):
+        """Place parameters in the flat arena on ``device`` (fp32 masters + optional bf16 compute copy)."""
+        return finalize(self, device, compute_dtype)
+
+    def set_dropout(self, p):
+        """utils/misc.py:19-25 set_dropout: the reference rewrites EVERY dropout probability (incl. feat_dropout)."""
+        self.feat_dropout = p
+        for m in self.modules():
+            for attr in ("drop_p", "dropout_p"):
+                if hasattr(m, attr):
+                    setattr(m, attr, p)
+
+    # -- lift + splat -------------------------------------------------------------------------------
+    def _projector(self, device):
+        if self._proj is None or self._proj[0].device != device:
+            cfg = self.config
+            self._proj = (ops.pixel_scale(cfg.grid_hw, device), bevpos_polar(cfg.bev_dim, device))
+        return self._proj
+
+    def lift_splat(self, batch):
+        cfg = self.config
+        rgbs, depths, sems = batch.pop("rgbs"), batch.pop("depths"), batch.pop("sems")
+        T_c2w, T_w2c, S_w2c = batch.pop("T_c2w"), batch.pop("T_w2c"), batch.pop("S_w2c")
+        bev_gpos_fts = batch.pop("bev_gpos_fts")
+        B = rgbs.shape[0]
+        dim, K = cfg.bev_dim, cfg.bev_dim * cfg.bev_dim
+        pix, polar = self._projector(rgbs.device)
+        cell, order, cell_start = ops.bev_lift_bin(depths, T_c2w, T_w2c, S_w2c, pix, dim, cfg.bev_res)
+        cd = ops._compute(self.bert.local_encoder.bev_fts_embeddings[0].weight).dtype
+        feat = rgbs.reshape(B, -1, rgbs.shape[-1])
+        sem_in = sems if sems.dim() == 2 else sems.reshape(B, feat.shape[1], -1)
+        bev_fts, bev_sems, bev_sem_masks = ops.bev_splat_mean(feat, order, cell_start, K, out_dtype=cd, sems=sem_in,
+                                                              n_classes=cfg.sem_classes)
+        bev_pos_fts = torch.cat([bev_gpos_fts.expand(-1, K, -1), polar[None].expand(B, -1, -1)], dim=-1)
+        batch.update({
+            "bev_fts": bev_fts,
+            "bev_masks": torch.ones(B, K, dtype=torch.bool, device=rgbs.device),   # pretrain_cmt.py:152
+            "bev_pos_fts": bev_pos_fts,
+            "bev_sems": bev_sems,
+            "bev_sem_masks": bev_sem_masks.bool(),
+            "_bev_masks_all_ones": True,
+            "_bev_cell": cell,
+        })
+        return batch
+
+    def drop_feats(self, batch):
+        for k in ("traj_view_img_fts", "traj_obj_img_fts", "bev_fts"):
+            if batch.get(k) is not None:
+                batch[k] = F.dropout(batch[k], self.feat_dropout, self.training)
+        return batch
+
+    # -- dispatcher ---------------------------------------------------------------------------------
+    _CMT_KEYS = ["txt_ids", "txt_lens", "traj_view_img_fts", "traj_obj_img_fts", "traj_loc_fts", "traj_nav_types",
+                 "traj_step_lens", "traj_vp_view_lens", "traj_vp_obj_lens", "traj_vpids", "traj_cand_vpids",
+                 "gmap_lens", "gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists", "gmap_vpids",
+                 "bev_fts", "bev_pos_fts", "bev_masks", "bev_nav_masks"]
+
+    def _cmt_args(self, b):
+        args = [b.get(k) for k in self._CMT_KEYS]
+        if b.get("_bev_masks_all_ones"):
+            args[18] = True          # lets the kernels skip an all-ones mask (see vilmodel._all_ones_to_none)
+        return args
+
+    def forward(self, batch, task, compute_loss=True):
+        if not any(task.startswith(t) for t in ("mlm", "mrc", "sap", "og", "sem", "masksem")):
+            raise ValueError("invalid task")
+        if task.startswith("mrc") or task.startswith("og"):
+            raise NotImplementedError("REVERIE object tasks (mrc / og) are SURVEY section 8 row f4: not built yet")
+        batch = dict(batch)     # the reference works on a defaultdict COPY (pretrain_cmt.py:170): the caller's dict is untouched
+        self.lift_splat(batch)
+        self.drop_feats(batch)
+        if task.startswith("mlm"):
+            return self.forward_mlm(batch, compute_loss)
+        if task.startswith("sap"):
+            return self.forward_sap(batch, compute_loss)
+        if task.startswith("masksem"):
+            return self.forward_masksem(batch, compute_loss)
+        return self.forward_sem(batch, compute_loss)
+
+    # -- tasks --------------------------------------------------------------------------------------
+    def forward_mlm(self, b, compute_loss):
+        txt_embeds = self.bert.forward_mlm(*self._cmt_args(b), view_lens_host=b.get("traj_vp_view_lens_cpu"))
+        labels = b["txt_labels"]
+        host = b.get("txt_labels_cpu")
+        if host is not None:        # host-known positions: no nonzero() sync (pretrain_cmt.py:254-256 has one)
+            pos = torch.nonzero(host.reshape(-1) != -1).squeeze(1).to(labels.device, non_blocking=True)
+        else:
+            pos = torch.nonzero(labels.reshape(-1) != -1).squeeze(1)
+        masked = txt_embeds.reshape(-1, txt_embeds.shape[-1]).index_select(0, pos)
+        scores = self.mlm_head(masked).float()
+        if compute_loss:
+            return F.cross_entropy(scores, labels.reshape(-1).index_select(0, pos), reduction="none")
+        return scores
+
+    def forward_sap(self, b, compute_loss):
+        cfg = self.config
+        gmap_embeds, bev_embeds, _, _ = self.bert(*self._cmt_args(b), view_lens_host=b.get("traj_vp_view_lens_cpu"))
+        if self.sap_fuse_linear is None:
+            fuse_weights = 0.5
+        else:
+            center = (cfg.bev_dim * cfg.bev_dim - 1) // 2
+            fuse_weights = torch.sigmoid(self.sap_fuse_linear(
+                torch.cat([gmap_embeds[:, 0], bev_embeds[:, center]], 1)).float())
+        G = gmap_embeds.shape[1]
+        global_logits = self.global_sap_head(gmap_embeds).squeeze(2).float() * fuse_weights
+        global_logits = global_logits.masked_fill(b["gmap_visited_masks"], -float("inf"))
+        global_logits = global_logits.masked_fill(gen_seq_masks(b["gmap_lens"], G).logical_not(), -float("inf"))
+
+        cand_idxs = b["bev_cand_idxs"]
+        bi = torch.arange(cand_idxs.shape[0], device=cand_idxs.device)[:, None]
+        cand_embeds = bev_embeds[bi, cand_idxs]
+        cand_masks = b["bev_nav_masks"][bi, cand_idxs]
+        local_logits = self.local_sap_head(cand_embeds).squeeze(2).float() * (1 - fuse_weights)
+        local_logits = local_logits.masked_fill(cand_masks.logical_not(), -float("inf"))
+
+        cand_vpids = [[None] + c[-1] for c in b["traj_cand_vpids"]]
+        src, vis_c = sap_fusion_indices(b["gmap_vpids"], _host_rows(b, "gmap_visited_masks"), cand_vpids, G,
+                                        cand_idxs.shape[1])
+        dev = global_logits.device
+        fused_logits = fuse_sap_logits(global_logits, local_logits, torch.from_numpy(src).to(dev, non_blocking=True),
+                                       torch.from_numpy(vis_c).to(dev, non_blocking=True))
+        if compute_loss:
+            return F.cross_entropy(global_logits, b["global_act_labels"], reduction="none") \
+                + F.cross_entropy(local_logits, b["local_act_labels"], reduction="none") \
+                + F.cross_entropy(fused_logits, b["global_act_labels"], reduction="none")
+        return global_logits, local_logits, fused_logits, b["global_act_labels"], b["local_act_labels"]
+
+    def _sem_common(self, b, sel, compute_loss):
+        bev_embeds = self.bert.forward_sem(*self._cmt_args(b), sem_pred_token=self.sem_pred_token)
+        masked = bev_embeds[sel]                               # data-dependent row count: one sync, as the reference
+        sem_logits = self.local_sem_head(masked).float()
+        sem_labels = b["bev_sems"][sel].float()
+        if compute_loss:
+            return F.binary_cross_entropy_with_logits(sem_logits, sem_labels, reduction="none")
+        return sem_logits, sem_labels
+
+    def forward_sem(self, b, compute_loss):
+        return self._sem_common(b, b["bev_sem_masks"], compute_loss)
+
+    def forward_masksem(self, b, compute_loss):
+        mrc = b["bev_mrc_masks"]
+        b["bev_fts"] = b["bev_fts"].detach().masked_fill(mrc.unsqueeze(-1), 0)        # pretrain_cmt.py:423-424
+        return self._sem_common(b, b["bev_sem_masks"] & mrc, compute_loss)

@@ -244,9 +244,17 @@ def make_batch(cfg, task, batch_size, seed=1000, txt_len=80, n_steps=5, ragged=F
     return collate(samples, cfg, task, rng, sems_as=sems_as)
 
 
+HOST_COPIES = ("gmap_visited_masks", "txt_labels", "traj_vp_view_lens")
+
+
 def batch_to(batch, device, non_blocking=True):
-    """move_to_cuda (pretrain_src/data/loader.py:78-120 PrefetchLoader): tensors move, lists stay."""
+    """move_to_cuda (pretrain_src/data/loader.py:78-120 PrefetchLoader): tensors move, lists stay.
+
+    The three small tensors the host-side index building needs (SAP fusion sets, MLM positions, gmap CSR) also keep
+    a '<key>_cpu' copy, so the forward never has to read them back from the device."""
     out = {}
     for k, v in batch.items():
         out[k] = v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v
+        if k in HOST_COPIES and torch.is_tensor(v):
+            out[k + "_cpu"] = v
     return out

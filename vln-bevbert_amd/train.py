@@ -1,0 +1,126 @@
+"""Synthetic-batch pre-training harness: the build's counterpart of the reference's hot loop
+(pretrain_src/train_r2r.py:247-313) -- task mix, loss.mean(), clip 5.0, warm-up-linear LR, AdamW -- plus the
+data-parallel gradient exchange that replaces DistributedDataParallel (pretrain_src/utils/misc.py:64-77).
+
+Data parallelism: one process per GPU, batches sharded by rank (seed + rank), weights replicated.
+The only data-path collective is the gradient SUM all-reduce; it runs IN PLACE on slices of the flat gradient
+arena (no bucket copies), on a side stream, in two phases so that it overlaps with the rest of backward:
+
+    phase A  [first map-encoder parameter, end of arena)   launched when d(loss)/d(text embeddings) is complete,
+             i.e. every kernel of the two map encoders and the heads has been enqueued (~57 % of the bytes);
+             it overlaps with the backward of the 9-layer text encoder and the panorama encoder;
+    phase B  [0, first map-encoder parameter)               launched when backward returns.
+
+The 1/world averaging is folded into the clip kernel (grad_pre_scale), and parameters unused by the step's task
+simply contribute zeros (the semantics of find_unused_parameters=True without the graph traversal).  The task of
+each step is drawn from a generator seeded identically on every rank, so the reference's per-step task-id broadcast
+(pretrain_src/data/loader.py:56-59) needs no collective at all.
+"""
+import random
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def warmup_linear_lr(step, base_lr, warmup_steps, total_steps):
+    """optim/sched.py:17-30."""
+    f = step / warmup_steps if step < warmup_steps else max(0, (total_steps - step) / (total_steps - warmup_steps))
+    lr = base_lr * f
+    return lr if lr > 0 else 1e-8
+
+
+class TaskSampler:
+    """MetaLoader's ratio sampling (data/loader.py:18-62) with a generator shared by all ranks."""
+
+    def __init__(self, task_ratio="mlm.5.sap.5.masksem.1", seed=0):
+        parts = task_ratio.split(".")
+        self.tasks = parts[::2]
+        ratios = [int(r) for r in parts[1::2]]
+        self.pool = [t for t, r in zip(self.tasks, ratios) for _ in range(r)]
+        self.rng = random.Random(seed)
+
+    def next(self):
+        return self.rng.choice(self.pool)
+
+
+class GradReducer:
+    """In-place SUM all-reduce of a flat gradient buffer in [split, end) then [0, split) (see module docstring)."""
+
+    def __init__(self, flat_grads, split, group=None):
+        self.flat = flat_grads
+        self.split = int(split)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.cuda = flat_grads.is_cuda
+        self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self._works = []
+        self._phase_a_done = False
+
+    def _launch(self, lo, hi):
+        if hi <= lo:
+            return
+        view = self.flat[lo:hi]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())     # everything enqueued so far has produced `view`
+            with torch.cuda.stream(self.stream):
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def phase_a(self, *_):
+        """Call when every gradient in [split, end) has been enqueued (tensor hook on the text embeddings)."""
+        if self.world > 1 and not self._phase_a_done:
+            self._phase_a_done = True
+            self._launch(self.split, self.flat.numel())
+
+    def finish(self):
+        """Call after backward: reduces what phase A did not cover and joins the side stream."""
+        if self.world > 1:
+            if not self._phase_a_done:
+                self._launch(0, self.flat.numel())
+            else:
+                self._launch(0, self.split)
+            for w in self._works:
+                w.wait()
+            if self.stream is not None:
+                torch.cuda.current_stream().wait_stream(self.stream)
+        self._works = []
+        self._phase_a_done = False
+
+
+class PretrainTrainer:
+    def __init__(self, model, arena, learning_rate=5e-5, warmup_steps=10000, num_train_steps=100000,
+                 betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0, seed=0, rank=0, world_size=1, overlap=True):
+        self.model, self.arena = model, arena
+        self.lr, self.warmup, self.total = learning_rate, warmup_steps, num_train_steps
+        self.betas, self.wd, self.grad_norm = betas, weight_decay, grad_norm
+        self.seed, self.rank, self.world = seed, rank, world_size
+        self.global_step = 0
+        first_map = min(arena.slices[n][0] for n in arena.slices
+                        if n.startswith("bert.local_encoder") or n.startswith("bert.global_encoder")
+                        or not n.startswith("bert."))
+        # the arena keeps registration order: embeddings, lang_encoder, img_embeddings come before the map encoders
+        self.reducer = GradReducer(arena.grads, first_map)
+        self.overlap = overlap and world_size > 1
+        if self.overlap:
+            model.bert.lang_encoder.register_forward_hook(self._hook_text)
+
+    def _hook_text(self, module, inputs, output):
+        if output.requires_grad and torch.is_grad_enabled():
+            output.register_hook(lambda g: (self.reducer.phase_a(), g)[1])
+        return output
+
+    def step(self, task, batch):
+        """One optimisation step on one batch (gradient_accumulation_steps == 1, as every shipped config)."""
+        self.global_step += 1
+        ops.RT.new_step((self.seed + self.rank) * 1000003 + self.global_step)    # per-rank dropout stream
+        self.arena.zero_grad()
+        loss_vec = self.model(batch, task, compute_loss=True)
+        loss = loss_vec.mean()                                                   # train_r2r.py:263
+        loss.backward()
+        self.reducer.finish()
+        lr = warmup_linear_lr(self.global_step, self.lr, self.warmup, self.total)
+        self.arena.clip_and_step(lr, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
+        return loss.detach()

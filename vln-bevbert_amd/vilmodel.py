@@ -1,0 +1,641 @@
+"""Host-side mirror of the reference's cross-modal transformer (pretrain_src/model/vilmodel.py).
+
+Class names, constructor arguments, forward signatures and -- exactly -- the ``state_dict`` keys follow the
+reference, so its checkpoints load and its callers (pretrain_src/train_r2r.py, map_nav_src/r2r/agent.py) drop in.
+The bodies do not: ``nn.Linear`` / ``nn.LayerNorm`` / ``nn.Embedding`` are used only as parameter holders, and every
+forward is a short chain of fused HIP kernels (ops.py) and library GEMMs:
+
+    BertAttention        = packed-QKV GEMM -> fused attention kernel -> GEMM -> fused bias+dropout+residual+LN
+    BertIntermediate/Out = GEMM -> fused bias+GELU -> GEMM -> fused bias+dropout+residual+LN
+    (N,12,Lq,Lk) scores, transpose_for_scores copies, (N,1,1,L) mask broadcasts: never materialised.
+
+Host/device syncs of the reference forward (4608 item() + 192 nonzero at B=64) are gone: sequence
+masks come from host-known shapes, the gmap aggregation is one CSR gather, the SAP fusion is one index gather.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .arena import ParamArena
+
+LN_EPS = 1e-12
+
+
+def gen_seq_masks(seq_lens, max_len):
+    """ops.py:36-44 with a host-known max_len (the reference calls max() on a device tensor -> sync)."""
+    return torch.arange(max_len, device=seq_lens.device)[None, :] < seq_lens[:, None]
+
+
+def neg_key_mask(masks, value=-10000.0):
+    """ops.py:25-34 extend_neg_masks, kept as (N, L) fp32 -- the kernels broadcast over heads and queries."""
+    if masks is None:
+        return None
+    return ((1.0 - masks.to(torch.float32)) * value).contiguous()
+
+
+class _Finalizable(nn.Module):
+    """Modules that cache packed arena views implement _after_arena(arena, prefix)."""
+
+    def _after_arena(self, arena, prefix):
+        pass
+
+
+class BertEmbeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout_p = config.hidden_dropout_prob
+        self.eps = config.layer_norm_eps
+
+    def forward(self, input_ids, token_type_ids=None, position_ids=None):
+        y = ops.embed_sum_layernorm(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
+                                    self.token_type_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias,
+                                    self.eps, 0)
+        return F.dropout(y, self.dropout_p, self.training)
+
+
+class BertSelfAttention(_Finalizable):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (config.hidden_size, config.num_attention_heads))
+        self.num_attention_heads = config.num_attention_heads
+        H = config.hidden_size
+        self.query, self.key, self.value = nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, H)
+        self.drop_p = config.attention_probs_dropout_prob
+
+    def _after_arena(self, arena, prefix):
+        H = self.query.weight.shape[0]
+        wn = [f"{prefix}{k}.weight" for k in ("query", "key", "value")]
+        bn = [f"{prefix}{k}.bias" for k in ("query", "key", "value")]
+        wc, wg = arena.packed(wn, (3 * H, H))
+        bc, bg = arena.packed(bn, (3 * H,))
+        self.pw = ops._PackedParam([self.query.weight, self.key.weight, self.value.weight], wc, wg)
+        self.pb = ops._PackedParam([self.query.bias, self.key.bias, self.value.bias], bc, bg)
+
+    @staticmethod
+    def arena_groups(prefix):
+        return [[f"{prefix}{k}.weight" for k in ("query", "key", "value")],
+                [f"{prefix}{k}.bias" for k in ("query", "key", "value")]]
+
+    def forward(self, hidden_states, key_mask, bias=None):
+        qkv = ops.linear_packed(hidden_states, self.pw, self.pb)
+        return ops.attention_self(qkv, key_mask, bias, self.num_attention_heads, self.drop_p, self.training)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.drop_p = config.hidden_dropout_prob
+        self.eps = config.layer_norm_eps
+
+    def forward(self, hidden_states, input_tensor):
+        h = ops.linear(hidden_states, self.dense.weight)            # bias folded into the fused kernel below
+        return ops.bias_dropout_residual_layernorm(h, self.dense.bias, input_tensor, self.LayerNorm.weight,
+                                                   self.LayerNorm.bias, self.eps, self.drop_p, self.training)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+    def forward(self, input_tensor, key_mask, bias=None):
+        return self.output(self.self(input_tensor, key_mask, bias), input_tensor)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+        assert config.hidden_act == "gelu", "the path is specialised for erf-GELU (configs/*_model.json)"
+
+    def forward(self, hidden_states):
+        return ops.bias_gelu(ops.linear(hidden_states, self.dense.weight), self.dense.bias)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.drop_p = config.hidden_dropout_prob
+        self.eps = config.layer_norm_eps
+
+    def forward(self, hidden_states, input_tensor):
+        h = ops.linear(hidden_states, self.dense.weight)
+        return ops.bias_dropout_residual_layernorm(h, self.dense.bias, input_tensor, self.LayerNorm.weight,
+                                                   self.LayerNorm.bias, self.eps, self.drop_p, self.training)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.attention = BertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def forward(self, hidden_states, key_mask):
+        a = self.attention(hidden_states, key_mask)
+        return self.output(self.intermediate(a), a)
+
+
+class BertPredictionHeadTransform(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.eps = config.layer_norm_eps
+
+    def forward(self, hidden_states):
+        h = ops.bias_gelu(ops.linear(hidden_states, self.dense.weight), self.dense.bias)
+        return ops.layernorm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.eps)
+
+
+class BertLMPredictionHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+
+    def forward(self, hidden_states):
+        h = self.transform(hidden_states)
+        return ops.linear(h, self.decoder.weight, self.bias)
+
+
+class BertOnlyMLMHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+
+    def forward(self, sequence_output):
+        return self.predictions(sequence_output)
+
+
+class BertOutAttention(_Finalizable):
+    def __init__(self, config, ctx_dim=None):
+        super().__init__()
+        self.num_attention_heads = config.num_attention_heads
+        H = config.hidden_size
+        ctx_dim = H if ctx_dim is None else ctx_dim
+        self.query = nn.Linear(H, H)
+        self.key = nn.Linear(ctx_dim, H)
+        self.value = nn.Linear(ctx_dim, H)
+        self.drop_p = config.attention_probs_dropout_prob
+
+    def _after_arena(self, arena, prefix):
+        H, C = self.key.weight.shape
+        wc, wg = arena.packed([f"{prefix}key.weight", f"{prefix}value.weight"], (2 * H, C))
+        bc, bg = arena.packed([f"{prefix}key.bias", f"{prefix}value.bias"], (2 * H,))
+        self.pw = ops._PackedParam([self.key.weight, self.value.weight], wc, wg)
+        self.pb = ops._PackedParam([self.key.bias, self.value.bias], bc, bg)
+
+    @staticmethod
+    def arena_groups(prefix):
+        return [[f"{prefix}key.weight", f"{prefix}value.weight"], [f"{prefix}key.bias", f"{prefix}value.bias"]]
+
+    def forward(self, hidden_states, context, key_mask=None):
+        q = ops.linear(hidden_states, self.query.weight, self.query.bias)
+        kv = ops.linear_packed(context, self.pw, self.pb)
+        return ops.attention_cross(q, kv, key_mask, self.num_attention_heads, self.drop_p, self.training)
+
+
+class BertXAttention(nn.Module):
+    def __init__(self, config, ctx_dim=None):
+        super().__init__()
+        self.att = BertOutAttention(config, ctx_dim=ctx_dim)
+        self.output = BertSelfOutput(config)
+
+    def forward(self, input_tensor, ctx_tensor, ctx_key_mask=None):
+        return self.output(self.att(input_tensor, ctx_tensor, ctx_key_mask), input_tensor)
+
+
+class GraphLXRTXLayer(nn.Module):
+    """vilmodel.py:365-421; masks are (N, L) additive fp32 (or None), graph_sprels is (N, G, G) additive fp32."""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.use_lang2visn_attn:
+            self.lang_self_att = BertAttention(config)
+            self.lang_inter = BertIntermediate(config)
+            self.lang_output = BertOutput(config)
+        self.visn_self_att = BertAttention(config)
+        self.visn_inter = BertIntermediate(config)
+        self.visn_output = BertOutput(config)
+        self.visual_attention = BertXAttention(config)
+
+    def forward(self, lang_feats, lang_key_mask, visn_feats, visn_key_mask, graph_sprels=None):
+        a = self.visual_attention(visn_feats, lang_feats, lang_key_mask)
+        a = self.visn_self_att(a, visn_key_mask, graph_sprels)
+        return self.visn_output(self.visn_inter(a), a)
+
+    def forward_lang2visn(self, lang_feats, lang_key_mask, visn_feats, visn_key_mask):
+        a = self.visual_attention(lang_feats, visn_feats, visn_key_mask)
+        a = self.lang_self_att(a, lang_key_mask)
+        return self.lang_output(self.lang_inter(a), a)
+
+    def forward_visn2visn(self, visn_feats, visn_key_mask):
+        a = self.visn_self_att(visn_feats, visn_key_mask)
+        return self.visn_output(self.visn_inter(a), a)
+
+
+class LanguageEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.num_l_layers = config.num_l_layers
+        self.update_lang_bert = config.update_lang_bert
+        self.layer = nn.ModuleList([BertLayer(config) for _ in range(self.num_l_layers)])
+        if not self.update_lang_bert:
+            for p in self.layer.parameters():
+                p.requires_grad = False
+
+    def forward(self, txt_embeds, txt_masks):
+        km = neg_key_mask(txt_masks)
+        for layer in self.layer:
+            txt_embeds = layer(txt_embeds, km)
+        if not self.update_lang_bert:
+            txt_embeds = txt_embeds.detach()
+        return txt_embeds
+
+
+class CrossmodalEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.num_x_layers = config.num_x_layers
+        self.x_layers = nn.ModuleList([GraphLXRTXLayer(config) for _ in range(self.num_x_layers)])
+
+    def forward(self, txt_embeds, txt_masks, img_embeds, img_masks, graph_sprels=None):
+        tm, im = neg_key_mask(txt_masks), neg_key_mask(img_masks)
+        for layer in self.x_layers:
+            img_embeds = layer(txt_embeds, tm, img_embeds, im, graph_sprels=graph_sprels)
+        return img_embeds
+
+
+# ----------------------------------------------------------------------------- panorama encoder
+class _MHAParams(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's names (in_proj_weight, in_proj_bias, out_proj.*)."""
+
+    def __init__(self, d_model):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = nn.Linear(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+class TransformerEncoderLayer(nn.Module):
+    """transformer.py:133-182 with normalize_before=True (the only mode create_transformer_encoder uses)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = _MHAParams(d_model)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)      # eps 1e-5 (nn.LayerNorm default), transformer.py:144-145
+        self.norm2 = nn.LayerNorm(d_model)
+        self.nhead, self.drop_p = nhead, dropout
+
+    def forward(self, src, key_mask):
+        tr, p = self.training, self.drop_p
+        h = ops.layernorm(src, self.norm1.weight, self.norm1.bias, 1e-5)
+        qkv = ops.linear(h, self.self_attn.in_proj_weight, self.self_attn.in_proj_bias)
+        a = ops.attention_self(qkv, key_mask, None, self.nhead, p, tr)
+        o = ops.linear(a, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias)
+        src = src + F.dropout(o, p, tr)
+        h = ops.layernorm(src, self.norm2.weight, self.norm2.bias, 1e-5)
+        f = ops.bias_gelu(ops.linear(h, self.linear1.weight), self.linear1.bias)
+        f = ops.linear(F.dropout(f, p, tr), self.linear2.weight, self.linear2.bias)
+        return src + F.dropout(f, p, tr)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, config, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            TransformerEncoderLayer(config.hidden_size, config.num_attention_heads, config.intermediate_size,
+                                    config.hidden_dropout_prob) for _ in range(num_layers)])
+        self.norm = nn.LayerNorm(config.hidden_size, eps=1e-12)      # ops.py:19-20
+
+    def forward(self, src, src_key_padding_mask):
+        km = None
+        if src_key_padding_mask is not None:      # boolean key_padding_mask -> -inf on padded keys (vilmodel.py:530-532)
+            km = torch.zeros(src_key_padding_mask.shape, dtype=torch.float32, device=src.device)
+            km = km.masked_fill(src_key_padding_mask, float("-inf")).contiguous()
+        for layer in self.layers:
+            src = layer(src, km)
+        return ops.layernorm(src, self.norm.weight, self.norm.bias, 1e-12)
+
+
+def _small_k_linear(x, lin, out_dtype):
+    """Feature projections with K in {7, 10, 14}: run on the fp32 masters (K is not MFMA-tileable), emit the
+    compute dtype.  The bias is NOT added here (the following fused LayerNorm kernel adds it)."""
+    y = ops.linear(x.to(torch.float32), lin.weight, None, w_c=lin.weight)
+    return y.to(out_dtype)
+
+
+class ImageEmbeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        H = config.hidden_size
+        self.img_linear = nn.Linear(config.image_feat_size, H)
+        self.img_layer_norm = nn.LayerNorm(H, eps=1e-12)
+        self.loc_linear = nn.Linear(config.angle_feat_size + 3, H)
+        self.loc_layer_norm = nn.LayerNorm(H, eps=1e-12)
+        if config.obj_feat_size > 0 and config.obj_feat_size != config.image_feat_size:
+            self.obj_linear = nn.Linear(config.obj_feat_size, H)
+            self.obj_layer_norm = nn.LayerNorm(H, eps=1e-12)
+        else:
+            self.obj_linear = self.obj_layer_norm = None
+        self.nav_type_embedding = nn.Embedding(3, H)
+        self.layer_norm = nn.LayerNorm(H, eps=1e-12)
+        self.drop_p = config.hidden_dropout_prob
+        self.pano_encoder = TransformerEncoder(config, config.num_pano_layers) if config.num_pano_layers > 0 else None
+
+    def embed(self, view_img_fts, loc_fts, nav_types, view_lens, type_embed_layer):
+        """Shared by forward (pre-training) and forward_panorama_per_step (fine-tuning)."""
+        cd = ops._compute(self.img_linear.weight).dtype
+        x = ops.linear(view_img_fts.to(cd), self.img_linear.weight)
+        e = ops.bias_dropout_residual_layernorm(x, self.img_linear.bias, None, self.img_layer_norm.weight,
+                                                self.img_layer_norm.bias, 1e-12)
+        loc = _small_k_linear(loc_fts, self.loc_linear, cd)
+        e = e + ops.bias_dropout_residual_layernorm(loc, self.loc_linear.bias, None, self.loc_layer_norm.weight,
+                                                    self.loc_layer_norm.bias, 1e-12)
+        e = e + embedding_lookup(self.nav_type_embedding, nav_types) \
+            + embedding_lookup(type_embed_layer, torch.ones(1, 1, dtype=torch.long, device=e.device))
+        e = ops.layernorm(e, self.layer_norm.weight, self.layer_norm.bias, 1e-12)
+        e = F.dropout(e, self.drop_p, self.training)
+        masks = gen_seq_masks(view_lens, view_img_fts.shape[1])
+        if self.pano_encoder is not None:
+            e = self.pano_encoder(e, masks.logical_not())
+        return e, masks
+
+    def forward(self, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types, traj_step_lens,
+                traj_vp_view_lens, traj_vp_obj_lens, type_embed_layer):
+        if traj_obj_img_fts is not None:
+            raise NotImplementedError("object tokens (REVERIE / SOON configs) are SURVEY section 8 row f4: not built yet")
+        e, _ = self.embed(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, type_embed_layer)
+        return torch.split(e, traj_step_lens, 0), torch.split(traj_vp_view_lens, traj_step_lens, 0)
+
+
+class _GatherRows(torch.autograd.Function):
+    """table[idx] on the compute copy; the gradient is index_add'ed into the master's fp32 gradient arena."""
+
+    @staticmethod
+    def forward(ctx, idx, table, table_c):
+        ctx.save_for_backward(idx)
+        ctx.table = table
+        return table_c[idx]
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        table = ctx.table
+        if not table.requires_grad:
+            return None, None, None
+        sink = ops._sink(table)
+        d = dy.reshape(-1, dy.shape[-1]).float()
+        if sink is not None:
+            ops._mark_touched(table)
+            sink.index_add_(0, idx.reshape(-1), d)
+            return None, None, None
+        g = torch.zeros(table.shape, dtype=torch.float32, device=dy.device)
+        g.index_add_(0, idx.reshape(-1), d)
+        return None, g.to(table.dtype), None
+
+
+def embedding_lookup(emb: nn.Embedding, idx):
+    return _GatherRows.apply(idx, emb.weight, ops._compute(emb.weight))
+
+
+class LocalBEVEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.bev_dim = config.bev_dim
+        H = config.hidden_size
+        self.bev_fts_embeddings = nn.Sequential(nn.Linear(768, H), nn.LayerNorm(H, eps=1e-12))
+        self.bev_pos_embeddings = nn.Sequential(nn.Linear(3 + 7, H), nn.LayerNorm(H, eps=1e-12))
+        self.nav_type_embedding = nn.Embedding(2, H)
+        self.encoder = CrossmodalEncoder(config)
+
+    def bev_input_embedding(self, bev_fts, bev_pos_fts, bev_nav_masks):
+        lin, ln = self.bev_fts_embeddings[0], self.bev_fts_embeddings[1]
+        cd = ops._compute(lin.weight).dtype
+        x = ops.linear(bev_fts.to(cd), lin.weight)
+        e = ops.bias_dropout_residual_layernorm(x, lin.bias, None, ln.weight, ln.bias, 1e-12)
+        lin, ln = self.bev_pos_embeddings[0], self.bev_pos_embeddings[1]
+        pos = _small_k_linear(bev_pos_fts, lin, cd)
+        e = e + ops.bias_dropout_residual_layernorm(pos, lin.bias, None, ln.weight, ln.bias, 1e-12)
+        return e + embedding_lookup(self.nav_type_embedding, bev_nav_masks.long())
+
+    def forward(self, txt_embeds, txt_masks, bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, obj_embeds, obj_masks):
+        if obj_embeds is not None:
+            raise NotImplementedError("object tokens are SURVEY section 8 row f4: not built yet")
+        bev_embeds = self.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
+        bev_embeds = self.encoder(txt_embeds, txt_masks, bev_embeds, bev_masks)
+        return bev_embeds, None
+
+
+def build_gmap_csr(traj_step_lens, view_lens_host, traj_vpids, traj_cand_vpids, gmap_vpids, n_views, device):
+    """vilmodel.py:632-666 (_aggregate_gmap_features) as a CSR over the flattened (sum_T * V) token rows.
+
+    Output row b*G + j (G = batch max incl. [stop]); [stop] and padding rows are empty segments (-> zeros)."""
+    B = len(traj_step_lens)
+    G = max(len(g) for g in gmap_vpids)
+    rowptr, idx, w = [0], [], []
+    t0 = 0
+    for i in range(B):
+        T = traj_step_lens[i]
+        visited, unvisited = {}, {}
+        for t in range(T):
+            visited[traj_vpids[i][t]] = t
+            for j, vp in enumerate(traj_cand_vpids[i][t]):
+                if vp not in visited:
+                    unvisited.setdefault(vp, []).append((t, j))
+        for j in range(G):
+            if 0 < j < len(gmap_vpids[i]):
+                vp = gmap_vpids[i][j]
+                if vp in visited:
+                    t = visited[vp]
+                    n = int(view_lens_host[t0 + t])
+                    base = (t0 + t) * n_views
+                    idx.extend(range(base, base + n))
+                    w.extend([1.0 / n] * n)
+                else:
+                    toks = unvisited[vp]
+                    idx.extend((t0 + t) * n_views + jj for t, jj in toks)
+                    w.extend([1.0 / len(toks)] * len(toks))
+            rowptr.append(len(idx))
+        t0 += T
+    return ops.SegmentCSR(rowptr, idx, w, t0 * n_views, device), G
+
+
+class GlobalMapEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        H = config.hidden_size
+        self.gmap_pos_embeddings = nn.Sequential(nn.Linear(config.angle_feat_size + 3, H), nn.LayerNorm(H, eps=1e-12))
+        self.gmap_step_embeddings = nn.Embedding(config.max_action_steps, H)
+        self.encoder = CrossmodalEncoder(config)
+        self.sprel_linear = nn.Linear(1, 1) if config.graph_sprels else None
+
+    def pos_step_embedding(self, gmap_img_fts, gmap_step_ids, gmap_pos_fts):
+        lin, ln = self.gmap_pos_embeddings[0], self.gmap_pos_embeddings[1]
+        pos = _small_k_linear(gmap_pos_fts, lin, gmap_img_fts.dtype)
+        pos = ops.bias_dropout_residual_layernorm(pos, lin.bias, None, ln.weight, ln.bias, 1e-12)
+        return gmap_img_fts + embedding_lookup(self.gmap_step_embeddings, gmap_step_ids) + pos
+
+    def gmap_input_embedding(self, traj_embeds_flat, csr, G, gmap_step_ids, gmap_pos_fts, gmap_lens):
+        B = gmap_step_ids.shape[0]
+        img = ops.segment_wsum(traj_embeds_flat, csr).view(B, G, -1)
+        return self.pos_step_embedding(img, gmap_step_ids, gmap_pos_fts), gen_seq_masks(gmap_lens, G)
+
+    def sprels(self, gmap_pair_dists):
+        if self.sprel_linear is None:
+            return None
+        w, b = ops.use_param(self.sprel_linear.weight).view(()), ops.use_param(self.sprel_linear.bias).view(())
+        return (gmap_pair_dists.float() * w + b).contiguous()          # (B, G, G) fp32 additive bias
+
+    def forward(self, txt_embeds, txt_masks, gmap_embeds, gmap_masks, gmap_pair_dists):
+        return self.encoder(txt_embeds, txt_masks, gmap_embeds, gmap_masks, graph_sprels=self.sprels(gmap_pair_dists))
+
+
+def _host_list(x):
+    return x.tolist() if torch.is_tensor(x) else list(x)
+
+
+class GlocalTextPathCMT(nn.Module):
+    """vilmodel.py:703-883.  Same 20-argument positional signature for forward / forward_mlm / forward_sem."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.bev_dim = config.bev_dim
+        self.embeddings = BertEmbeddings(config)
+        self.lang_encoder = LanguageEncoder(config)
+        self.img_embeddings = ImageEmbeddings(config)
+        self.local_encoder = LocalBEVEncoder(config)
+        self.global_encoder = GlobalMapEncoder(config)
+
+    # -- shared stages -------------------------------------------------------------------------
+    def _text(self, txt_ids, txt_lens):
+        txt_masks = gen_seq_masks(txt_lens, txt_ids.shape[1])
+        return self.lang_encoder(self.embeddings(txt_ids), txt_masks), txt_masks
+
+    def _traj(self, traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens):
+        e, masks = self.img_embeddings.embed(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens,
+                                             self.embeddings.token_type_embeddings)
+        return e
+
+    def _gmap_inputs(self, traj_embeds, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids, gmap_vpids,
+                     gmap_step_ids, gmap_pos_fts, gmap_lens, view_lens_host=None):
+        if view_lens_host is None:
+            view_lens_host = _host_list(traj_vp_view_lens)            # one small D2H copy when no host copy is given
+        V = traj_embeds.shape[1]
+        csr, G = build_gmap_csr(traj_step_lens, view_lens_host, traj_vpids, traj_cand_vpids, gmap_vpids, V,
+                                traj_embeds.device)
+        assert G == gmap_step_ids.shape[1]
+        flat = traj_embeds.reshape(-1, traj_embeds.shape[-1])
+        return self.global_encoder.gmap_input_embedding(flat, csr, G, gmap_step_ids, gmap_pos_fts, gmap_lens)
+
+    # -- reference entry points ----------------------------------------------------------------
+    def forward(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
+                traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
+                gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
+                bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, return_gmap_embeds=True, view_lens_host=None):
+        if traj_obj_img_fts is not None:
+            raise NotImplementedError("object tokens are SURVEY section 8 row f4: not built yet")
+        txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
+        gmap_embeds = None
+        if return_gmap_embeds:
+            traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens)
+            g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
+                                              gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, view_lens_host)
+            gmap_embeds = self.global_encoder(txt_embeds, txt_masks, g_in, g_masks, gmap_pair_dists)
+        bev_embeds, obj_embeds = self.local_encoder(txt_embeds, txt_masks, bev_fts, bev_pos_fts,
+                                                    _all_ones_to_none(bev_masks), bev_nav_masks, None, None)
+        return gmap_embeds, bev_embeds, obj_embeds, None
+
+    def forward_mlm(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
+                    traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
+                    gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
+                    bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, view_lens_host=None):
+        if traj_obj_img_fts is not None:
+            raise NotImplementedError("object tokens are SURVEY section 8 row f4: not built yet")
+        txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
+        tm = neg_key_mask(txt_masks)
+        traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens)
+        g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
+                                          gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, view_lens_host)
+        gm = neg_key_mask(g_masks)
+        g_txt = txt_embeds
+        for layer in self.global_encoder.encoder.x_layers:
+            g_txt = layer.forward_lang2visn(g_txt, tm, g_in, gm)
+        bev_in = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
+        bm = neg_key_mask(_all_ones_to_none(bev_masks))
+        b_txt = txt_embeds
+        for layer in self.local_encoder.encoder.x_layers:
+            b_txt = layer.forward_lang2visn(b_txt, tm, bev_in, bm)
+        return g_txt + b_txt
+
+    def forward_sem(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
+                    traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
+                    gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
+                    bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, sem_pred_token=None):
+        bm = _all_ones_to_none(bev_masks)
+        if sem_pred_token == "cattn":
+            txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
+            # the reference also runs img_embeddings here (vilmodel.py:847-851) but nothing consumes the result
+            bev_embeds, _ = self.local_encoder(txt_embeds, txt_masks, bev_fts, bev_pos_fts, bm, bev_nav_masks, None, None)
+        elif sem_pred_token == "sattn":
+            bev_embeds = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
+            km = neg_key_mask(bm)
+            for layer in self.local_encoder.encoder.x_layers:
+                bev_embeds = layer.forward_visn2visn(bev_embeds, km)
+        elif sem_pred_token == "embed":
+            bev_embeds = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
+        else:
+            raise NotImplementedError
+        return bev_embeds
+
+
+def _all_ones_to_none(mask):
+    """bev_masks is forced to all-ones upstream (pretrain_cmt.py:152, agent.py:187); a Python ``True`` marker
+    (set by our lift_splat) lets the kernels skip the mask entirely.  A real tensor mask is honoured as is."""
+    if mask is None or mask is True:
+        return None
+    return mask
+
+
+# ----------------------------------------------------------------------------- arena wiring
+def arena_groups(module):
+    groups = []
+    for name, m in module.named_modules():
+        if isinstance(m, (BertSelfAttention, BertOutAttention)):
+            groups.extend(m.arena_groups(name + "." if name else ""))
+    return groups
+
+
+def finalize(module, device, compute_dtype=torch.float32):
+    """Move a freshly built / loaded model into a ParamArena on ``device`` and cache the packed views."""
+    if compute_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be float32 or bfloat16")
+    for b in module.buffers():
+        b.data = b.data.to(device)
+    arena = ParamArena(module, device, compute_dtype, groups=arena_groups(module))
+    for name, m in module.named_modules():
+        if isinstance(m, _Finalizable):
+            m._after_arena(arena, name + "." if name else "")
+    module.arena = arena
+    return arena
