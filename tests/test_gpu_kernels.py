@@ -149,7 +149,7 @@ def test_layernorm_fwd_bwd(ops, dtype, with_res, p):
     bias_r, gam_r, bet_r = (t.detach().clone().requires_grad_(True) for t in (bias, gam, bet))
     yr, _ = _ln_ref(xr, bias_r, rr, gam_r, bet_r, 1e-12, keep, p)
     tol = 1e-4 if dtype == torch.float32 else 2e-2
-    assert float((y.float() - yr).abs().max()) < tol
+    assert float((y.float() - yr).detach().abs().max()) < tol
     dy = torch.randn(rows, H, device=DEV)
     y.backward(dy.to(dtype))
     yr.backward(dy.to(dtype).float())
@@ -188,7 +188,7 @@ def test_bias_gelu_fwd_bwd(ops, dtype):
     xr = x.detach().float().requires_grad_(True)
     br = bias.detach().clone().requires_grad_(True)
     yr = R.gelu_erf(xr + br)
-    assert float((y.float() - yr).abs().max()) < (1e-5 if dtype == torch.float32 else 3e-2)
+    assert float(((y.float() - yr).abs() / (1 + yr.abs())).max()) < (1e-5 if dtype == torch.float32 else 8e-3)
     dy = torch.randn(rows, C, device=DEV).to(dtype)
     y.backward(dy)
     yr.backward(dy.float())
