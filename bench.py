@@ -31,6 +31,28 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
 
+T_START = time.perf_counter()
+
+
+def log(msg):
+    """progress to stderr (stdout carries only the JSON line)"""
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """cores this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
+    whole host and oversubscribes a container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +119,7 @@ def main():
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
     from vln_bevbert_amd.train import PretrainTrainer, TaskSampler
 
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)}; building model")
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     esize = 2 if a.dtype == "bf16" else 4
     cfg = BevBertConfig()                                   # configs/r2r_model.json
@@ -108,6 +131,7 @@ def main():
     trainer = PretrainTrainer(model, arena, rank=rank, world_size=world)
     sampler = TaskSampler("mlm.5.sap.5.masksem.1", seed=0)
 
+    log(f"model in arena: {arena.n_params / 1e6:.1f} M params; generating resident batches")
     # resident synthetic batches: two per task and rank, drawn with seed 1000 + rank
     batches = {t: [synthetic.batch_to(synthetic.make_batch(cfg, t, a.batch, seed=1000 + rank + 97 * j,
                                                            txt_len=a.txt_len, sems_as="ids"), dev)
@@ -126,12 +150,15 @@ def main():
             losses.append(trainer.step(t, batches[t][i % 2]))
         return losses
 
+    log("batches resident; warm-up")
     run(a.warmup)
     barrier()
+    log(f"warm-up done; timing {a.steps} steps")
     t0 = time.perf_counter()
     losses = run(a.steps)
     barrier()
     dt = time.perf_counter() - t0
+    log(f"timed region: {1000 * dt / a.steps:.2f} ms/step")
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -152,6 +179,7 @@ def main():
 
     if rank == 0 and not a.no_kernel_pass:
         # ---- per-kernel timing pass (not part of the timed region above): HIP events around every C-ABI launch
+        log("kernel timing pass")
         ops.TRACE = {}
         prof_start = torch.cuda.Event(enable_timing=True)
         prof_end = torch.cuda.Event(enable_timing=True)
@@ -192,7 +220,9 @@ def main():
                                "avg_launch_us": dom["avg_us"], "launches": dom["launches"]}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log("cpu baseline (oracle)")
         out["cpu_baseline"] = cpu_baseline(cfg, a)
+    log("done")
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -205,7 +235,7 @@ def cpu_baseline(cfg, a):
     from oracle import bevbert_ref as R
     from vln_bevbert_amd import synthetic, weights
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
-    n = a.cpu_threads or os.cpu_count()
+    n = a.cpu_threads or usable_cores()
     torch.set_num_threads(n)
     shapes = {k: tuple(v.shape) for k, v in GlocalTextPathCMTPreTraining(cfg).state_dict().items()}
     sd = {k: v.requires_grad_(True) for k, v in weights.fill_state_dict(shapes).items()}
@@ -213,8 +243,10 @@ def cpu_baseline(cfg, a):
     m = [torch.zeros_like(p) for p in params]
     v = [torch.zeros_like(p) for p in params]
     B = 4
-    t_total, n_samples = 0.0, 0
+    t_total, n_samples, budget_s = 0.0, 0, 30.0
     for it, task in enumerate(("sap", "mlm", "sap", "mlm", "masksem")):
+        if t_total > budget_s:
+            break
         b = synthetic.make_batch(cfg, task, B, seed=4000 + it, txt_len=a.txt_len)
         t0 = time.perf_counter()
         loss = R.pretrain_forward(sd, cfg, b, task).mean()
@@ -224,12 +256,13 @@ def cpu_baseline(cfg, a):
                 if g is not None:
                     R.adamw_step(p, g, mm, vv, it + 1, 5e-5, 0.01)
         dt = time.perf_counter() - t0
+        log(f"  cpu step {it} ({task}): {dt:.2f} s")
         if it > 0:                         # first iteration pages everything in
             t_total += dt
             n_samples += B
     return {"value": round(n_samples / t_total, 3), "unit": "samples/s", "cores": n, "kind": "port",
-            "sample": f"4 steps (sap, mlm, sap, masksem) of batch {B}, same shapes, fp32, dropout off, "
-                      f"torch CPU with {n} threads; 1 untimed warm-up step"}
+            "sample": f"{n_samples // B} steps (mlm, sap, mlm, masksem order) of batch {B}, same shapes, fp32, "
+                      f"dropout off, fwd+bwd+AdamW, torch CPU with {n} threads; 1 untimed warm-up step"}
 
 
 if __name__ == "__main__":

