@@ -100,6 +100,10 @@ int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const 
                                     float* rstd, int rows, int L, int H, float eps, int dtype, float drop_p,
                                     uint64_t seed, uint64_t offset, hipStream_t stream);
 
+/* backward of the word-embedding gather of BertEmbeddings: table_grad[ids[r], :] += d[r, :] (fp32 atomics). */
+int bevbert_embedding_grad(const int64_t* ids, const void* d, float* table_grad, int rows, int H, int dtype,
+                           hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * K4  y = gelu_erf(x + bias)  -- BertIntermediate.forward + gelu (vilmodel.py:31-37,177-180); F.gelu in the pano
  * encoder (transformer.py:178).  bwd: dx = dy * gelu'(x + bias) (dx may alias dy), dbias (C) written/accumulated. */

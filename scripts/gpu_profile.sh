@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- \
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- \
   python "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-pass "$@" > "$OUT/trace_bench.log" 2>&1
 echo "trace rc=$?" >> "$OUT/trace_bench.log"
 # keep only the summaries (the raw trace is large)

@@ -315,14 +315,16 @@ def test_attention_fwd_bwd(ops, case, impl, dtype):
         assert rel_err(bi.grad, br.grad) < gt, "dbias"
 
 
+@pytest.mark.parametrize("Lk", [140, 441])
 @pytest.mark.parametrize("impl,dtype", [(1, torch.float32), (2, torch.bfloat16)])
-def test_attention_dropout_matches_exported_mask(ops, impl, dtype):
-    B, Lq, Lk, p = 2, 100, 140, 0.1
+def test_attention_dropout_matches_exported_mask(ops, impl, dtype, Lk):
+    B, Lq, p = 2, 100, 0.1
     q, k, v, km, _, nh = _make_attn_inputs(B, Lq, Lk, "neg", False, dtype, seed=5)
     ops.RT.new_step(99)
     qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
     o = ops._Attention.apply("sep", qi, ki, vi, km, None, nh, p, impl)
-    keep = ops.dropout_keep_mask(B * nh * Lq * Lk, p, 99, 0, DEV).view(B, nh, Lq, Lk)
+    Lk2 = (Lk + 1) // 2 * 2            # the kernels index dropout elements with the key count rounded up to even
+    keep = ops.dropout_keep_mask(B * nh * Lq * Lk2, p, 99, 0, DEV).view(B, nh, Lq, Lk2)[..., :Lk]
     assert abs(float(keep.float().mean()) - 0.9) < 0.01
     qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
     orf = _attn_ref(qr, kr, vr, km, None, nh, keep, p)

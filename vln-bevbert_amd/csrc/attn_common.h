@@ -25,8 +25,9 @@ struct AttnArgs {
   int B, nh, Lq, Lk;
   float scale;
   float drop_p;
-  uint32_t drop_thr;
-  uint64_t seed, offset;
+  uint32_t drop_thr;   // 16-bit threshold
+  uint32_t drop_key;   // bb_site_key(seed, offset)
+  int Lk2;             // Lk rounded up to even: dropout element index = ((b*nh + h)*Lq + q)*Lk2 + k
   // backward only
   const void* dout;        // (B, Lq, nh*64), strides ldo/bso
   const float* delta;      // (B, nh, Lq) rowsum(dO * O)
@@ -34,6 +35,9 @@ struct AttnArgs {
   float* dbias;            // (B, Lq, Lk) fp32, accumulated with atomics over heads, or null
 };
 
-__device__ __forceinline__ uint64_t attn_elem(const AttnArgs& a, int b, int h, int q, int k) {
-  return a.offset + (((uint64_t)b * a.nh + h) * a.Lq + q) * (uint64_t)a.Lk + k;
+__device__ __forceinline__ uint32_t attn_row_base(const AttnArgs& a, int b, int h, int q) {
+  return (uint32_t)((((uint32_t)b * a.nh + h) * a.Lq + q) * (uint32_t)a.Lk2);
+}
+__device__ __forceinline__ uint32_t attn_elem(const AttnArgs& a, int b, int h, int q, int k) {
+  return attn_row_base(a, b, h, q) + (uint32_t)k;
 }

@@ -16,6 +16,8 @@
 // never touches LDS.  K tiles are staged row-major [key][d]; V tiles are staged transposed [d][key] so the A
 // fragments of the second product are two 8-byte LDS reads.  Row stride 72 bf16 (144 B) keeps 16-byte reads of 16
 // consecutive rows on distinct banks.
+#include <stdlib.h>
+
 #include "attn_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -37,30 +39,38 @@ __device__ __forceinline__ uint4 ld_frag_global(const bf16_raw* base, int64_t ld
   return *reinterpret_cast<const uint4*>(base + (size_t)row * ld + d0);
 }
 
-// Stage a [TK rows][64] tile row-major into LDS (dst[row][d], stride LDT); rows >= nrows are zero filled.
-__device__ __forceinline__ void stage_rows(bf16_raw* dst, const bf16_raw* src, int64_t ld, int row0, int nrows,
-                                           int tid) {
+// A [TK rows][64] tile travels global -> registers -> LDS in two steps so that the global loads of tile j+1 are in
+// flight while tile j is being computed.  Thread t owns 16-byte chunks c = t and t + 256: row c >> 3, dims 8 (c & 7)..+7.
+struct TileRegs { uint4 v[2]; };
+__device__ __forceinline__ void tile_load(TileRegs& r, const bf16_raw* src, int64_t ld, int row0, int nrows, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int c = tid + i * 256, r = c >> 3, ch = c & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + r < nrows) v = ld_frag_global(src, ld, row0 + r, ch * 8);
-    *reinterpret_cast<uint4*>(dst + r * LDT + ch * 8) = v;
+    const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+    r.v[i] = make_uint4(0, 0, 0, 0);                       // rows past the end are zero filled
+    if (row0 + row < nrows) r.v[i] = ld_frag_global(src, ld, row0 + row, ch * 8);
   }
 }
-// Stage the same tile transposed (dst[d][row], stride LDT).
-__device__ __forceinline__ void stage_cols(bf16_raw* dst, const bf16_raw* src, int64_t ld, int row0, int nrows,
-                                           int tid) {
+// row-major image: dst[row][d], stride LDT
+__device__ __forceinline__ void tile_store_rows(bf16_raw* dst, const TileRegs& r, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int c = tid + i * 256, r = c >> 3, ch = c & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + r < nrows) v = ld_frag_global(src, ld, row0 + r, ch * 8);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+    *reinterpret_cast<uint4*>(dst + row * LDT + ch * 8) = r.v[i];
+  }
+}
+// transposed image: dst[d][row ^ swz(d)], swz(d) = 8 * ((d >> 3) & 7).  Without the XOR the 64 lanes of a wave
+// (8 rows x 8 chunks) would hit 4 banks (16-way conflict); with it they cover 64 consecutive columns of one d-row.
+__device__ __forceinline__ int swz_cols(int d) { return ((d >> 3) & 7) << 3; }
+__device__ __forceinline__ void tile_store_cols(bf16_raw* dst, const TileRegs& r, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+    const int col = row ^ (ch << 3);                        // swz_cols(ch*8 + e) == ch << 3 for e in 0..7
+    const uint32_t w[4] = {r.v[i].x, r.v[i].y, r.v[i].z, r.v[i].w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      dst[(ch * 8 + 2 * j) * LDT + r] = (bf16_raw)(w[j] & 0xffffu);
-      dst[(ch * 8 + 2 * j + 1) * LDT + r] = (bf16_raw)(w[j] >> 16);
+      dst[(ch * 8 + 2 * j) * LDT + col] = (bf16_raw)(w[j] & 0xffffu);
+      dst[(ch * 8 + 2 * j + 1) * LDT + col] = (bf16_raw)(w[j] >> 16);
     }
   }
 }
@@ -70,11 +80,16 @@ __device__ __forceinline__ bf16x8 lds_frag_rows(const bf16_raw* tile, int t, int
 }
 // A fragment from a transposed tile: row d = dt*16 + (l&15), k-slots (g, j) <-> tile column 32 m + 16 (j>>2) + 4 g + (j&3)
 __device__ __forceinline__ bf16x8 lds_frag_cols(const bf16_raw* tileT, int dt, int m, int lane) {
-  const bf16_raw* p = tileT + (dt * 16 + (lane & 15)) * LDT + m * 32 + (lane >> 4) * 4;
-  const uint2 lo = *reinterpret_cast<const uint2*>(p);
-  const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+  const int d = dt * 16 + (lane & 15);
+  const bf16_raw* row = tileT + d * LDT;
+  const int c0 = (m * 32 + (lane >> 4) * 4) ^ swz_cols(d);         // XOR by a multiple of 8 keeps 4-runs contiguous
+  const int c1 = (m * 32 + 16 + (lane >> 4) * 4) ^ swz_cols(d);
+  const uint2 lo = *reinterpret_cast<const uint2*>(row + c0);
+  const uint2 hi = *reinterpret_cast<const uint2*>(row + c1);
   return as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
+// 2^x on the transcendental unit (v_exp_f32); arguments here are <= 0 and results below 2^-126 may flush to 0
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // pack accumulators of key/query tiles (2m, 2m+1) into the B operand of the second product
 __device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
   return as_bf16x8(make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
@@ -94,7 +109,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 // Forward.  Workgroup = 4 waves; wave w owns QT query tiles of 16 rows: rows q0 + (w*QT + qt)*16 + (l&15).
 // =============================================================================================
 template <int QT>
-__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_raw s_k[TK * LDT];
   __shared__ __attribute__((aligned(16))) bf16_raw s_vt[ATTN_D * LDT];
   __shared__ __attribute__((aligned(16))) float s_mask[TK];
@@ -126,10 +141,13 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
     for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
+  TileRegs kreg, vreg;
+  tile_load(kreg, kp, a.ldk, 0, a.Lk, tid);
+  tile_load(vreg, vp, a.ldv, 0, a.Lk, tid);
   for (int kv0 = 0; kv0 < a.Lk; kv0 += TK) {
     __syncthreads();  // previous tile fully consumed
-    stage_rows(s_k, kp, a.ldk, kv0, a.Lk, tid);
-    stage_cols(s_vt, vp, a.ldv, kv0, a.Lk, tid);
+    tile_store_rows(s_k, kreg, tid);
+    tile_store_cols(s_vt, vreg, tid);
     if (tid < TK) {
       const int key = kv0 + tid;
       float mv = -INFINITY;
@@ -137,6 +155,10 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
       s_mask[tid] = mv;
     }
     __syncthreads();
+    if (kv0 + TK < a.Lk) {  // next tile's global loads fly while this tile is computed
+      tile_load(kreg, kp, a.ldk, kv0 + TK, a.Lk, tid);
+      tile_load(vreg, vp, a.ldv, kv0 + TK, a.Lk, tid);
+    }
 
     // ---- S^T = K Q^T
     f32x4 sacc[QT][4];
@@ -173,21 +195,29 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
       mx = quad_max(mx);
       const float m_new = fmaxf(m_run[qt], mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = exp2f(m_run[qt] - m_use);  // first tile: exp2(-inf) = 0
+      const float alpha = fast_exp2(m_run[qt] - m_use);  // first tile: exp2(-inf) = 0
       m_run[qt] = m_new;
       float psum = 0.f;
+      const uint32_t rbase = attn_row_base(a, b, h, qrow[qt]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        float p[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = exp2f(sacc[qt][t][r] - m_use);
-          psum += p;
-          if (a.drop_p > 0.f) {
-            const int key = kv0 + t * 16 + g * 4 + r;
-            p = bb_keep(a.seed, attn_elem(a, b, h, qrow[qt], key), a.drop_thr) ? p * keep_scale : 0.f;
-          }
-          sacc[qt][t][r] = p;
+          p[r] = fast_exp2(sacc[qt][t][r] - m_use);
+          psum += p[r];
         }
+        if (a.drop_p > 0.f) {   // keys kv0+16t+4g .. +3: two index pairs, one hash each
+          const uint32_t pr = (rbase + (uint32_t)(kv0 + t * 16 + g * 4)) >> 1;
+          const uint32_t b0 = bb_pair_bits(a.drop_key, pr), b1 = bb_pair_bits(a.drop_key, pr + 1);
+          p[0] = bb_keep_lo(b0, a.drop_thr) ? p[0] * keep_scale : 0.f;
+          p[1] = bb_keep_hi(b0, a.drop_thr) ? p[1] * keep_scale : 0.f;
+          p[2] = bb_keep_lo(b1, a.drop_thr) ? p[2] * keep_scale : 0.f;
+          p[3] = bb_keep_hi(b1, a.drop_thr) ? p[3] * keep_scale : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[qt][t][r] = p[r];
+      }
       l_run[qt] = l_run[qt] * alpha + psum;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
@@ -233,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
 //   S^T, P = exp2(S2 - lse2);  dP^T = V dO^T;  dS = P * (drop(dP) - delta);  dQ^T += K^T dS^T
 // =============================================================================================
 template <int QT>
-__global__ __launch_bounds__(256) void attn_mfma_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_raw s_k[TK * LDT];
   __shared__ __attribute__((aligned(16))) bf16_raw s_v[TK * LDT];
   __shared__ __attribute__((aligned(16))) bf16_raw s_kt[ATTN_D * LDT];
@@ -248,6 +278,7 @@ __global__ __launch_bounds__(256) void attn_mfma_dq_kernel(AttnArgs a) {
   const float sc2 = a.scale * LOG2E;
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
 
+  const bf16_raw* op = (const bf16_raw*)a.o + (size_t)b * a.bso + h * ATTN_D;
   bf16x8 qf[QT][2], dof[QT][2];
   int qrow[QT];
   float lse2[QT], dlt[QT];
@@ -255,14 +286,23 @@ __global__ __launch_bounds__(256) void attn_mfma_dq_kernel(AttnArgs a) {
   for (int qt = 0; qt < QT; ++qt) {
     qrow[qt] = qbase + qt * 16 + c;
     const int r = qrow[qt] < a.Lq ? qrow[qt] : a.Lq - 1;
+    float dsum = 0.f;      // delta[q] = sum_d dO[q][d] * O[q][d]: this lane's 16 dims, then the 4 lanes of the query
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       qf[qt][ks] = as_bf16x8(ld_frag_global(qp, a.ldq, r, ks * 32 + g * 8));
-      dof[qt][ks] = as_bf16x8(ld_frag_global(dop, a.ldo, r, ks * 32 + g * 8));
+      const uint4 du = ld_frag_global(dop, a.ldo, r, ks * 32 + g * 8);
+      const uint4 ou = ld_frag_global(op, a.ldo, r, ks * 32 + g * 8);
+      dof[qt][ks] = as_bf16x8(du);
+      const uint32_t dw[4] = {du.x, du.y, du.z, du.w}, ow[4] = {ou.x, ou.y, ou.z, ou.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        dsum += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16) +
+                __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
     }
+    dlt[qt] = quad_sum(dsum);
     const size_t ridx = ((size_t)b * a.nh + h) * a.Lq + r;
     lse2[qt] = a.lse[ridx] * LOG2E;
-    dlt[qt] = a.delta[ridx];
+    if (g == 0 && qrow[qt] < a.Lq) const_cast<float*>(a.delta)[ridx] = dlt[qt];   // consumed by the dK/dV kernel
   }
   f32x4 dqacc[QT][4];
 #pragma unroll
@@ -270,11 +310,14 @@ __global__ __launch_bounds__(256) void attn_mfma_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dqacc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  TileRegs kreg, vreg;
+  tile_load(kreg, kp, a.ldk, 0, a.Lk, tid);
+  tile_load(vreg, vp, a.ldv, 0, a.Lk, tid);
   for (int kv0 = 0; kv0 < a.Lk; kv0 += TK) {
     __syncthreads();
-    stage_rows(s_k, kp, a.ldk, kv0, a.Lk, tid);
-    stage_rows(s_v, vp, a.ldv, kv0, a.Lk, tid);
-    stage_cols(s_kt, kp, a.ldk, kv0, a.Lk, tid);
+    tile_store_rows(s_k, kreg, tid);
+    tile_store_cols(s_kt, kreg, tid);
+    tile_store_rows(s_v, vreg, tid);
     if (tid < TK) {
       const int key = kv0 + tid;
       float mv = -INFINITY;
@@ -282,60 +325,72 @@ __global__ __launch_bounds__(256) void attn_mfma_dq_kernel(AttnArgs a) {
       s_mask[tid] = mv;
     }
     __syncthreads();
+    if (kv0 + TK < a.Lk) {
+      tile_load(kreg, kp, a.ldk, kv0 + TK, a.Lk, tid);
+      tile_load(vreg, vp, a.ldv, kv0 + TK, a.Lk, tid);
+    }
 
-    f32x4 sacc[QT][4], dpacc[QT][4];
+    // two halves of 32 keys: scores + dP for key tiles (2m, 2m+1), then their contribution to dQ^T
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int m = 0; m < 2; ++m) {
+      f32x4 sacc[QT][2], dpacc[QT][2];
 #pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        sacc[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dpacc[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 kf = lds_frag_rows(s_k, t, ks, lane);
-        const bf16x8 vf = lds_frag_rows(s_v, t, ks, lane);
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * m + tt;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-          sacc[qt][t] = mfma16(kf, qf[qt][ks], sacc[qt][t]);
-          dpacc[qt][t] = mfma16(vf, dof[qt][ks], dpacc[qt][t]);
+          sacc[qt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          dpacc[qt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 kf = lds_frag_rows(s_k, t, ks, lane);
+          const bf16x8 vf = lds_frag_rows(s_v, t, ks, lane);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            sacc[qt][tt] = mfma16(kf, qf[qt][ks], sacc[qt][tt]);
+            dpacc[qt][tt] = mfma16(vf, dof[qt][ks], dpacc[qt][tt]);
+          }
         }
       }
-    }
+      bf16x8 dsb[QT];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
+      for (int qt = 0; qt < QT; ++qt) {
+        const uint32_t rbase = attn_row_base(a, b, h, qrow[qt]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float4 mk = *reinterpret_cast<const float4*>(&s_mask[t * 16 + g * 4]);
-        const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * m + tt;
+          const float4 mk = *reinterpret_cast<const float4*>(&s_mask[t * 16 + g * 4]);
+          const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+          bool keep[4] = {true, true, true, true};
+          if (a.drop_p > 0.f) {
+            const uint32_t pr = (rbase + (uint32_t)(kv0 + t * 16 + g * 4)) >> 1;
+            const uint32_t b0 = bb_pair_bits(a.drop_key, pr), b1 = bb_pair_bits(a.drop_key, pr + 1);
+            keep[0] = bb_keep_lo(b0, a.drop_thr); keep[1] = bb_keep_hi(b0, a.drop_thr);
+            keep[2] = bb_keep_lo(b1, a.drop_thr); keep[3] = bb_keep_hi(b1, a.drop_thr);
+          }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + t * 16 + g * 4 + r;
-          const bool valid = key < a.Lk && qrow[qt] < a.Lq;
-          float s = sacc[qt][t][r] * sc2 + mkv[r];
-          if (a.bias && valid) s += a.bias[((size_t)b * a.Lq + qrow[qt]) * a.Lk + key] * LOG2E;
-          const float p = exp2f(s - lse2[qt]);
-          float dp = dpacc[qt][t][r];
-          if (a.drop_p > 0.f) dp = bb_keep(a.seed, attn_elem(a, b, h, qrow[qt], key), a.drop_thr) ? dp * keep_scale : 0.f;
-          const float ds = valid ? p * (dp - dlt[qt]) : 0.f;
-          sacc[qt][t][r] = ds;
-          if (a.dbias && valid) atomicAdd(a.dbias + ((size_t)b * a.Lq + qrow[qt]) * a.Lk + key, ds);
+          for (int r = 0; r < 4; ++r) {
+            const int key = kv0 + t * 16 + g * 4 + r;
+            const bool valid = key < a.Lk && qrow[qt] < a.Lq;
+            float sv = sacc[qt][tt][r] * sc2 + mkv[r];
+            if (a.bias && valid) sv += a.bias[((size_t)b * a.Lq + qrow[qt]) * a.Lk + key] * LOG2E;
+            const float p = fast_exp2(sv - lse2[qt]);
+            const float dp = keep[r] ? dpacc[qt][tt][r] * keep_scale : 0.f;
+            const float ds = valid ? p * (dp - dlt[qt]) : 0.f;
+            sacc[qt][tt][r] = ds;
+            if (a.dbias && valid) atomicAdd(a.dbias + ((size_t)b * a.Lq + qrow[qt]) * a.Lk + key, ds);
+          }
         }
+        dsb[qt] = pack_pair(sacc[qt][0], sacc[qt][1]);
       }
-    bf16x8 dsb[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      dsb[qt][0] = pack_pair(sacc[qt][0], sacc[qt][1]);
-      dsb[qt][1] = pack_pair(sacc[qt][2], sacc[qt][3]);
-    }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int dt = 0; dt < 4; ++dt) {
         const bf16x8 kt = lds_frag_cols(s_kt, dt, m, lane);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) dqacc[qt][dt] = mfma16(kt, dsb[qt][m], dqacc[qt][dt]);
+        for (int qt = 0; qt < QT; ++qt) dqacc[qt][dt] = mfma16(kt, dsb[qt], dqacc[qt][dt]);
       }
+    }
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt)
@@ -355,7 +410,7 @@ __global__ __launch_bounds__(256) void attn_mfma_dq_kernel(AttnArgs a) {
 //   dV^T += dO^T Pd ;  dK^T += Q^T dS      (A = transposed dO / Q tiles, B = packed Pd / dS, k-slots <-> queries)
 // =============================================================================================
 template <int KT>
-__global__ __launch_bounds__(256) void attn_mfma_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_raw s_q[TK * LDT];
   __shared__ __attribute__((aligned(16))) bf16_raw s_do[TK * LDT];
   __shared__ __attribute__((aligned(16))) bf16_raw s_qt[ATTN_D * LDT];
@@ -395,12 +450,15 @@ __global__ __launch_bounds__(256) void attn_mfma_dkv_kernel(AttnArgs a) {
       dvacc[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
+  TileRegs qreg, doreg;
+  tile_load(qreg, qp, a.ldq, 0, a.Lq, tid);
+  tile_load(doreg, dop, a.ldo, 0, a.Lq, tid);
   for (int q0 = 0; q0 < a.Lq; q0 += TK) {
     __syncthreads();
-    stage_rows(s_q, qp, a.ldq, q0, a.Lq, tid);
-    stage_rows(s_do, dop, a.ldo, q0, a.Lq, tid);
-    stage_cols(s_qt, qp, a.ldq, q0, a.Lq, tid);
-    stage_cols(s_dot, dop, a.ldo, q0, a.Lq, tid);
+    tile_store_rows(s_q, qreg, tid);
+    tile_store_cols(s_qt, qreg, tid);
+    tile_store_rows(s_do, doreg, tid);
+    tile_store_cols(s_dot, doreg, tid);
     if (tid < TK) {
       const int qi = q0 + tid;
       const size_t ridx = ((size_t)b * a.nh + h) * a.Lq + (qi < a.Lq ? qi : a.Lq - 1);
@@ -408,71 +466,77 @@ __global__ __launch_bounds__(256) void attn_mfma_dkv_kernel(AttnArgs a) {
       s_dlt[tid] = a.delta[ridx];
     }
     __syncthreads();
+    if (q0 + TK < a.Lq) {
+      tile_load(qreg, qp, a.ldq, q0 + TK, a.Lq, tid);
+      tile_load(doreg, dop, a.ldo, q0 + TK, a.Lq, tid);
+    }
 
-    f32x4 sacc[KT][4], dpacc[KT][4];
+    // two halves of 32 queries: S and dP for query tiles (2m, 2m+1), then their contribution to dK^T / dV^T
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int m = 0; m < 2; ++m) {
+      f32x4 sacc[KT][2], dpacc[KT][2];
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        sacc[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dpacc[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 qa = lds_frag_rows(s_q, t, ks, lane);
-        const bf16x8 da = lds_frag_rows(s_do, t, ks, lane);
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * m + tt;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-          sacc[kt][t] = mfma16(qa, kf[kt][ks], sacc[kt][t]);
-          dpacc[kt][t] = mfma16(da, vf[kt][ks], dpacc[kt][t]);
+          sacc[kt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          dpacc[kt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 qa = lds_frag_rows(s_q, t, ks, lane);
+          const bf16x8 da = lds_frag_rows(s_do, t, ks, lane);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+            sacc[kt][tt] = mfma16(qa, kf[kt][ks], sacc[kt][tt]);
+            dpacc[kt][tt] = mfma16(da, vf[kt][ks], dpacc[kt][tt]);
+          }
         }
       }
-    }
-    // sacc -> dS, dpacc -> dropped P
+      // sacc -> dS, dpacc -> dropped P
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float4 l4 = *reinterpret_cast<const float4*>(&s_lse2[t * 16 + g * 4]);
-      const float4 d4 = *reinterpret_cast<const float4*>(&s_dlt[t * 16 + g * 4]);
-      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * m + tt;
+        const float4 l4 = *reinterpret_cast<const float4*>(&s_lse2[t * 16 + g * 4]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&s_dlt[t * 16 + g * 4]);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qi = q0 + t * 16 + g * 4 + r;
-          float s = sacc[kt][t][r] * sc2 + mask2[kt];
-          if (a.bias && qi < a.Lq && krow[kt] < a.Lk)
-            s += a.bias[((size_t)b * a.Lq + qi) * a.Lk + krow[kt]] * LOG2E;
-          const float p = exp2f(s - lv[r]);
-          float dp = dpacc[kt][t][r], pd = p;
-          if (a.drop_p > 0.f) {
-            const bool keep = bb_keep(a.seed, attn_elem(a, b, h, qi, krow[kt]), a.drop_thr);
-            dp = keep ? dp * keep_scale : 0.f;
-            pd = keep ? p * keep_scale : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + t * 16 + g * 4 + r;
+            float sv = sacc[kt][tt][r] * sc2 + mask2[kt];
+            if (a.bias && qi < a.Lq && krow[kt] < a.Lk)
+              sv += a.bias[((size_t)b * a.Lq + qi) * a.Lk + krow[kt]] * LOG2E;
+            const float p = fast_exp2(sv - lv[r]);
+            float dp = dpacc[kt][tt][r], pd = p;
+            if (a.drop_p > 0.f) {
+              const bool keep = bb_keep(a.drop_key, attn_elem(a, b, h, qi, krow[kt]), a.drop_thr);
+              dp = keep ? dp * keep_scale : 0.f;
+              pd = keep ? p * keep_scale : 0.f;
+            }
+            sacc[kt][tt][r] = p * (dp - dv[r]);
+            dpacc[kt][tt][r] = pd;
           }
-          sacc[kt][t][r] = p * (dp - dv[r]);
-          dpacc[kt][t][r] = pd;
-        }
-    }
-    bf16x8 dsb[KT][2], pdb[KT][2];
+      }
+      bf16x8 dsb[KT], pdb[KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      dsb[kt][0] = pack_pair(sacc[kt][0], sacc[kt][1]);
-      dsb[kt][1] = pack_pair(sacc[kt][2], sacc[kt][3]);
-      pdb[kt][0] = pack_pair(dpacc[kt][0], dpacc[kt][1]);
-      pdb[kt][1] = pack_pair(dpacc[kt][2], dpacc[kt][3]);
-    }
+      for (int kt = 0; kt < KT; ++kt) {
+        dsb[kt] = pack_pair(sacc[kt][0], sacc[kt][1]);
+        pdb[kt] = pack_pair(dpacc[kt][0], dpacc[kt][1]);
+      }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int dt = 0; dt < 4; ++dt) {
         const bf16x8 qt_ = lds_frag_cols(s_qt, dt, m, lane);
         const bf16x8 dot_ = lds_frag_cols(s_dot, dt, m, lane);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-          dkacc[kt][dt] = mfma16(qt_, dsb[kt][m], dkacc[kt][dt]);
-          dvacc[kt][dt] = mfma16(dot_, pdb[kt][m], dvacc[kt][dt]);
+          dkacc[kt][dt] = mfma16(qt_, dsb[kt], dkacc[kt][dt]);
+          dvacc[kt][dt] = mfma16(dot_, pdb[kt], dvacc[kt][dt]);
         }
       }
+    }
   }
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
@@ -499,9 +563,16 @@ static bool aligned8(const AttnArgs& a) {
          ((uintptr_t)a.v % 16) == 0 && ((uintptr_t)a.o % 16) == 0;
 }
 
+// Tile-shape knobs for A/B measurements (read once): BEVBERT_FWD_QT / BEVBERT_DQ_QT / BEVBERT_DKV_KT in {1, 2}.
+static int env_knob(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && (v[0] == '1' || v[0] == '2')) ? v[0] - '0' : dflt;
+}
+
 int attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
+  static const int fwd_qt = env_knob("BEVBERT_FWD_QT", 2);
   BB_REQUIRE(aligned8(a), "attention (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
-  if (a.Lq > 64) {
+  if (a.Lq > 64 && fwd_qt == 2) {
     hipLaunchKernelGGL(attn_mfma_fwd_kernel<2>, dim3((a.Lq + 127) / 128, a.nh, a.B), dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL(attn_mfma_fwd_kernel<1>, dim3((a.Lq + 63) / 64, a.nh, a.B), dim3(256), 0, st, a);
@@ -514,11 +585,12 @@ int attn_mfma_bwd(const AttnArgs& a, hipStream_t st) {
   BB_REQUIRE(aligned8(a), "attention (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
   BB_REQUIRE(((uintptr_t)a.dout % 16) == 0 && ((uintptr_t)a.dq % 16) == 0 && ((uintptr_t)a.dk % 16) == 0 &&
                  ((uintptr_t)a.dv % 16) == 0, "attention bwd (MFMA path): gradient pointers must be 16-byte aligned");
-  if (a.Lq > 64)
+  static const int dq_qt = env_knob("BEVBERT_DQ_QT", 2), dkv_kt = env_knob("BEVBERT_DKV_KT", 1);
+  if (a.Lq > 64 && dq_qt == 2)
     hipLaunchKernelGGL(attn_mfma_dq_kernel<2>, dim3((a.Lq + 127) / 128, a.nh, a.B), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(attn_mfma_dq_kernel<1>, dim3((a.Lq + 63) / 64, a.nh, a.B), dim3(256), 0, st, a);
-  if (a.Lk > 64)
+  if (a.Lk > 64 && dkv_kt == 2)
     hipLaunchKernelGGL(attn_mfma_dkv_kernel<2>, dim3((a.Lk + 127) / 128, a.nh, a.B), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(attn_mfma_dkv_kernel<1>, dim3((a.Lk + 63) / 64, a.nh, a.B), dim3(256), 0, st, a);

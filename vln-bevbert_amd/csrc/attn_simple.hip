@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void attn_simple_fwd_kernel(AttnArgs a) {
   for (int key = lane; key < a.Lk; key += 64) {
     float p = __expf(s_p[w][key] - m_use);
     l += p;
-    if (a.drop_p > 0.f) p = bb_keep(a.seed, attn_elem(a, b, h, qi, key), a.drop_thr) ? p * keep_scale : 0.f;
+    if (a.drop_p > 0.f) p = bb_keep(a.drop_key, attn_elem(a, b, h, qi, key), a.drop_thr) ? p * keep_scale : 0.f;
     s_p[w][key] = p;
   }
   l = wave_sum(l);
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_simple_dq_kernel(AttnArgs a) {
     const float s = score<T>(a, kbase, s_q[w], b, qi, key);
     const float p = __expf(s - lse);
     float dp = dot64_row<T>(vbase + (size_t)key * a.ldv, s_do[w]);
-    if (a.drop_p > 0.f) dp = bb_keep(a.seed, attn_elem(a, b, h, qi, key), a.drop_thr) ? dp * keep_scale : 0.f;
+    if (a.drop_p > 0.f) dp = bb_keep(a.drop_key, attn_elem(a, b, h, qi, key), a.drop_thr) ? dp * keep_scale : 0.f;
     const float ds = p * (dp - delta);
     s_ds[w][key] = ds;
     if (a.dbias) atomicAdd(a.dbias + ((size_t)b * a.Lq + qi) * a.Lk + key, ds);
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_simple_dkv_kernel(AttnArgs a) {
     float dp = wave_sum(dod * vd);
     float pd = p;
     if (a.drop_p > 0.f) {
-      const bool keep = bb_keep(a.seed, attn_elem(a, b, h, qi, key), a.drop_thr);
+      const bool keep = bb_keep(a.drop_key, attn_elem(a, b, h, qi, key), a.drop_thr);
       dp = keep ? dp * keep_scale : 0.f;
       pd = keep ? p * keep_scale : 0.f;
     }

@@ -40,7 +40,9 @@ static int fill_common(AttnArgs& a, const void* q, const void* k, const void* v,
   a.ldq = strides[0]; a.ldk = strides[1]; a.ldv = strides[2]; a.ldo = strides[3];
   a.bsq = strides[4]; a.bsk = strides[5]; a.bsv = strides[6]; a.bso = strides[7];
   a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
-  a.drop_p = drop_p; a.drop_thr = bb_drop_threshold(drop_p); a.seed = seed; a.offset = offset;
+  a.drop_p = drop_p; a.drop_thr = bb_drop_threshold(drop_p); a.drop_key = bb_site_key(seed, offset);
+  a.Lk2 = (Lk + 1) & ~1;
+  BB_REQUIRE((double)B * nh * Lq * a.Lk2 < 4294967296.0, "attention: more than 2^32 score elements per launch");
   return BB_OK;
 }
 
@@ -73,27 +75,27 @@ BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, co
   BB_REQUIRE(lse != nullptr && delta_ws != nullptr, "attn_bwd: lse and the (B,nh,Lq) delta workspace are required");
   a.o = const_cast<void*>(o); a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta_ws;
   a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
-  rc = attn_delta(a, delta_ws, dtype, stream);
-  if (rc != BB_OK) return rc;
   const int im = pick_impl(dtype, impl);
-  if (im == 2) {
+  if (im == 2) {   // the MFMA dQ kernel computes delta itself (and publishes it for the dK/dV kernel)
     BB_REQUIRE(dtype == BB_BF16, "attn_bwd: the MFMA path takes bf16 tensors");
     return attn_mfma_bwd(a, stream);
   }
+  rc = attn_delta(a, delta_ws, dtype, stream);
+  if (rc != BB_OK) return rc;
   return attn_simple_bwd(a, dtype, stream);
 }
 
 // Test hook: materialise the dropout keep-mask the kernels derive from (seed, offset + element index).
-__global__ void keep_mask_kernel(uint8_t* out, size_t n, uint64_t seed, uint64_t offset, uint32_t thr) {
+__global__ void keep_mask_kernel(uint8_t* out, size_t n, uint32_t key, uint32_t thr) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    out[i] = (uint8_t)bb_keep(seed, offset + i, thr);
+    out[i] = (uint8_t)bb_keep(key, (uint32_t)i, thr);
 }
 BEVBERT_API int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p, uint64_t seed, uint64_t offset,
                                           hipStream_t stream) {
   if (n <= 0) return BB_OK;
   size_t nb = ((size_t)n + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(keep_mask_kernel, dim3(nb), dim3(256), 0, stream, out, (size_t)n, seed, offset,
+  hipLaunchKernelGGL(keep_mask_kernel, dim3(nb), dim3(256), 0, stream, out, (size_t)n, bb_site_key(seed, offset),
                      bb_drop_threshold(drop_p));
   BB_CHECK_LAUNCH("dropout_keep_mask");
   return BB_OK;

@@ -37,14 +37,14 @@ typedef unsigned short bf16_raw;
 
 // ---- scalar conversions (round-to-nearest-even, NaN preserved) ----------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_raw v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_raw)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_raw)(u >> 16);
-}
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even): let the compiler pick it
+typedef __bf16 bb_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) { return __builtin_bit_cast(bf16_raw, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  bb_bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> struct io;  // load/store `float` through storage type T
@@ -102,28 +102,35 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- counter-based dropout RNG --------------------------------------------------------------
-// keep(element) is a pure function of (seed, element index), so a backward kernel regenerates the
-// forward's mask without storing it.  One 32-bit mix per element ("lowbias32"-style finaliser over
-// seed-keyed 64-bit counter folded to 32 bits); statistical quality is ample for dropout.
-__device__ __forceinline__ uint32_t bb_hash32(uint32_t x) {
+// keep(element) is a pure function of (seed, offset, element index), so a backward kernel regenerates the forward's
+// mask instead of storing it.  A launch folds (seed, offset) into one 32-bit site key on the host; on the device one
+// 32-bit mix ("lowbias32") serves TWO neighbouring elements (index pair 2j, 2j+1 -> low / high 16 bits), compared
+// against a 16-bit threshold (p = 0.1 -> 6554/65536).  Element indices are < 2^32 per dropout site.
+__host__ __device__ __forceinline__ uint32_t bb_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du;
   x ^= x >> 15; x *= 0x846ca68bu;
   x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ uint32_t bb_rand32(uint64_t seed, uint64_t idx) {
-  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
-  return bb_hash32(lo ^ bb_hash32(hi ^ s1 ^ 0x9e3779b9u) ^ s0);
+__host__ __device__ __forceinline__ uint32_t bb_site_key(uint64_t seed, uint64_t offset) {
+  uint32_t k = bb_hash32((uint32_t)seed ^ 0x9e3779b9u);
+  k = bb_hash32(k ^ (uint32_t)(seed >> 32));
+  k = bb_hash32(k ^ (uint32_t)offset);
+  return bb_hash32(k ^ (uint32_t)(offset >> 32));
 }
-// threshold = round(p * 2^32) clamped; keep iff rand >= threshold
+// threshold = round(p * 2^16); keep iff the element's 16 random bits >= threshold
 __host__ __device__ __forceinline__ uint32_t bb_drop_threshold(float p) {
-  double t = (double)p * 4294967296.0;
-  if (t <= 0.0) return 0u;
-  if (t >= 4294967295.0) return 4294967295u;
-  return (uint32_t)(t + 0.5);
+  const float t = p * 65536.0f + 0.5f;
+  if (t <= 0.f) return 0u;
+  return t >= 65535.f ? 65535u : (uint32_t)t;
 }
-__device__ __forceinline__ bool bb_keep(uint64_t seed, uint64_t idx, uint32_t thr) { return bb_rand32(seed, idx) >= thr; }
+__device__ __forceinline__ uint32_t bb_pair_bits(uint32_t key, uint32_t pair_idx) { return bb_hash32(pair_idx ^ key); }
+__device__ __forceinline__ bool bb_keep_lo(uint32_t bits, uint32_t thr) { return (bits & 0xffffu) >= thr; }
+__device__ __forceinline__ bool bb_keep_hi(uint32_t bits, uint32_t thr) { return (bits >> 16) >= thr; }
+__device__ __forceinline__ bool bb_keep(uint32_t key, uint32_t idx, uint32_t thr) {
+  const uint32_t bits = bb_pair_bits(key, idx >> 1);
+  return ((idx & 1u) ? (bits >> 16) : (bits & 0xffffu)) >= thr;
+}
 
 // erf-GELU (reference: pretrain_src/model/vilmodel.py:31-37) and its derivative
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }

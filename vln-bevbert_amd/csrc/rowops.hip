@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      T* __restrict__ z_out, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int rows, float eps, float drop_p,
-                                                     uint32_t drop_thr, uint64_t seed, uint64_t offset,
+                                                     uint32_t drop_thr, uint32_t drop_key,
                                                      const int64_t* __restrict__ ids, const T* __restrict__ word,
                                                      const T* __restrict__ pos, const T* __restrict__ type_row, int L) {
   constexpr int H = NV * 256;
@@ -50,11 +50,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
     }
     if (drop_p > 0.f) {
-      const uint64_t e = offset + (uint64_t)row * H + col;
-      a.x = bb_keep(seed, e + 0, drop_thr) ? a.x * keep_scale : 0.f;
-      a.y = bb_keep(seed, e + 1, drop_thr) ? a.y * keep_scale : 0.f;
-      a.z = bb_keep(seed, e + 2, drop_thr) ? a.z * keep_scale : 0.f;
-      a.w = bb_keep(seed, e + 3, drop_thr) ? a.w * keep_scale : 0.f;
+      const uint32_t pr = ((uint32_t)row * H + col) >> 1;        // col % 4 == 0: two index pairs
+      const uint32_t b0 = bb_pair_bits(drop_key, pr), b1 = bb_pair_bits(drop_key, pr + 1);
+      a.x = bb_keep_lo(b0, drop_thr) ? a.x * keep_scale : 0.f;
+      a.y = bb_keep_hi(b0, drop_thr) ? a.y * keep_scale : 0.f;
+      a.z = bb_keep_lo(b1, drop_thr) ? a.z * keep_scale : 0.f;
+      a.w = bb_keep_hi(b1, drop_thr) ? a.w * keep_scale : 0.f;
     }
     if (residual != nullptr) {
       const float4 r = ld4<T>(residual + (size_t)row * H + col);
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, T* __restrict__ dz_out,
                                                      T* __restrict__ dx_out, float* __restrict__ partials, int rows,
-                                                     float drop_p, uint32_t drop_thr, uint64_t seed, uint64_t offset) {
+                                                     float drop_p, uint32_t drop_thr, uint32_t drop_key) {
   constexpr int H = NV * 256;
   __shared__ float4 s_red[3][4][NV * 64];  // [which][wave][lane-major float4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -144,11 +145,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       o.w = rs * (d[i].w - s1 - xh[i].w * s2);
       if (dz_out != nullptr) st4<T>(dz_out + (size_t)row * H + col, o);
       if (drop_p > 0.f) {
-        const uint64_t e = offset + (uint64_t)row * H + col;
-        o.x = bb_keep(seed, e + 0, drop_thr) ? o.x * keep_scale : 0.f;
-        o.y = bb_keep(seed, e + 1, drop_thr) ? o.y * keep_scale : 0.f;
-        o.z = bb_keep(seed, e + 2, drop_thr) ? o.z * keep_scale : 0.f;
-        o.w = bb_keep(seed, e + 3, drop_thr) ? o.w * keep_scale : 0.f;
+        const uint32_t pr = ((uint32_t)row * H + col) >> 1;
+        const uint32_t b0 = bb_pair_bits(drop_key, pr), b1 = bb_pair_bits(drop_key, pr + 1);
+        o.x = bb_keep_lo(b0, drop_thr) ? o.x * keep_scale : 0.f;
+        o.y = bb_keep_hi(b0, drop_thr) ? o.y * keep_scale : 0.f;
+        o.z = bb_keep_lo(b1, drop_thr) ? o.z * keep_scale : 0.f;
+        o.w = bb_keep_hi(b1, drop_thr) ? o.w * keep_scale : 0.f;
       }
       if (dx_out != nullptr) st4<T>(dx_out + (size_t)row * H + col, o);
       ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
@@ -173,14 +175,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-// out[c] (+)= sum_b partials[b][which][c]   (fixed order => deterministic)
-__global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nblocks, int nwhich, int which, int C,
-                                       float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out_w[c] (+)= sum_b partials[b][w][c] for every w with a non-null output.  Block = 64 columns x 16 partial groups:
+// coalesced 256-B reads, 16 independent running sums per column, fixed combination order => deterministic.
+struct FinalizeOut { float* out[3]; };
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ partials, int nblocks,
+                                                              int nwhich, int C, FinalizeOut o, int accumulate) {
+  __shared__ float sh[16][64];
+  const int which = blockIdx.y;
+  float* out = o.out[which];
+  if (out == nullptr) return;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c = blockIdx.x * 64 + tx;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partials[((size_t)b * nwhich + which) * C + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < C)
+    for (int b = ty; b < nblocks; b += 16) s += partials[((size_t)b * nwhich + which) * C + c];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    float t = sh[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sh[k][tx];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+static void launch_finalize(const float* partials, int nblocks, int nwhich, int C, float* o0, float* o1, float* o2,
+                            int accumulate, hipStream_t stream) {
+  FinalizeOut o;
+  o.out[0] = o0; o.out[1] = o1; o.out[2] = o2;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64, nwhich), dim3(64, 16), 0, stream, partials, nblocks,
+                     nwhich, C, o, accumulate);
 }
 
 // =============================================================================================
@@ -199,27 +222,47 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict_
 }
 
 // MODE 0: dx = dy * gelu'(x + bias) ; partial column sums of dx.   MODE 1: plain column sums of dy (no dx).
+// Grid (row groups, column slices of 1024): thread t owns 4 columns and walks its row group 4 rows at a time
+// (4 independent loads in flight); partials[blockIdx.x][C].
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colwise_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ bias, T* __restrict__ dx,
                                                           float* __restrict__ partials, int rows, int C) {
-  // thread t owns columns [4t, 4t+4) + k*1024
-  for (int c0 = threadIdx.x * 4; c0 < C; c0 += 1024) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == 0) b = *reinterpret_cast<const float4*>(bias + c0);
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-      float4 d = ld4<T>(dy + (size_t)r * C + c0);
-      if (MODE == 0) {
-        const float4 a = ld4<T>(x + (size_t)r * C + c0);
-        d.x *= gelu_erf_grad(a.x + b.x); d.y *= gelu_erf_grad(a.y + b.y);
-        d.z *= gelu_erf_grad(a.z + b.z); d.w *= gelu_erf_grad(a.w + b.w);
-        st4<T>(dx + (size_t)r * C + c0, d);
-      }
-      acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+  const int c0 = blockIdx.y * 1024 + threadIdx.x * 4;
+  if (c0 >= C) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == 0) b = *reinterpret_cast<const float4*>(bias + c0);
+  const int stride = gridDim.x;
+  int r = blockIdx.x;
+  for (; r + 3 * stride < rows; r += 4 * stride) {
+    float4 d[4], a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      d[k] = ld4<T>(dy + (size_t)(r + k * stride) * C + c0);
+      if (MODE == 0) a[k] = ld4<T>(x + (size_t)(r + k * stride) * C + c0);
     }
-    *reinterpret_cast<float4*>(partials + (size_t)blockIdx.x * C + c0) = acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (MODE == 0) {
+        d[k].x *= gelu_erf_grad(a[k].x + b.x); d[k].y *= gelu_erf_grad(a[k].y + b.y);
+        d[k].z *= gelu_erf_grad(a[k].z + b.z); d[k].w *= gelu_erf_grad(a[k].w + b.w);
+        st4<T>(dx + (size_t)(r + k * stride) * C + c0, d[k]);
+      }
+      acc.x += d[k].x; acc.y += d[k].y; acc.z += d[k].z; acc.w += d[k].w;
+    }
   }
+  for (; r < rows; r += stride) {
+    float4 d = ld4<T>(dy + (size_t)r * C + c0);
+    if (MODE == 0) {
+      const float4 a = ld4<T>(x + (size_t)r * C + c0);
+      d.x *= gelu_erf_grad(a.x + b.x); d.y *= gelu_erf_grad(a.y + b.y);
+      d.z *= gelu_erf_grad(a.z + b.z); d.w *= gelu_erf_grad(a.w + b.w);
+      st4<T>(dx + (size_t)r * C + c0, d);
+    }
+    acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+  }
+  *reinterpret_cast<float4*>(partials + (size_t)blockIdx.x * C + c0) = acc;
 }
 
 // =============================================================================================
@@ -241,6 +284,18 @@ __global__ __launch_bounds__(192) void gather_wsum_kernel(const T* __restrict__ 
       acc.x += ww * v.x; acc.y += ww * v.y; acc.z += ww * v.z; acc.w += ww * v.w;
     }
     st4<T>(out + (size_t)r * H + c, acc);
+  }
+}
+
+// table_grad[ids[r]] += d[r]  (fp32 atomics; the reference's embedding backward is an atomic index_add too)
+template <typename T>
+__global__ __launch_bounds__(192) void embedding_grad_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d,
+                                                             float* __restrict__ table_grad, int H) {
+  const int r = blockIdx.x;
+  float* dst = table_grad + (size_t)ids[r] * H;
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+    const float4 v = ld4<T>(d + (size_t)r * H + c);
+    atomicAdd(dst + c, v.x); atomicAdd(dst + c + 1, v.y); atomicAdd(dst + c + 2, v.z); atomicAdd(dst + c + 3, v.w);
   }
 }
 
@@ -337,7 +392,7 @@ static int ln_fwd_dispatch(int NV, dim3 grid, hipStream_t st, const void* x, con
 #define GO(N)                                                                                                        \
   case N:                                                                                                            \
     hipLaunchKernelGGL((ln_fwd_kernel<T, N, GATHER>), grid, dim3(256), 0, st, (const T*)x, bias, (const T*)residual, \
-                       gamma, beta, (T*)y, (T*)z_out, mean, rstd, rows, eps, p, thr, seed, offset, ids,              \
+                       gamma, beta, (T*)y, (T*)z_out, mean, rstd, rows, eps, p, thr, bb_site_key(seed, offset), ids, \
                        (const T*)word, (const T*)pos, (const T*)type_row, L);                                        \
     break;
   switch (NV) {
@@ -405,6 +460,13 @@ static int partial_blocks(int rows, int per_block) {
   return nb < 1 ? 1 : nb;
 }
 
+// row groups of the column kernels: enough blocks to fill the chip, >= 16 rows each, <= 512 partial rows
+static int colwise_blocks(int rows) {
+  int nb = (rows + 15) / 16;
+  if (nb > 512) nb = 512;
+  return nb < 1 ? 1 : nb;
+}
+
 // workspace: >= bevbert_colsum_workspace_floats(3*H) floats
 BEVBERT_API int64_t bevbert_colsum_workspace_floats(int total_cols) { return (int64_t)512 * total_cols; }
 
@@ -418,7 +480,7 @@ BEVBERT_API int bevbert_layernorm_bwd(const void* dy, const void* z, const float
   const uint32_t thr = bb_drop_threshold(drop_p);
 #define GO(T, N)                                                                                              \
   hipLaunchKernelGGL((ln_bwd_kernel<T, N>), dim3(nb), dim3(256), 0, stream, (const T*)dy, (const T*)z, mean, \
-                     rstd, gamma, (T*)dz, (T*)dx, workspace, rows, drop_p, thr, seed, offset)
+                     rstd, gamma, (T*)dz, (T*)dx, workspace, rows, drop_p, thr, bb_site_key(seed, offset))
 #define SW(T)                                                                     \
   switch (H / 256) {                                                              \
     case 1: GO(T, 1); break;                                                      \
@@ -434,10 +496,7 @@ BEVBERT_API int bevbert_layernorm_bwd(const void* dy, const void* z, const float
 #undef SW
 #undef GO
   BB_CHECK_LAUNCH("layernorm_bwd");
-  const dim3 fg((H + 255) / 256);
-  if (dgamma) hipLaunchKernelGGL(colsum_finalize_kernel, fg, dim3(256), 0, stream, workspace, nb, 3, 0, H, dgamma, accumulate);
-  if (dbeta) hipLaunchKernelGGL(colsum_finalize_kernel, fg, dim3(256), 0, stream, workspace, nb, 3, 1, H, dbeta, accumulate);
-  if (dbias) hipLaunchKernelGGL(colsum_finalize_kernel, fg, dim3(256), 0, stream, workspace, nb, 3, 2, H, dbias, accumulate);
+  if (dgamma || dbeta || dbias) launch_finalize(workspace, nb, 3, H, dgamma, dbeta, dbias, accumulate, stream);
   BB_CHECK_LAUNCH("layernorm_bwd finalize");
   return BB_OK;
 }
@@ -466,18 +525,19 @@ BEVBERT_API int bevbert_bias_gelu_bwd(const void* dy, const void* x, const float
                                       hipStream_t stream) {
   BB_REQUIRE(C % 4 == 0, "bias_gelu_bwd: C=%d must be a multiple of 4", C);
   if (rows <= 0) return BB_OK;
-  const int nb = partial_blocks(rows, 8);
+  const int nb = colwise_blocks(rows);
+  const dim3 grid(nb, (C + 1023) / 1024);
   if (dtype == BB_F32)
-    hipLaunchKernelGGL((colwise_bwd_kernel<float, 0>), dim3(nb), dim3(256), 0, stream, (const float*)dy, (const float*)x, bias, (float*)dx, workspace, rows, C);
+    hipLaunchKernelGGL((colwise_bwd_kernel<float, 0>), grid, dim3(256), 0, stream, (const float*)dy, (const float*)x, bias, (float*)dx, workspace, rows, C);
   else if (dtype == BB_BF16)
-    hipLaunchKernelGGL((colwise_bwd_kernel<bf16_raw, 0>), dim3(nb), dim3(256), 0, stream, (const bf16_raw*)dy, (const bf16_raw*)x, bias, (bf16_raw*)dx, workspace, rows, C);
+    hipLaunchKernelGGL((colwise_bwd_kernel<bf16_raw, 0>), grid, dim3(256), 0, stream, (const bf16_raw*)dy, (const bf16_raw*)x, bias, (bf16_raw*)dx, workspace, rows, C);
   else {
     bb_set_error("bias_gelu_bwd: dtype %d unsupported", dtype);
     return BB_EUNSUPPORTED;
   }
   BB_CHECK_LAUNCH("bias_gelu_bwd");
   if (dbias) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, nb, 1, 0, C, dbias, accumulate);
+    launch_finalize(workspace, nb, 1, C, dbias, nullptr, nullptr, accumulate, stream);
     BB_CHECK_LAUNCH("bias_gelu_bwd finalize");
   }
   return BB_OK;
@@ -487,17 +547,18 @@ BEVBERT_API int bevbert_colsum(const void* dy, float* out, float* workspace, int
                                hipStream_t stream) {
   BB_REQUIRE(C % 4 == 0, "colsum: C=%d must be a multiple of 4", C);
   if (rows <= 0) return BB_OK;
-  const int nb = partial_blocks(rows, 8);
+  const int nb = colwise_blocks(rows);
+  const dim3 grid(nb, (C + 1023) / 1024);
   if (dtype == BB_F32)
-    hipLaunchKernelGGL((colwise_bwd_kernel<float, 1>), dim3(nb), dim3(256), 0, stream, (const float*)dy, nullptr, nullptr, nullptr, workspace, rows, C);
+    hipLaunchKernelGGL((colwise_bwd_kernel<float, 1>), grid, dim3(256), 0, stream, (const float*)dy, nullptr, nullptr, nullptr, workspace, rows, C);
   else if (dtype == BB_BF16)
-    hipLaunchKernelGGL((colwise_bwd_kernel<bf16_raw, 1>), dim3(nb), dim3(256), 0, stream, (const bf16_raw*)dy, nullptr, nullptr, nullptr, workspace, rows, C);
+    hipLaunchKernelGGL((colwise_bwd_kernel<bf16_raw, 1>), grid, dim3(256), 0, stream, (const bf16_raw*)dy, nullptr, nullptr, nullptr, workspace, rows, C);
   else {
     bb_set_error("colsum: dtype %d unsupported", dtype);
     return BB_EUNSUPPORTED;
   }
   BB_CHECK_LAUNCH("colsum");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, nb, 1, 0, C, out, accumulate);
+  launch_finalize(workspace, nb, 1, C, out, nullptr, nullptr, accumulate, stream);
   BB_CHECK_LAUNCH("colsum finalize");
   return BB_OK;
 }
@@ -515,6 +576,22 @@ BEVBERT_API int bevbert_segment_wsum(const void* src, const int* rowptr, const i
     return BB_EUNSUPPORTED;
   }
   BB_CHECK_LAUNCH("segment_wsum");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_embedding_grad(const int64_t* ids, const void* d, float* table_grad, int rows, int H,
+                                       int dtype, hipStream_t stream) {
+  BB_REQUIRE(H % 4 == 0, "embedding_grad: H=%d must be a multiple of 4", H);
+  if (rows <= 0) return BB_OK;
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL(embedding_grad_kernel<float>, dim3(rows), dim3(192), 0, stream, ids, (const float*)d, table_grad, H);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL(embedding_grad_kernel<bf16_raw>, dim3(rows), dim3(192), 0, stream, ids, (const bf16_raw*)d, table_grad, H);
+  else {
+    bb_set_error("embedding_grad: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("embedding_grad");
   return BB_OK;
 }
 

@@ -459,9 +459,14 @@ class _EmbedLN(torch.autograd.Function):
             rb = torch.empty(H, dtype=torch.float32, device=dy.device)
             call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz), None,
                  ptr(rg), ptr(rb), None, ptr(ws), rows, H, dtype_code(dy), 0.0, 0, 0, 0, stream())
-        dzf = dz.reshape(rows, H).float()
+        dz2 = dz.reshape(rows, H)
+        dzf = dz2.float()
+
+        def word_grad(t):
+            call("bevbert_embedding_grad", ptr(ids), ptr(dz2), ptr(t), rows, H, dtype_code(dz2), stream())
+
         outs = []
-        for p, make in ((word, lambda t: t.index_add_(0, ids.reshape(-1), dzf)),
+        for p, make in ((word, word_grad),
                         (pos, lambda t: t[:L].add_(dzf.view(B, L, H).sum(0))),
                         (typ, lambda t: t[type_index].add_(dzf.sum(0)))):
             if not p.requires_grad:
