@@ -117,7 +117,9 @@ def main():
     from vln_bevbert_amd import ops, synthetic
     from vln_bevbert_amd.config import BevBertConfig
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
-    from vln_bevbert_amd.train import PretrainTrainer, TaskSampler
+    from vln_bevbert_amd.train import PretrainTrainer, TaskSampler, load_gemm_tuning
+    n_tuned = load_gemm_tuning()
+    log(f"hipBLASLt solution table: {n_tuned} tuned GEMM shapes loaded")
 
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)}; building model")
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -173,7 +175,7 @@ def main():
                                "scripts/pt_r2r.bash shapes: 36 views x 512, 5-step paths, 2352 grid points x 768 -> "
                                f"21x21 BEV, {a.txt_len}-token text, task mix mlm.5.sap.5.masksem.1, dropout 0.1",
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                   "params_M": round(arena.n_params / 1e6, 1)},
+                   "params_M": round(arena.n_params / 1e6, 1), "tuned_gemm_shapes": n_tuned},
         "final_loss": round(float(losses[-1].item()), 4),
     }
 

@@ -31,6 +31,24 @@ def warmup_linear_lr(step, base_lr, warmup_steps, total_steps):
     return lr if lr > 0 else 1e-8
 
 
+def load_gemm_tuning():
+    """Load scripts/tune_gemms.py's hipBLASLt solution table (read-only) if one was shipped; returns #entries or 0."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_results.csv")
+    if os.environ.get("BEVBERT_GEMM_TUNING", "1") != "1" or not os.path.exists(path):
+        return 0
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.record_untuned_enable(False) if hasattr(tunable, "record_untuned_enable") else None
+        tunable.set_filename(path + ".unused")      # never overwrite the shipped table
+        ok = tunable.read_file(path)
+        return len(tunable.get_results()) if ok else 0
+    except Exception:
+        return 0
+
+
 class TaskSampler:
     """MetaLoader's ratio sampling (data/loader.py:18-62) with a generator shared by all ranks."""
 

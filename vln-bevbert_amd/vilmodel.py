@@ -405,13 +405,15 @@ class _GatherRows(torch.autograd.Function):
         if not table.requires_grad:
             return None, None, None
         sink = ops._sink(table)
-        d = dy.reshape(-1, dy.shape[-1]).float()
+        d = dy.reshape(-1, dy.shape[-1])
+        # the tables here have 2..100 rows: a one-hot GEMM (rows x N) @ (N x H) is deterministic and avoids the
+        # atomic pile-up of index_add_ on two or three destination rows (0.3 ms per call at N = 28 224)
+        onehot = F.one_hot(idx.reshape(-1), table.shape[0]).to(d.dtype)
+        g = onehot.t().mm(d)
         if sink is not None:
             ops._mark_touched(table)
-            sink.index_add_(0, idx.reshape(-1), d)
+            sink.add_(g)
             return None, None, None
-        g = torch.zeros(table.shape, dtype=torch.float32, device=dy.device)
-        g.index_add_(0, idx.reshape(-1), d)
         return None, g.to(table.dtype), None
 
 
