@@ -29,8 +29,8 @@ def main():
     t0 = time.time()
     tunable.enable(True)
     tunable.tuning_enable(True)
-    tunable.set_max_tuning_duration(15)          # ms per candidate
-    tunable.set_max_tuning_iterations(5)
+    tunable.set_max_tuning_duration(30)          # ms per candidate
+    tunable.set_max_tuning_iterations(10)
     tunable.set_filename(OUT)
     dev = torch.device("cuda:0")
     cfg = BevBertConfig()
@@ -44,13 +44,11 @@ def main():
         b = synthetic.batch_to(synthetic.make_batch(cfg, task, 64, seed=1000, sems_as="ids"), dev)
         trainer.step(task, b)
         torch.cuda.synchronize()
-        tunable.write_file(OUT)
-        n = sum(1 for _ in open(OUT)) if os.path.exists(OUT) else 0
-        print(f"[tune +{time.time() - t0:6.1f}s] {task}: {n} lines in {OUT}", flush=True)
+        print(f"[tune +{time.time() - t0:6.1f}s] {task}: {len(tunable.get_results())} tuned shapes", flush=True)
         if time.time() - t0 > budget_s:
             print("budget exhausted", flush=True)
             break
-    tunable.write_file(OUT)
+    # the table is flushed to OUT when the process exits (write_file_on_exit)
 
 
 if __name__ == "__main__":
