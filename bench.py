@@ -57,7 +57,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=22)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=11)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE.json configs[1]: 64)")
     ap.add_argument("--txt-len", type=int, default=80)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -94,7 +94,7 @@ def algorithmic_work(key, args, esize):
         out_size = {0: 4, 1: 2, 2: 2}[args[5]]
         return 0.0, B * (P * C * in_size + P * 4 + K * C * out_size + P * 1 + K * 41)
     if key == "bevbert_adamw_step":
-        return 0.0, args[6] * (16 + 12 + 2)
+        return 0.0, args[7] * (16 + 12 + 2)
     if key == "bevbert_grad_norm_clip":
         return 0.0, args[1] * 4
     return 0.0, 0.0
@@ -131,7 +131,10 @@ def main():
     model.train()
     model.set_dropout(0.1)                                  # train_r2r.py:157
     trainer = PretrainTrainer(model, arena, rank=rank, world_size=world)
-    sampler = TaskSampler("mlm.5.sap.5.masksem.1", seed=0)
+    # the reference draws the task of each step at random with ratio 5:5:1 (MetaLoader); the bench walks that mix as
+    # a fixed 11-step cycle so that every run (and every K that is a multiple of 11) times exactly the same work
+    cycle = ["mlm", "sap", "mlm", "sap", "mlm", "sap", "masksem", "mlm", "sap", "mlm", "sap"]
+    counter = [0]
 
     log(f"model in arena: {arena.n_params / 1e6:.1f} M params; generating resident batches")
     # resident synthetic batches: two per task and rank, drawn with seed 1000 + rank
@@ -147,9 +150,11 @@ def main():
 
     def run(n):
         losses = []
-        for i in range(n):
-            t = sampler.next()
-            losses.append(trainer.step(t, batches[t][i % 2]))
+        for _ in range(n):
+            i = counter[0]
+            counter[0] += 1
+            t = cycle[i % len(cycle)]
+            losses.append(trainer.step(t, batches[t][(i // len(cycle)) % 2]))
         return losses
 
     log("batches resident; warm-up")
@@ -173,7 +178,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "R2R pre-train step (lift+splat, fwd, bwd, all-reduce, clip, AdamW), "
                                "scripts/pt_r2r.bash shapes: 36 views x 512, 5-step paths, 2352 grid points x 768 -> "
-                               f"21x21 BEV, {a.txt_len}-token text, task mix mlm.5.sap.5.masksem.1, dropout 0.1",
+                               f"21x21 BEV, {a.txt_len}-token text, task mix mlm.5.sap.5.masksem.1 (fixed 11-step cycle), dropout 0.1",
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "params_M": round(arena.n_params / 1e6, 1), "tuned_gemm_shapes": n_tuned},
         "final_loss": round(float(losses[-1].item()), 4),

@@ -128,12 +128,14 @@ int bevbert_segment_wsum(const void* src, const int* rowptr, const int* idx, con
  *   (torch.nn.utils.clip_grad_norm_ as called at pretrain_src/train_r2r.py:295-306; pre_scale folds DDP's 1/world).
  *   partials: 1024 floats scratch.  No host sync: adamw_step reads the multiplier from device memory.
  * bevbert_adamw_step: AdamW.step (pretrain_src/optim/adamw.py:53-112): bias-corrected Adam, decoupled decay applied
- *   after the update; optionally refreshes the bf16 shadow copy of the parameters in the same pass. */
+ *   after the update; optionally refreshes the bf16 shadow copy of the parameters in the same pass.  chunk_steps
+ *   (int32 per 1024-element chunk, zero-initialised by the caller) is the reference's per-parameter state["step"]:
+ *   it advances only for chunks whose flag bit1 is set, so a parameter first used at step 6 starts at t = 1. */
 int bevbert_grad_norm_clip(const float* grads, int64_t n, float pre_scale, float max_norm, float* partials,
                            float* scalars, hipStream_t stream);
 int bevbert_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* params_bf16,
-                       const uint8_t* chunk_flags, int64_t n, const float* grad_scale_dev, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, int64_t step, hipStream_t stream);
+                       const uint8_t* chunk_flags, int* chunk_steps, int64_t n, const float* grad_scale_dev, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, hipStream_t stream);
 int bevbert_cast_f32(const float* src, void* dst, int64_t n, int dst_dtype, hipStream_t stream);
 
 /* test hook: keep-mask (uint8) the kernels derive for n consecutive elements starting at `offset` */

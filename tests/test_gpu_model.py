@@ -98,6 +98,9 @@ def _check_tasks(env, cfg, tag, keys_file, dtype, check_grads=False):
                     else:   # bf16: relative L2 error of the sampled gradient entries
                         # (small gradients that are sums of cancelling bf16-rounded paths, e.g. the word embeddings
                         # behind the whole text encoder, sit at ~0.1; fp32 mode pins the same tensors to 2e-3)
+                        if float(np.abs(ref).max()) < 1e-6:     # analytically-zero gradient (softmax shift invariance)
+                            assert float(np.abs(got).max()) < 5e-2, (gk, got)
+                            continue
                         l2 = float(np.linalg.norm(got - ref) / max(1e-12, np.linalg.norm(ref)))
                         assert l2 < 0.2, (gk, l2)
             # parameters the task does not use keep an exactly-zero gradient (find_unused_parameters semantics)

@@ -85,6 +85,7 @@ class ParamArena:
             for n in seg:
                 self._seg_of[n] = (start // CHUNK, end // CHUNK)
         self.flags = self._flags_host.to(dev)
+        self.chunk_steps = torch.zeros(off // CHUNK, dtype=torch.int32, device=dev)   # per-parameter state["step"]
         self._touched = set()
         self._flags_dirty = False
         self.step_count = 0
@@ -151,8 +152,8 @@ class ParamArena:
         call("bevbert_grad_norm_clip", ptr(self.grads), self.numel, float(grad_pre_scale),
              float(max_norm if max_norm is not None else -1.0), ptr(self._partials), ptr(self._scalars), stream())
         call("bevbert_adamw_step", ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-             ptr(self.shadow), ptr(self.flags), self.numel, self._scalars[1:].data_ptr(), float(lr), float(betas[0]),
-             float(betas[1]), float(eps), float(weight_decay), self.step_count, stream())
+             ptr(self.shadow), ptr(self.flags), ptr(self.chunk_steps), self.numel, self._scalars[1:].data_ptr(),
+             float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), stream())
 
     def grad_norm(self):
         """L2 norm computed by the last clip_and_step (device scalar; reading it syncs)."""

@@ -26,6 +26,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TK 64   // keys (or queries, in dKV) per LDS tile
 #define LDT 72  // LDS row stride in bf16 elements
 
+#define DKV_TILE_BYTES (2 * 4 * TK * LDT * 2)                 // dK/dV kernel: two buffers of four bf16 tiles
+#define DKV_SMEM_BYTES (DKV_TILE_BYTES + 2 * 2 * TK * 4)     // + lse / delta rows
+
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
@@ -110,9 +113,10 @@ __device__ __forceinline__ float quad_sum(float v) {
 // =============================================================================================
 template <int QT>
 __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_raw s_k[TK * LDT];
-  __shared__ __attribute__((aligned(16))) bf16_raw s_vt[ATTN_D * LDT];
-  __shared__ __attribute__((aligned(16))) float s_mask[TK];
+  // double-buffered tiles: while tile j is consumed from buffer j&1, tile j+1 is written to the other one
+  __shared__ __attribute__((aligned(16))) bf16_raw s_k[2][TK * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_vt[2][ATTN_D * LDT];
+  __shared__ __attribute__((aligned(16))) float s_mask[2][TK];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   const int qbase = blockIdx.x * (64 * QT) + w * (16 * QT);
@@ -141,24 +145,30 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
     for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
+  // additive key mask of a tile (log2 domain), one key per thread of the first wave; -inf beyond Lk
+  auto mask_of = [&](int kv0) -> float {
+    const int key = kv0 + tid;
+    if (tid >= TK || key >= a.Lk) return -INFINITY;
+    return a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * LOG2E : 0.f;
+  };
   TileRegs kreg, vreg;
+  float mreg;
   tile_load(kreg, kp, a.ldk, 0, a.Lk, tid);
   tile_load(vreg, vp, a.ldv, 0, a.Lk, tid);
-  for (int kv0 = 0; kv0 < a.Lk; kv0 += TK) {
-    __syncthreads();  // previous tile fully consumed
-    tile_store_rows(s_k, kreg, tid);
-    tile_store_cols(s_vt, vreg, tid);
-    if (tid < TK) {
-      const int key = kv0 + tid;
-      float mv = -INFINITY;
-      if (key < a.Lk) mv = a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * LOG2E : 0.f;
-      s_mask[tid] = mv;
-    }
-    __syncthreads();
-    if (kv0 + TK < a.Lk) {  // next tile's global loads fly while this tile is computed
-      tile_load(kreg, kp, a.ldk, kv0 + TK, a.Lk, tid);
-      tile_load(vreg, vp, a.ldv, kv0 + TK, a.Lk, tid);
-    }
+  mreg = mask_of(0);
+  tile_store_rows(s_k[0], kreg, tid);
+  tile_store_cols(s_vt[0], vreg, tid);
+  if (tid < TK) s_mask[0][tid] = mreg;
+  if (TK < a.Lk) {
+    tile_load(kreg, kp, a.ldk, TK, a.Lk, tid);
+    tile_load(vreg, vp, a.ldv, TK, a.Lk, tid);
+    mreg = mask_of(TK);
+  }
+  __syncthreads();
+  for (int kv0 = 0, cur = 0; kv0 < a.Lk; kv0 += TK, cur ^= 1) {
+    const bf16_raw* ck = s_k[cur];
+    const bf16_raw* cvt = s_vt[cur];
+    const float* cmask = s_mask[cur];
 
     // ---- S^T = K Q^T
     f32x4 sacc[QT][4];
@@ -168,9 +178,21 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
       for (int qt = 0; qt < QT; ++qt) sacc[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 kf = lds_frag_rows(s_k, t, ks, lane);
+        const bf16x8 kf = lds_frag_rows(ck, t, ks, lane);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) sacc[qt][t] = mfma16(kf, qf[qt][ks], sacc[qt][t]);
+      }
+    }
+    // ---- stage tile j+1 into the other buffer (its last readers passed the barrier that closed iteration j-1);
+    //      the LDS writes overlap the softmax arithmetic below; then start the global loads of tile j+2
+    if (kv0 + TK < a.Lk) {
+      tile_store_rows(s_k[cur ^ 1], kreg, tid);
+      tile_store_cols(s_vt[cur ^ 1], vreg, tid);
+      if (tid < TK) s_mask[cur ^ 1][tid] = mreg;
+      if (kv0 + 2 * TK < a.Lk) {
+        tile_load(kreg, kp, a.ldk, kv0 + 2 * TK, a.Lk, tid);
+        tile_load(vreg, vp, a.ldv, kv0 + 2 * TK, a.Lk, tid);
+        mreg = mask_of(kv0 + 2 * TK);
       }
     }
     // ---- online softmax (log2 domain), per owned query
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
       float mx = -INFINITY;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float4 mk = *reinterpret_cast<const float4*>(&s_mask[t * 16 + g * 4]);
+        const float4 mk = *reinterpret_cast<const float4*>(&cmask[t * 16 + g * 4]);
         const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -233,10 +255,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const bf16x8 vf = lds_frag_cols(s_vt, dt, m, lane);
+        const bf16x8 vf = lds_frag_cols(cvt, dt, m, lane);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = mfma16(vf, pb[qt][m], oacc[qt][dt]);
       }
+    __syncthreads();  // one barrier per tile: buffer `cur` is free again, buffer `cur^1` is complete
   }
 
   // ---- epilogue: normalise, store O[q][h*64 + dt*16 + g*4 .. +3] and the log-sum-exp
@@ -264,10 +287,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
 // =============================================================================================
 template <int QT>
 __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_raw s_k[TK * LDT];
-  __shared__ __attribute__((aligned(16))) bf16_raw s_v[TK * LDT];
-  __shared__ __attribute__((aligned(16))) bf16_raw s_kt[ATTN_D * LDT];
-  __shared__ __attribute__((aligned(16))) float s_mask[TK];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_k[2][TK * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_v[2][TK * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_kt[2][ATTN_D * LDT];
+  __shared__ __attribute__((aligned(16))) float s_mask[2][TK];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   const int qbase = blockIdx.x * (64 * QT) + w * (16 * QT);
@@ -310,25 +333,32 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dqacc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  auto mask_of = [&](int kv0) -> float {
+    const int key = kv0 + tid;
+    if (tid >= TK || key >= a.Lk) return -INFINITY;
+    return a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * LOG2E : 0.f;
+  };
   TileRegs kreg, vreg;
+  float mreg;
   tile_load(kreg, kp, a.ldk, 0, a.Lk, tid);
   tile_load(vreg, vp, a.ldv, 0, a.Lk, tid);
-  for (int kv0 = 0; kv0 < a.Lk; kv0 += TK) {
-    __syncthreads();
-    tile_store_rows(s_k, kreg, tid);
-    tile_store_cols(s_kt, kreg, tid);
-    tile_store_rows(s_v, vreg, tid);
-    if (tid < TK) {
-      const int key = kv0 + tid;
-      float mv = -INFINITY;
-      if (key < a.Lk) mv = a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * LOG2E : 0.f;
-      s_mask[tid] = mv;
-    }
-    __syncthreads();
-    if (kv0 + TK < a.Lk) {
-      tile_load(kreg, kp, a.ldk, kv0 + TK, a.Lk, tid);
-      tile_load(vreg, vp, a.ldv, kv0 + TK, a.Lk, tid);
-    }
+  mreg = mask_of(0);
+  tile_store_rows(s_k[0], kreg, tid);
+  tile_store_cols(s_kt[0], kreg, tid);
+  tile_store_rows(s_v[0], vreg, tid);
+  if (tid < TK) s_mask[0][tid] = mreg;
+  if (TK < a.Lk) {
+    tile_load(kreg, kp, a.ldk, TK, a.Lk, tid);
+    tile_load(vreg, vp, a.ldv, TK, a.Lk, tid);
+    mreg = mask_of(TK);
+  }
+  __syncthreads();
+  for (int kv0 = 0, cur = 0; kv0 < a.Lk; kv0 += TK, cur ^= 1) {
+    const bf16_raw* ck = s_k[cur];
+    const bf16_raw* cv = s_v[cur];
+    const bf16_raw* ckt = s_kt[cur];
+    const float* cmask = s_mask[cur];
+    bool staged = false;
 
     // two halves of 32 keys: scores + dP for key tiles (2m, 2m+1), then their contribution to dQ^T
 #pragma unroll
@@ -344,8 +374,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 kf = lds_frag_rows(s_k, t, ks, lane);
-          const bf16x8 vf = lds_frag_rows(s_v, t, ks, lane);
+          const bf16x8 kf = lds_frag_rows(ck, t, ks, lane);
+          const bf16x8 vf = lds_frag_rows(cv, t, ks, lane);
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) {
             sacc[qt][tt] = mfma16(kf, qf[qt][ks], sacc[qt][tt]);
@@ -353,6 +383,18 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
           }
         }
       }
+      if (!staged && kv0 + TK < a.Lk) {   // next tile -> other buffer, overlapping the VALU work below
+        tile_store_rows(s_k[cur ^ 1], kreg, tid);
+        tile_store_cols(s_kt[cur ^ 1], kreg, tid);
+        tile_store_rows(s_v[cur ^ 1], vreg, tid);
+        if (tid < TK) s_mask[cur ^ 1][tid] = mreg;
+        if (kv0 + 2 * TK < a.Lk) {
+          tile_load(kreg, kp, a.ldk, kv0 + 2 * TK, a.Lk, tid);
+          tile_load(vreg, vp, a.ldv, kv0 + 2 * TK, a.Lk, tid);
+          mreg = mask_of(kv0 + 2 * TK);
+        }
+      }
+      staged = true;
       bf16x8 dsb[QT];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
@@ -360,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * m + tt;
-          const float4 mk = *reinterpret_cast<const float4*>(&s_mask[t * 16 + g * 4]);
+          const float4 mk = *reinterpret_cast<const float4*>(&cmask[t * 16 + g * 4]);
           const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
           bool keep[4] = {true, true, true, true};
           if (a.drop_p > 0.f) {
@@ -386,11 +428,12 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 kt = lds_frag_cols(s_kt, dt, m, lane);
+        const bf16x8 kt = lds_frag_cols(ckt, dt, m, lane);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) dqacc[qt][dt] = mfma16(kt, dsb[qt], dqacc[qt][dt]);
       }
     }
+    __syncthreads();
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt)
@@ -411,12 +454,15 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
 // =============================================================================================
 template <int KT>
 __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_raw s_q[TK * LDT];
-  __shared__ __attribute__((aligned(16))) bf16_raw s_do[TK * LDT];
-  __shared__ __attribute__((aligned(16))) bf16_raw s_qt[ATTN_D * LDT];
-  __shared__ __attribute__((aligned(16))) bf16_raw s_dot[ATTN_D * LDT];
-  __shared__ __attribute__((aligned(16))) float s_lse2[TK];
-  __shared__ __attribute__((aligned(16))) float s_dlt[TK];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dkv_smem[];
+  bf16_raw* const tiles = reinterpret_cast<bf16_raw*>(dkv_smem);            // [2 buffers][4 tiles][TK * LDT]
+  float* const stats = reinterpret_cast<float*>(dkv_smem + DKV_TILE_BYTES);   // [2 buffers][2][TK]
+  auto s_q = [&](int bf) { return tiles + (bf * 4 + 0) * (TK * LDT); };
+  auto s_do = [&](int bf) { return tiles + (bf * 4 + 1) * (TK * LDT); };
+  auto s_qt = [&](int bf) { return tiles + (bf * 4 + 2) * (TK * LDT); };
+  auto s_dot = [&](int bf) { return tiles + (bf * 4 + 3) * (TK * LDT); };
+  auto s_lse2 = [&](int bf) { return stats + (bf * 2 + 0) * TK; };
+  auto s_dlt = [&](int bf) { return stats + (bf * 2 + 1) * TK; };
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z;
   const int kbase = blockIdx.x * (64 * KT) + w * (16 * KT);
@@ -450,26 +496,38 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(Att
       dvacc[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
+  // per-query statistics of a tile, one query per thread of the first wave: lse (log2 domain; +inf for padding
+  // rows so that their probabilities vanish) and delta
+  auto stats_of = [&](int q0, float& l2, float& dl) {
+    const int qi = q0 + tid;
+    l2 = INFINITY;
+    dl = 0.f;
+    if (tid < TK && qi < a.Lq) {
+      const size_t ridx = ((size_t)b * a.nh + h) * a.Lq + qi;
+      l2 = a.lse[ridx] * LOG2E;
+      dl = a.delta[ridx];
+    }
+  };
   TileRegs qreg, doreg;
+  float lreg, dreg;
   tile_load(qreg, qp, a.ldq, 0, a.Lq, tid);
   tile_load(doreg, dop, a.ldo, 0, a.Lq, tid);
-  for (int q0 = 0; q0 < a.Lq; q0 += TK) {
-    __syncthreads();
-    tile_store_rows(s_q, qreg, tid);
-    tile_store_cols(s_qt, qreg, tid);
-    tile_store_rows(s_do, doreg, tid);
-    tile_store_cols(s_dot, doreg, tid);
-    if (tid < TK) {
-      const int qi = q0 + tid;
-      const size_t ridx = ((size_t)b * a.nh + h) * a.Lq + (qi < a.Lq ? qi : a.Lq - 1);
-      s_lse2[tid] = qi < a.Lq ? a.lse[ridx] * LOG2E : INFINITY;  // +inf -> p = 0 for padding rows
-      s_dlt[tid] = a.delta[ridx];
-    }
-    __syncthreads();
-    if (q0 + TK < a.Lq) {
-      tile_load(qreg, qp, a.ldq, q0 + TK, a.Lq, tid);
-      tile_load(doreg, dop, a.ldo, q0 + TK, a.Lq, tid);
-    }
+  stats_of(0, lreg, dreg);
+  tile_store_rows(s_q(0), qreg, tid);
+  tile_store_cols(s_qt(0), qreg, tid);
+  tile_store_rows(s_do(0), doreg, tid);
+  tile_store_cols(s_dot(0), doreg, tid);
+  if (tid < TK) { s_lse2(0)[tid] = lreg; s_dlt(0)[tid] = dreg; }
+  if (TK < a.Lq) {
+    tile_load(qreg, qp, a.ldq, TK, a.Lq, tid);
+    tile_load(doreg, dop, a.ldo, TK, a.Lq, tid);
+    stats_of(TK, lreg, dreg);
+  }
+  __syncthreads();
+  for (int q0 = 0, cur = 0; q0 < a.Lq; q0 += TK, cur ^= 1) {
+    const bf16_raw *cq = s_q(cur), *cdo = s_do(cur), *cqt = s_qt(cur), *cdot = s_dot(cur);
+    const float *clse = s_lse2(cur), *cdlt = s_dlt(cur);
+    bool staged = false;
 
     // two halves of 32 queries: S and dP for query tiles (2m, 2m+1), then their contribution to dK^T / dV^T
 #pragma unroll
@@ -485,8 +543,8 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(Att
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 qa = lds_frag_rows(s_q, t, ks, lane);
-          const bf16x8 da = lds_frag_rows(s_do, t, ks, lane);
+          const bf16x8 qa = lds_frag_rows(cq, t, ks, lane);
+          const bf16x8 da = lds_frag_rows(cdo, t, ks, lane);
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) {
             sacc[kt][tt] = mfma16(qa, kf[kt][ks], sacc[kt][tt]);
@@ -494,12 +552,25 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(Att
           }
         }
       }
+      if (!staged && q0 + TK < a.Lq) {   // next query tile -> other buffer, overlapping the VALU work below
+        tile_store_rows(s_q(cur ^ 1), qreg, tid);
+        tile_store_cols(s_qt(cur ^ 1), qreg, tid);
+        tile_store_rows(s_do(cur ^ 1), doreg, tid);
+        tile_store_cols(s_dot(cur ^ 1), doreg, tid);
+        if (tid < TK) { s_lse2(cur ^ 1)[tid] = lreg; s_dlt(cur ^ 1)[tid] = dreg; }
+        if (q0 + 2 * TK < a.Lq) {
+          tile_load(qreg, qp, a.ldq, q0 + 2 * TK, a.Lq, tid);
+          tile_load(doreg, dop, a.ldo, q0 + 2 * TK, a.Lq, tid);
+          stats_of(q0 + 2 * TK, lreg, dreg);
+        }
+      }
+      staged = true;
       // sacc -> dS, dpacc -> dropped P
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * m + tt;
-        const float4 l4 = *reinterpret_cast<const float4*>(&s_lse2[t * 16 + g * 4]);
-        const float4 d4 = *reinterpret_cast<const float4*>(&s_dlt[t * 16 + g * 4]);
+        const float4 l4 = *reinterpret_cast<const float4*>(&clse[t * 16 + g * 4]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&cdlt[t * 16 + g * 4]);
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -528,8 +599,8 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(Att
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 qt_ = lds_frag_cols(s_qt, dt, m, lane);
-        const bf16x8 dot_ = lds_frag_cols(s_dot, dt, m, lane);
+        const bf16x8 qt_ = lds_frag_cols(cqt, dt, m, lane);
+        const bf16x8 dot_ = lds_frag_cols(cdot, dt, m, lane);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           dkacc[kt][dt] = mfma16(qt_, dsb[kt], dkacc[kt][dt]);
@@ -537,6 +608,7 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(Att
         }
       }
     }
+    __syncthreads();
   }
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
@@ -590,10 +662,18 @@ int attn_mfma_bwd(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(attn_mfma_dq_kernel<2>, dim3((a.Lq + 127) / 128, a.nh, a.B), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(attn_mfma_dq_kernel<1>, dim3((a.Lq + 63) / 64, a.nh, a.B), dim3(256), 0, st, a);
+  static const bool attr_ok = [] {   // 73.7 KB of dynamic LDS exceeds the default 64 KB cap: opt in once
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_dkv_kernel<1>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_BYTES);
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_dkv_kernel<2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_BYTES);
+    return e1 == hipSuccess && e2 == hipSuccess;
+  }();
+  BB_REQUIRE(attr_ok, "attention bwd: cannot raise the dynamic LDS limit to %d bytes", DKV_SMEM_BYTES);
   if (a.Lk > 64 && dkv_kt == 2)
-    hipLaunchKernelGGL(attn_mfma_dkv_kernel<2>, dim3((a.Lk + 127) / 128, a.nh, a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_mfma_dkv_kernel<2>, dim3((a.Lk + 127) / 128, a.nh, a.B), dim3(256), DKV_SMEM_BYTES, st, a);
   else
-    hipLaunchKernelGGL(attn_mfma_dkv_kernel<1>, dim3((a.Lk + 63) / 64, a.nh, a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_mfma_dkv_kernel<1>, dim3((a.Lk + 63) / 64, a.nh, a.B), dim3(256), DKV_SMEM_BYTES, st, a);
   BB_CHECK_LAUNCH("attn_bwd(mfma)");
   return BB_OK;
 }

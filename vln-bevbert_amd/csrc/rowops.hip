@@ -342,15 +342,23 @@ __global__ void clip_coef_kernel(const float* __restrict__ partials, int n, floa
   }
 }
 
+// One block per 1024-element chunk.  The bias-correction step count is PER CHUNK (the reference keeps state["step"]
+// per parameter and only advances it when the parameter has a gradient: adamw.py:66-67,84,96-100).
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16_raw* __restrict__ p_bf16, const uint8_t* __restrict__ flags,
-                                                    size_t nchunks, const float* __restrict__ gscale_ptr, float lr,
-                                                    float beta1, float beta2, float eps, float wd, float step_size) {
+                                                    int* __restrict__ chunk_steps, size_t nchunks,
+                                                    const float* __restrict__ gscale_ptr, float lr, float beta1,
+                                                    float beta2, float eps, float wd) {
   const size_t chunk = blockIdx.x;
   if (chunk >= nchunks) return;
   const uint8_t f = flags[chunk];
   if (!(f & 2)) return;
+  const int t = chunk_steps[chunk] + 1;          // every thread reads the old value before thread 0 bumps it
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_steps[chunk] = t;
+  const float bc1 = 1.0f - powf(beta1, (float)t), bc2 = 1.0f - powf(beta2, (float)t);
+  const float step_size = lr * sqrtf(bc2) / bc1;
   const float gs = gscale_ptr ? *gscale_ptr : 1.0f;
   const float decay = (f & 1) ? lr * wd : 0.f;
   const size_t i = chunk * 1024 + threadIdx.x * 4;
@@ -606,17 +614,15 @@ BEVBERT_API int bevbert_grad_norm_clip(const float* grads, int64_t n, float pre_
 }
 
 BEVBERT_API int bevbert_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                                   void* params_bf16, const uint8_t* chunk_flags, int64_t n,
+                                   void* params_bf16, const uint8_t* chunk_flags, int* chunk_steps, int64_t n,
                                    const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
-                                   float weight_decay, int64_t step, hipStream_t stream) {
+                                   float weight_decay, hipStream_t stream) {
   BB_REQUIRE(n % 1024 == 0, "adamw_step: arena length must be a multiple of 1024 elements");
-  BB_REQUIRE(step >= 1, "adamw_step: step is the 1-based update count");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr * sqrt(bc2) / bc1);  // adamw.py:96-100
+  BB_REQUIRE(chunk_steps != nullptr, "adamw_step: per-chunk step counters are required");
   const size_t nchunks = (size_t)n / 1024;
   hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq,
-                     (bf16_raw*)params_bf16, chunk_flags, nchunks, grad_scale_dev, lr, beta1, beta2, eps, weight_decay,
-                     step_size);
+                     (bf16_raw*)params_bf16, chunk_flags, chunk_steps, nchunks, grad_scale_dev, lr, beta1, beta2, eps,
+                     weight_decay);
   BB_CHECK_LAUNCH("adamw_step");
   return BB_OK;
 }
