@@ -111,7 +111,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 // =============================================================================================
 // Forward.  Workgroup = 4 waves; wave w owns QT query tiles of 16 rows: rows q0 + (w*QT + qt)*16 + (l&15).
 // =============================================================================================
-template <int QT>
+template <int QT, bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
   // double-buffered tiles: while tile j is consumed from buffer j&1, tile j+1 is written to the other one
   __shared__ __attribute__((aligned(16))) bf16_raw s_k[2][TK * LDT];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
   const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
   const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
   const float sc2 = a.scale * LOG2E;
-  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const float keep_scale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
 
   bf16x8 qf[QT][2];
   int qrow[QT];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float s = sacc[qt][t][r] * sc2 + mkv[r];
-          if (a.bias) {
+          if (BIAS) {
             const int key = kv0 + t * 16 + g * 4 + r;
             if (key < a.Lk && qrow[qt] < a.Lq) s += a.bias[((size_t)b * a.Lq + qrow[qt]) * a.Lk + key] * LOG2E;
           }
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
           p[r] = fast_exp2(sacc[qt][t][r] - m_use);
           psum += p[r];
         }
-        if (a.drop_p > 0.f) {   // keys kv0+16t+4g .. +3: two index pairs, one hash each
+        if (DROP) {   // keys kv0+16t+4g .. +3: two index pairs, one hash each
           const uint32_t pr = (rbase + (uint32_t)(kv0 + t * 16 + g * 4)) >> 1;
           const uint32_t b0 = bb_pair_bits(a.drop_key, pr), b1 = bb_pair_bits(a.drop_key, pr + 1);
           p[0] = bb_keep_lo(b0, a.drop_thr) ? p[0] * keep_scale : 0.f;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
 // Backward, part 1: dQ (and dbias).  Same ownership as the forward; per key tile
 //   S^T, P = exp2(S2 - lse2);  dP^T = V dO^T;  dS = P * (drop(dP) - delta);  dQ^T += K^T dS^T
 // =============================================================================================
-template <int QT>
+template <int QT, bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_raw s_k[2][TK * LDT];
   __shared__ __attribute__((aligned(16))) bf16_raw s_v[2][TK * LDT];
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
   const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
   const bf16_raw* dop = (const bf16_raw*)a.dout + (size_t)b * a.bso + h * ATTN_D;
   const float sc2 = a.scale * LOG2E;
-  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const float keep_scale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
 
   const bf16_raw* op = (const bf16_raw*)a.o + (size_t)b * a.bso + h * ATTN_D;
   bf16x8 qf[QT][2], dof[QT][2];
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
           const float4 mk = *reinterpret_cast<const float4*>(&cmask[t * 16 + g * 4]);
           const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
           bool keep[4] = {true, true, true, true};
-          if (a.drop_p > 0.f) {
+          if (DROP) {
             const uint32_t pr = (rbase + (uint32_t)(kv0 + t * 16 + g * 4)) >> 1;
             const uint32_t b0 = bb_pair_bits(a.drop_key, pr), b1 = bb_pair_bits(a.drop_key, pr + 1);
             keep[0] = bb_keep_lo(b0, a.drop_thr); keep[1] = bb_keep_hi(b0, a.drop_thr);
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
             const int key = kv0 + t * 16 + g * 4 + r;
             const bool valid = key < a.Lk && qrow[qt] < a.Lq;
             float sv = sacc[qt][tt][r] * sc2 + mkv[r];
-            if (a.bias && valid) sv += a.bias[((size_t)b * a.Lq + qrow[qt]) * a.Lk + key] * LOG2E;
+            if (BIAS && valid) sv += a.bias[((size_t)b * a.Lq + qrow[qt]) * a.Lk + key] * LOG2E;
             const float p = fast_exp2(sv - lse2[qt]);
             const float dp = keep[r] ? dpacc[qt][tt][r] * keep_scale : 0.f;
             const float ds = valid ? p * (dp - dlt[qt]) : 0.f;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
 //   S = Q K^T (A = Q tile rows, B = K fragments in registers) -> lane (key = l&15) holds S[q = 16 t + 4 g + r][key]
 //   dV^T += dO^T Pd ;  dK^T += Q^T dS      (A = transposed dO / Q tiles, B = packed Pd / dS, k-slots <-> queries)
 // =============================================================================================
-template <int KT>
+template <int KT, bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dkv_smem[];
   bf16_raw* const tiles = reinterpret_cast<bf16_raw*>(dkv_smem);            // [2 buffers][4 tiles][TK * LDT]
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(Att
   const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
   const bf16_raw* dop = (const bf16_raw*)a.dout + (size_t)b * a.bso + h * ATTN_D;
   const float sc2 = a.scale * LOG2E;
-  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const float keep_scale = DROP ? 1.0f / (1.0f - a.drop_p) : 1.0f;
 
   bf16x8 kf[KT][2], vf[KT][2];
   int krow[KT];
@@ -578,11 +578,11 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(Att
           for (int r = 0; r < 4; ++r) {
             const int qi = q0 + t * 16 + g * 4 + r;
             float sv = sacc[kt][tt][r] * sc2 + mask2[kt];
-            if (a.bias && qi < a.Lq && krow[kt] < a.Lk)
+            if (BIAS && qi < a.Lq && krow[kt] < a.Lk)
               sv += a.bias[((size_t)b * a.Lq + qi) * a.Lk + krow[kt]] * LOG2E;
             const float p = fast_exp2(sv - lv[r]);
             float dp = dpacc[kt][tt][r], pd = p;
-            if (a.drop_p > 0.f) {
+            if (DROP) {
               const bool keep = bb_keep(a.drop_key, attn_elem(a, b, h, qi, krow[kt]), a.drop_thr);
               dp = keep ? dp * keep_scale : 0.f;
               pd = keep ? p * keep_scale : 0.f;
@@ -641,16 +641,31 @@ static int env_knob(const char* name, int dflt) {
   return (v && (v[0] == '1' || v[0] == '2')) ? v[0] - '0' : dflt;
 }
 
+// compile-time specialisation on (graph bias present, dropout active): the common launches carry neither
+#define BB_DISPATCH_FLAGS(KERNEL, N, GRID, SMEM)                                                         \
+  do {                                                                                                  \
+    const bool hb = a.bias != nullptr, hd = a.drop_p > 0.f;                                             \
+    if (hb && hd) hipLaunchKernelGGL((KERNEL<N, true, true>), GRID, dim3(256), SMEM, st, a);            \
+    else if (hb) hipLaunchKernelGGL((KERNEL<N, true, false>), GRID, dim3(256), SMEM, st, a);            \
+    else if (hd) hipLaunchKernelGGL((KERNEL<N, false, true>), GRID, dim3(256), SMEM, st, a);            \
+    else hipLaunchKernelGGL((KERNEL<N, false, false>), GRID, dim3(256), SMEM, st, a);                   \
+  } while (0)
+
 int attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
   static const int fwd_qt = env_knob("BEVBERT_FWD_QT", 2);
   BB_REQUIRE(aligned8(a), "attention (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
-  if (a.Lq > 64 && fwd_qt == 2) {
-    hipLaunchKernelGGL(attn_mfma_fwd_kernel<2>, dim3((a.Lq + 127) / 128, a.nh, a.B), dim3(256), 0, st, a);
-  } else {
-    hipLaunchKernelGGL(attn_mfma_fwd_kernel<1>, dim3((a.Lq + 63) / 64, a.nh, a.B), dim3(256), 0, st, a);
-  }
+  if (a.Lq > 64 && fwd_qt == 2)
+    BB_DISPATCH_FLAGS(attn_mfma_fwd_kernel, 2, dim3((a.Lq + 127) / 128, a.nh, a.B), 0);
+  else
+    BB_DISPATCH_FLAGS(attn_mfma_fwd_kernel, 1, dim3((a.Lq + 63) / 64, a.nh, a.B), 0);
   BB_CHECK_LAUNCH("attn_fwd(mfma)");
   return BB_OK;
+}
+
+template <int KT, bool B_, bool D_>
+static bool raise_lds_limit() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_dkv_kernel<KT, B_, D_>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_BYTES) == hipSuccess;
 }
 
 int attn_mfma_bwd(const AttnArgs& a, hipStream_t st) {
@@ -659,21 +674,22 @@ int attn_mfma_bwd(const AttnArgs& a, hipStream_t st) {
                  ((uintptr_t)a.dv % 16) == 0, "attention bwd (MFMA path): gradient pointers must be 16-byte aligned");
   static const int dq_qt = env_knob("BEVBERT_DQ_QT", 2), dkv_kt = env_knob("BEVBERT_DKV_KT", 1);
   if (a.Lq > 64 && dq_qt == 2)
-    hipLaunchKernelGGL(attn_mfma_dq_kernel<2>, dim3((a.Lq + 127) / 128, a.nh, a.B), dim3(256), 0, st, a);
+    BB_DISPATCH_FLAGS(attn_mfma_dq_kernel, 2, dim3((a.Lq + 127) / 128, a.nh, a.B), 0);
   else
-    hipLaunchKernelGGL(attn_mfma_dq_kernel<1>, dim3((a.Lq + 63) / 64, a.nh, a.B), dim3(256), 0, st, a);
-  static const bool attr_ok = [] {   // 73.7 KB of dynamic LDS exceeds the default 64 KB cap: opt in once
-    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_dkv_kernel<1>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_BYTES);
-    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_dkv_kernel<2>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_BYTES);
-    return e1 == hipSuccess && e2 == hipSuccess;
+    BB_DISPATCH_FLAGS(attn_mfma_dq_kernel, 1, dim3((a.Lq + 63) / 64, a.nh, a.B), 0);
+  static const bool attr_ok = [] {   // 73.7 KB of dynamic LDS exceeds the default 64 KB cap: opt in once per variant
+    bool ok = true;
+    ok &= raise_lds_limit<1, false, false>() && raise_lds_limit<1, false, true>();
+    ok &= raise_lds_limit<1, true, false>() && raise_lds_limit<1, true, true>();
+    ok &= raise_lds_limit<2, false, false>() && raise_lds_limit<2, false, true>();
+    ok &= raise_lds_limit<2, true, false>() && raise_lds_limit<2, true, true>();
+    return ok;
   }();
   BB_REQUIRE(attr_ok, "attention bwd: cannot raise the dynamic LDS limit to %d bytes", DKV_SMEM_BYTES);
   if (a.Lk > 64 && dkv_kt == 2)
-    hipLaunchKernelGGL(attn_mfma_dkv_kernel<2>, dim3((a.Lk + 127) / 128, a.nh, a.B), dim3(256), DKV_SMEM_BYTES, st, a);
+    BB_DISPATCH_FLAGS(attn_mfma_dkv_kernel, 2, dim3((a.Lk + 127) / 128, a.nh, a.B), DKV_SMEM_BYTES);
   else
-    hipLaunchKernelGGL(attn_mfma_dkv_kernel<1>, dim3((a.Lk + 63) / 64, a.nh, a.B), dim3(256), DKV_SMEM_BYTES, st, a);
+    BB_DISPATCH_FLAGS(attn_mfma_dkv_kernel, 1, dim3((a.Lk + 63) / 64, a.nh, a.B), DKV_SMEM_BYTES);
   BB_CHECK_LAUNCH("attn_bwd(mfma)");
   return BB_OK;
 }
