@@ -27,6 +27,7 @@ struct AttnArgs {
   float drop_p;
   uint32_t drop_thr;   // 16-bit threshold
   uint32_t drop_key;   // bb_site_key(seed, offset)
+  int nblk;            // workgroups per (batch, head) along the tiled sequence axis (set by the launcher)
   int Lk2;             // Lk rounded up to even: dropout element index = ((b*nh + h)*Lq + q)*Lk2 + k
   // backward only
   const void* dout;        // (B, Lq, nh*64), strides ldo/bso
@@ -34,6 +35,19 @@ struct AttnArgs {
   void *dq, *dk, *dv;      // same strides as q/k/v
   float* dbias;            // (B, Lq, Lk) fp32, accumulated with atomics over heads, or null
 };
+
+// XCD-aware decode of a 1-D grid: hardware places workgroup id on XCD id % 8, each XCD has a private L2.  Work items
+// are numbered (block-in-sequence fastest, then head, then batch) and every XCD takes one contiguous run of them, so
+// the nblk workgroups that share one (batch, head)'s K/V (or Q/dO) tiles hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ void attn_decode_block(const AttnArgs& a, int& blk, int& h, int& b) {
+  const int nwg = gridDim.x, id = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, slot = id >> 3;
+  const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  blk = w % a.nblk;
+  const int t = w / a.nblk;
+  h = t % a.nh;
+  b = t / a.nh;
+}
 
 __device__ __forceinline__ uint32_t attn_row_base(const AttnArgs& a, int b, int h, int q) {
   return (uint32_t)((((uint32_t)b * a.nh + h) * a.Lq + q) * (uint32_t)a.Lk2);

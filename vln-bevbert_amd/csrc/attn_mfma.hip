@@ -118,8 +118,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_raw s_vt[2][ATTN_D * LDT];
   __shared__ __attribute__((aligned(16))) float s_mask[2][TK];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int qbase = blockIdx.x * (64 * QT) + w * (16 * QT);
+  int blk, h, b;
+  attn_decode_block(a, blk, h, b);
+  const int qbase = blk * (64 * QT) + w * (16 * QT);
   const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
   const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
   const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
@@ -292,8 +293,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_raw s_kt[2][ATTN_D * LDT];
   __shared__ __attribute__((aligned(16))) float s_mask[2][TK];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int qbase = blockIdx.x * (64 * QT) + w * (16 * QT);
+  int blk, h, b;
+  attn_decode_block(a, blk, h, b);
+  const int qbase = blk * (64 * QT) + w * (16 * QT);
   const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
   const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
   const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
@@ -464,8 +466,9 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(Att
   auto s_lse2 = [&](int bf) { return stats + (bf * 2 + 0) * TK; };
   auto s_dlt = [&](int bf) { return stats + (bf * 2 + 1) * TK; };
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int kbase = blockIdx.x * (64 * KT) + w * (16 * KT);
+  int blk, h, b;
+  attn_decode_block(a, blk, h, b);
+  const int kbase = blk * (64 * KT) + w * (16 * KT);
   const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
   const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
   const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
@@ -642,8 +645,11 @@ static int env_knob(const char* name, int dflt) {
 }
 
 // compile-time specialisation on (graph bias present, dropout active): the common launches carry neither
-#define BB_DISPATCH_FLAGS(KERNEL, N, GRID, SMEM)                                                         \
+#define BB_DISPATCH_FLAGS(KERNEL, N, NBLK, SMEM)                                                         \
   do {                                                                                                  \
+    AttnArgs a = a_in;                                                                                  \
+    a.nblk = (NBLK);                                                                                    \
+    const dim3 GRID((unsigned)a.nblk * a.nh * a.B);                                                     \
     const bool hb = a.bias != nullptr, hd = a.drop_p > 0.f;                                             \
     if (hb && hd) hipLaunchKernelGGL((KERNEL<N, true, true>), GRID, dim3(256), SMEM, st, a);            \
     else if (hb) hipLaunchKernelGGL((KERNEL<N, true, false>), GRID, dim3(256), SMEM, st, a);            \
@@ -651,13 +657,14 @@ static int env_knob(const char* name, int dflt) {
     else hipLaunchKernelGGL((KERNEL<N, false, false>), GRID, dim3(256), SMEM, st, a);                   \
   } while (0)
 
-int attn_mfma_fwd(const AttnArgs& a, hipStream_t st) {
+int attn_mfma_fwd(const AttnArgs& a_in, hipStream_t st) {
+  const AttnArgs& a = a_in;
   static const int fwd_qt = env_knob("BEVBERT_FWD_QT", 2);
   BB_REQUIRE(aligned8(a), "attention (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
   if (a.Lq > 64 && fwd_qt == 2)
-    BB_DISPATCH_FLAGS(attn_mfma_fwd_kernel, 2, dim3((a.Lq + 127) / 128, a.nh, a.B), 0);
+    BB_DISPATCH_FLAGS(attn_mfma_fwd_kernel, 2, (a.Lq + 127) / 128, 0);
   else
-    BB_DISPATCH_FLAGS(attn_mfma_fwd_kernel, 1, dim3((a.Lq + 63) / 64, a.nh, a.B), 0);
+    BB_DISPATCH_FLAGS(attn_mfma_fwd_kernel, 1, (a.Lq + 63) / 64, 0);
   BB_CHECK_LAUNCH("attn_fwd(mfma)");
   return BB_OK;
 }
@@ -668,15 +675,16 @@ static bool raise_lds_limit() {
                              hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM_BYTES) == hipSuccess;
 }
 
-int attn_mfma_bwd(const AttnArgs& a, hipStream_t st) {
+int attn_mfma_bwd(const AttnArgs& a_in, hipStream_t st) {
+  const AttnArgs& a = a_in;
   BB_REQUIRE(aligned8(a), "attention (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
   BB_REQUIRE(((uintptr_t)a.dout % 16) == 0 && ((uintptr_t)a.dq % 16) == 0 && ((uintptr_t)a.dk % 16) == 0 &&
                  ((uintptr_t)a.dv % 16) == 0, "attention bwd (MFMA path): gradient pointers must be 16-byte aligned");
   static const int dq_qt = env_knob("BEVBERT_DQ_QT", 2), dkv_kt = env_knob("BEVBERT_DKV_KT", 1);
   if (a.Lq > 64 && dq_qt == 2)
-    BB_DISPATCH_FLAGS(attn_mfma_dq_kernel, 2, dim3((a.Lq + 127) / 128, a.nh, a.B), 0);
+    BB_DISPATCH_FLAGS(attn_mfma_dq_kernel, 2, (a.Lq + 127) / 128, 0);
   else
-    BB_DISPATCH_FLAGS(attn_mfma_dq_kernel, 1, dim3((a.Lq + 63) / 64, a.nh, a.B), 0);
+    BB_DISPATCH_FLAGS(attn_mfma_dq_kernel, 1, (a.Lq + 63) / 64, 0);
   static const bool attr_ok = [] {   // 73.7 KB of dynamic LDS exceeds the default 64 KB cap: opt in once per variant
     bool ok = true;
     ok &= raise_lds_limit<1, false, false>() && raise_lds_limit<1, false, true>();
@@ -687,9 +695,9 @@ int attn_mfma_bwd(const AttnArgs& a, hipStream_t st) {
   }();
   BB_REQUIRE(attr_ok, "attention bwd: cannot raise the dynamic LDS limit to %d bytes", DKV_SMEM_BYTES);
   if (a.Lk > 64 && dkv_kt == 2)
-    BB_DISPATCH_FLAGS(attn_mfma_dkv_kernel, 2, dim3((a.Lk + 127) / 128, a.nh, a.B), DKV_SMEM_BYTES);
+    BB_DISPATCH_FLAGS(attn_mfma_dkv_kernel, 2, (a.Lk + 127) / 128, DKV_SMEM_BYTES);
   else
-    BB_DISPATCH_FLAGS(attn_mfma_dkv_kernel, 1, dim3((a.Lk + 63) / 64, a.nh, a.B), DKV_SMEM_BYTES);
+    BB_DISPATCH_FLAGS(attn_mfma_dkv_kernel, 1, (a.Lk + 63) / 64, DKV_SMEM_BYTES);
   BB_CHECK_LAUNCH("attn_bwd(mfma)");
   return BB_OK;
 }
