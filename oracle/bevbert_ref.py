@@ -141,22 +141,36 @@ def pano_layer(sd, p, x, key_pad, nh):
     return x + h
 
 
-def image_embeddings(sd, p, cfg, view_fts, loc_fts, nav_types, view_lens, type_emb_row1):
-    """vilmodel.py:494-532 ImageEmbeddings.forward (no-object branch) incl. pano encoder.
+def image_embeddings(sd, p, cfg, view_fts, loc_fts, nav_types, view_lens, type_emb_row1, obj_fts=None, obj_lens=None):
+    """vilmodel.py:494-532 ImageEmbeddings.forward incl. the object branch (:502-516) and the pano encoder.
 
-    Returns (sum_T, V, H) embeddings and the (sum_T, V) validity mask.
+    Returns (sum_T, L, H) embeddings, the (sum_T, L) validity mask and the token counts (views + objects).
     """
-    e = layer_norm(sd, p + ".img_layer_norm", linear(sd, p + ".img_linear", view_fts)) \
+    img = layer_norm(sd, p + ".img_layer_norm", linear(sd, p + ".img_linear", view_fts))
+    lens = view_lens
+    if obj_fts is not None:
+        if (p + ".obj_linear.weight") in sd:
+            obj = layer_norm(sd, p + ".obj_layer_norm", linear(sd, p + ".obj_linear", obj_fts))
+        else:
+            obj = layer_norm(sd, p + ".img_layer_norm", linear(sd, p + ".img_linear", obj_fts))
+        lens = view_lens + obj_lens
+        L = int(lens.max())
+        rows = []
+        for k in range(img.shape[0]):           # cat(view[:view_len], obj[:obj_len]) then zero-pad (:507-515)
+            r = torch.cat([img[k, :int(view_lens[k])], obj[k, :int(obj_lens[k])]], 0)
+            rows.append(torch.cat([r, r.new_zeros(L - r.shape[0], r.shape[1])], 0))
+        img = torch.stack(rows, 0)
+    e = img \
         + layer_norm(sd, p + ".loc_layer_norm", linear(sd, p + ".loc_linear", loc_fts)) \
         + sd[p + ".nav_type_embedding.weight"][nav_types] \
         + type_emb_row1[None, None]
     e = layer_norm(sd, p + ".layer_norm", e)
-    masks = seq_mask(view_lens, view_fts.shape[1])
+    masks = seq_mask(lens, img.shape[1])
     if cfg.num_pano_layers > 0:
         for i in range(cfg.num_pano_layers):
             e = pano_layer(sd, f"{p}.pano_encoder.layers.{i}", e, ~masks, cfg.num_attention_heads)
         e = layer_norm(sd, p + ".pano_encoder.norm", e)          # ops.py:19-20, eps 1e-12
-    return e, masks
+    return e, masks, lens
 
 
 def aggregate_gmap(traj_embeds, traj_masks, view_lens, step_lens, traj_vpids, traj_cand_vpids, gmap_vpids):
@@ -241,35 +255,66 @@ def _common(sd, cfg, b, pfx):
     txt_masks = seq_mask(b["txt_lens"], b["txt_ids"].shape[1])
     txt = text_embeddings(sd, pfx + "embeddings", b["txt_ids"])
     txt = lang_encoder(sd, pfx + "lang_encoder", cfg, txt, txt_masks)
-    traj, traj_masks = image_embeddings(
+    traj, traj_masks, lens = image_embeddings(
         sd, pfx + "img_embeddings", cfg, b["traj_view_img_fts"], b["traj_loc_fts"], b["traj_nav_types"],
-        b["traj_vp_view_lens"], sd[pfx + "embeddings.token_type_embeddings.weight"][1])
+        b["traj_vp_view_lens"], sd[pfx + "embeddings.token_type_embeddings.weight"][1],
+        b.get("traj_obj_img_fts"), b.get("traj_vp_obj_lens"))
+    b["_traj_lens"] = lens
     return txt, txt_masks, traj, traj_masks
 
 
+def _obj_tokens(b, traj):
+    """vilmodel.py:748-756: object tokens of every sample's LAST panorama, zero-padded, + validity mask."""
+    if b.get("traj_obj_img_fts") is None:
+        return None, None
+    ends = torch.cumsum(torch.tensor(b["traj_step_lens"]), 0) - 1
+    vl, ol = b["traj_vp_view_lens"][ends], b["traj_vp_obj_lens"][ends]
+    O = int(ol.max())
+    out = traj.new_zeros(len(ends), O, traj.shape[-1])
+    for i, e in enumerate(ends.tolist()):
+        out[i, :int(ol[i])] = traj[e, int(vl[i]):int(vl[i]) + int(ol[i])]
+    return out, seq_mask(ol, O)
+
+
+def _local(sd, cfg, pfx, txt, txt_masks, b, obj, obj_masks):
+    """vilmodel.py:595-615 LocalBEVEncoder.forward with the optional object tokens appended to the BEV cells."""
+    bev_in = bev_input_embedding(sd, pfx + "local_encoder", b["bev_fts"], b["bev_pos_fts"], b["bev_nav_masks"])
+    masks = b["bev_masks"]
+    if obj is not None:
+        bev_in = torch.cat([bev_in, obj], 1)
+        masks = torch.cat([masks, obj_masks], 1)
+    out = crossmodal_encoder(sd, pfx + "local_encoder.encoder", cfg, txt, txt_masks, bev_in, masks)
+    K = cfg.bev_dim * cfg.bev_dim
+    return out[:, :K], (out[:, K:] if obj is not None else None)
+
+
 def _gmap_inputs(sd, cfg, b, pfx, traj, traj_masks):
-    img = aggregate_gmap(traj, traj_masks, b["traj_vp_view_lens"], b["traj_step_lens"],
+    img = aggregate_gmap(traj, traj_masks, b["_traj_lens"], b["traj_step_lens"],
                          b["traj_vpids"], b["traj_cand_vpids"], b["gmap_vpids"])
     emb = gmap_input_embedding(sd, pfx + "global_encoder", img, b["gmap_step_ids"], b["gmap_pos_fts"])
     return emb, seq_mask(b["gmap_lens"], emb.shape[1])
 
 
-def cmt_forward(sd, cfg, b, pfx="bert.", return_gmap_embeds=True):
-    """vilmodel.py:717-765 GlocalTextPathCMT.forward (no-object configs)."""
+def cmt_forward(sd, cfg, b, pfx="bert.", return_gmap_embeds=True, with_objs=False):
+    """vilmodel.py:717-765 GlocalTextPathCMT.forward.  Returns (gmap, bev) or, with_objs, (gmap, bev, obj, obj_masks)."""
+    b = dict(b)
     txt, txt_masks, traj, traj_masks = _common(sd, cfg, b, pfx)
     gmap = None
     if return_gmap_embeds:
         g_in, g_masks = _gmap_inputs(sd, cfg, b, pfx, traj, traj_masks)
         sp = sprel_bias(sd, pfx + "global_encoder", b["gmap_pair_dists"]) if cfg.graph_sprels else None
         gmap = crossmodal_encoder(sd, pfx + "global_encoder.encoder", cfg, txt, txt_masks, g_in, g_masks, sp)
-    bev_in = bev_input_embedding(sd, pfx + "local_encoder", b["bev_fts"], b["bev_pos_fts"], b["bev_nav_masks"])
-    bev = crossmodal_encoder(sd, pfx + "local_encoder.encoder", cfg, txt, txt_masks, bev_in, b["bev_masks"])
+    obj, obj_masks = _obj_tokens(b, traj)
+    bev, obj_out = _local(sd, cfg, pfx, txt, txt_masks, b, obj, obj_masks)
+    if with_objs:
+        return gmap, bev, obj_out, obj_masks
     return gmap, bev
 
 
 def cmt_forward_mlm(sd, cfg, b, pfx="bert."):
     """vilmodel.py:768-830 forward_mlm: text is the query stream of both map encoders."""
     nh = cfg.num_attention_heads
+    b = dict(b)
     txt, txt_masks, traj, traj_masks = _common(sd, cfg, b, pfx)
     tm = neg_mask(txt_masks)
     g_in, g_masks = _gmap_inputs(sd, cfg, b, pfx, traj, traj_masks)
@@ -278,7 +323,12 @@ def cmt_forward_mlm(sd, cfg, b, pfx="bert."):
     for i in range(cfg.num_x_layers):
         g_txt = x_layer_lang2visn(sd, f"{pfx}global_encoder.encoder.x_layers.{i}", nh, g_txt, tm, g_in, gm)
     bev_in = bev_input_embedding(sd, pfx + "local_encoder", b["bev_fts"], b["bev_pos_fts"], b["bev_nav_masks"])
-    bm = neg_mask(b["bev_masks"])
+    obj, obj_masks = _obj_tokens(b, traj)
+    bev_masks = b["bev_masks"]
+    if obj is not None:                                               # vilmodel.py:814-816
+        bev_in = torch.cat([bev_in, obj], 1)
+        bev_masks = torch.cat([bev_masks, obj_masks], 1)
+    bm = neg_mask(bev_masks)
     b_txt = txt
     for i in range(cfg.num_x_layers):
         b_txt = x_layer_lang2visn(sd, f"{pfx}local_encoder.encoder.x_layers.{i}", nh, b_txt, tm, bev_in, bm)
@@ -288,9 +338,10 @@ def cmt_forward_mlm(sd, cfg, b, pfx="bert."):
 def cmt_forward_sem(sd, cfg, b, sem_pred_token, pfx="bert."):
     """vilmodel.py:833-883 forward_sem."""
     if sem_pred_token == "cattn":
-        txt, txt_masks, _, _ = _common(sd, cfg, b, pfx)
-        bev_in = bev_input_embedding(sd, pfx + "local_encoder", b["bev_fts"], b["bev_pos_fts"], b["bev_nav_masks"])
-        return crossmodal_encoder(sd, pfx + "local_encoder.encoder", cfg, txt, txt_masks, bev_in, b["bev_masks"])
+        b = dict(b)
+        txt, txt_masks, traj, _ = _common(sd, cfg, b, pfx)
+        obj, obj_masks = _obj_tokens(b, traj)
+        return _local(sd, cfg, pfx, txt, txt_masks, b, obj, obj_masks)[0]
     bev = bev_input_embedding(sd, pfx + "local_encoder", b["bev_fts"], b["bev_pos_fts"], b["bev_nav_masks"])
     if sem_pred_token == "sattn":
         bm = neg_mask(b["bev_masks"])
@@ -478,6 +529,20 @@ def pretrain_forward(sd, cfg, batch, task, compute_loss=True):
                 + F.cross_entropy(l, b["local_act_labels"], reduction="none") \
                 + F.cross_entropy(f, b["global_act_labels"], reduction="none")
         return g, l, f, b["global_act_labels"], b["local_act_labels"]
+    if task.startswith("mrc"):                                              # pretrain_cmt.py:272-297
+        _, _, obj, _ = cmt_forward(sd, cfg, b, return_gmap_embeds=False, with_objs=True)
+        sel = b["vp_obj_mrc_masks"]
+        pred = cls_head(sd, "obj_classifier", obj[sel])
+        target = b["vp_obj_probs"][sel]
+        if compute_loss:
+            return F.kl_div(F.log_softmax(pred, -1), target, reduction="none").sum(1)
+        return pred, target
+    if task.startswith("og"):                                               # pretrain_cmt.py:367-389
+        _, _, obj, obj_masks = cmt_forward(sd, cfg, b, return_gmap_embeds=False, with_objs=True)
+        logits = cls_head(sd, "og_head", obj).squeeze(2).masked_fill(~obj_masks, float("-inf"))
+        if compute_loss:
+            return F.cross_entropy(logits, b["obj_labels"], reduction="none")
+        return logits
     if task.startswith("sem") or task.startswith("masksem"):
         sel = b["bev_sem_masks"]
         if task.startswith("masksem"):                                  # pretrain_cmt.py:423-435
@@ -500,8 +565,9 @@ def nav_forward(sd, cfg, mode, b):
         txt = text_embeddings(sd, "embeddings", b["txt_ids"])
         return lang_encoder(sd, "lang_encoder", cfg, txt, b["txt_masks"])
     if mode == "panorama":                                              # :750-795
-        e, m = image_embeddings(sd, "img_embeddings", cfg, b["view_img_fts"], b["loc_fts"], b["nav_types"],
-                                b["view_lens"], sd["embeddings.token_type_embeddings.weight"][1])
+        e, m, _ = image_embeddings(sd, "img_embeddings", cfg, b["view_img_fts"], b["loc_fts"], b["nav_types"],
+                                   b["view_lens"], sd["embeddings.token_type_embeddings.weight"][1],
+                                   b.get("obj_img_fts"), b.get("obj_lens"))
         return e, m
     if mode == "navigation":                                            # :803-887
         g_in = gmap_input_embedding(sd, "global_encoder", b["gmap_img_embeds"], b["gmap_step_ids"], b["gmap_pos_fts"])

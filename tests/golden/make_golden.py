@@ -83,7 +83,8 @@ def build_ref_pretrain(cfg):
         cls.tie_weights = lambda self, *a, **k: None
     m = pretrain_cmt.GlocalTextPathCMTPreTraining(_ref_config(cfg))
     load_rule_weights(m)
-    m.mlm_head.predictions.decoder.weight = m.bert.embeddings.word_embeddings.weight
+    if hasattr(m, "mlm_head"):
+        m.mlm_head.predictions.decoder.weight = m.bert.embeddings.word_embeddings.weight
     return m.eval()
 
 
@@ -258,6 +259,49 @@ GRAD_KEYS = {
 }
 
 
+def gen_objects(cfg, tag, tasks, seed):
+    """REVERIE-style object tokens (configs/rvr_model.json): MLM / MRC / SAP / OG with objects appended to the
+    panoramas and to the BEV cells; `tag` selects shared (obj_feat == image_feat) or separate obj_linear weights."""
+    print(f"object tokens [{tag}]")
+    ref = build_ref_pretrain(cfg)
+    with open(os.path.join(OUT, f"pretrain_state_dict_keys_{tag}.txt"), "w") as f:
+        for k, v in ref.state_dict().items():
+            f.write(f"{k} {tuple(v.shape)}\n")
+    B = 4
+    arrs = {"seed": np.int64(seed), "B": np.int64(B)}
+    for task in tasks:
+        b = synthetic.make_batch(cfg, task, B, seed=seed, ragged=True)
+        with torch.no_grad():
+            arrs[f"{task}_loss"] = npy(ref(dict(b), task, True))
+            outs = ref(dict(b), task, False)
+        if task == "mlm":
+            arrs["mlm_scores_sub"] = sub(outs, 13)
+        elif task == "sap":
+            arrs.update(sap_global=npy(outs[0]), sap_local=npy(outs[1]), sap_fused=npy(outs[2]))
+        elif task == "mrc":
+            arrs.update(mrc_pred_sub=sub(outs[0], 7), mrc_n=np.int64(outs[0].shape[0]))
+        elif task == "og":
+            arrs["og_logits"] = npy(outs)
+        ref.zero_grad(set_to_none=True)
+        ref(dict(b), task, True).mean().backward()
+        arrs[f"{task}_grad_sqnorm"] = np.float64(
+            sum(float((p.grad.double() ** 2).sum()) for p in ref.parameters() if p.grad is not None))
+        arrs[f"{task}_n_params_with_grad"] = np.int64(sum(p.grad is not None for p in ref.parameters()))
+        for k, p in ref.named_parameters():
+            if p.grad is not None and k in OBJ_GRAD_KEYS:
+                arrs[f"{task}_grad::{k}"] = sub(p.grad, 97 if p.numel() > 4096 else 1)
+    save(f"tasks_{tag}", **arrs)
+
+
+OBJ_GRAD_KEYS = {
+    "bert.img_embeddings.img_linear.weight", "bert.img_embeddings.obj_linear.weight",
+    "bert.img_embeddings.obj_layer_norm.weight", "bert.img_embeddings.nav_type_embedding.weight",
+    "obj_classifier.net.3.weight", "og_head.net.0.weight", "og_head.net.3.bias",
+    "bert.local_encoder.encoder.x_layers.0.visn_self_att.self.key.weight",
+    "bert.embeddings.word_embeddings.weight",
+}
+
+
 def gen_nav(cfg):
     print("fine-tune API (GlocalTextPathNavCMT)")
     nav = build_ref_nav(cfg)
@@ -361,6 +405,13 @@ def main():
     gen_tasks(ref, tiny, "tiny_b2_fixed", B=2, seed=8, ragged=False, with_grads=False)
     gen_nav(tiny)
     gen_adamw()
+
+    rvr = BevBertConfig.tiny(image_feat_size=768, obj_feat_size=768, obj_prob_size=50,
+                             pretrain_tasks=("mlm", "mrc", "sap", "og"))
+    gen_objects(rvr, "tiny_rvr", ("mlm", "mrc", "sap", "og"), seed=31)
+    objlin = BevBertConfig.tiny(image_feat_size=512, obj_feat_size=640, obj_prob_size=50, num_l_layers=1,
+                                num_x_layers=1, pretrain_tasks=("mrc", "og"))
+    gen_objects(objlin, "tiny_objlin", ("mrc", "og"), seed=32)
 
     full = BevBertConfig()
     ref = build_ref_pretrain(full)

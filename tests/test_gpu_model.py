@@ -128,6 +128,62 @@ def test_full_r2r_config_bf16(env):
     _check_tasks(env, BevBertConfig(), "r2r_b2", "pretrain_state_dict_keys_r2r.txt", torch.bfloat16)
 
 
+OBJ_CASES = [
+    ("tiny_rvr", dict(image_feat_size=768, obj_feat_size=768, obj_prob_size=50,
+                      pretrain_tasks=("mlm", "mrc", "sap", "og")), ("mlm", "mrc", "sap", "og")),
+    ("tiny_objlin", dict(image_feat_size=512, obj_feat_size=640, obj_prob_size=50, num_l_layers=1, num_x_layers=1,
+                         pretrain_tasks=("mrc", "og")), ("mrc", "og")),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag,kw,tasks", OBJ_CASES)
+def test_object_token_tasks(env, tag, kw, tasks, dtype):
+    """REVERIE-style object tokens on the HIP path vs the reference's golden vectors (forward + gradients)."""
+    cfg = BevBertConfig.tiny(**kw)
+    g = load_golden(f"tasks_{tag}")
+    model, arena = build(cfg, f"pretrain_state_dict_keys_{tag}.txt", dtype)
+    fp32 = dtype == torch.float32
+    B, seed = int(g["B"]), int(g["seed"])
+
+    def cmp(got, ref, what):
+        got = got.detach().float().cpu().numpy()
+        if fp32:
+            assert max_abs(got, ref) < FP32_TOL, (what, max_abs(got, ref))
+        else:
+            bf16_close(got, ref, what)
+
+    for task in tasks:
+        b = synthetic.batch_to(synthetic.make_batch(cfg, task, B, seed=seed, ragged=True), DEV)
+        arena.zero_grad()
+        loss = model(b, task)
+        cmp(loss, g[f"{task}_loss"], f"{task}_loss")
+        loss.mean().backward()
+        with torch.no_grad():
+            outs = model(b, task, compute_loss=False)
+        if task == "og":
+            cmp(outs, g["og_logits"], "og_logits")
+        elif task == "mrc":
+            assert outs[0].shape[0] == int(g["mrc_n"])
+            cmp(torch.from_numpy(sub(outs[0].float().cpu(), 7).copy()), g["mrc_pred_sub"], "mrc_pred")
+        elif task == "sap":
+            cmp(outs[2], g["sap_fused"], "sap_fused")
+        sq = float((arena.grads.double() ** 2).sum())
+        ref_sq = float(g[f"{task}_grad_sqnorm"])
+        assert abs(sq - ref_sq) < (2e-3 if fp32 else 6e-2) * ref_sq, (task, sq, ref_sq)
+        for name, p in model.named_parameters():
+            gk = f"{task}_grad::{name}"
+            if gk in g.files:
+                ref = g[gk]
+                got = sub(p.main_grad.cpu(), 97 if p.numel() > 4096 else 1)
+                scale = max(1e-6, float(np.abs(ref).max()))
+                if fp32:
+                    assert max_abs(got, ref) < 2e-3 * scale + 1e-7, (gk, max_abs(got, ref), scale)
+                else:
+                    l2 = float(np.linalg.norm(got - ref) / max(1e-12, np.linalg.norm(ref)))
+                    assert l2 < 0.2, (gk, l2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_nav_api(env, dtype):
     cfg = BevBertConfig.tiny()

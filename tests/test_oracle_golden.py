@@ -130,6 +130,50 @@ def test_tasks_full_r2r_config():
     _check_tasks(BevBertConfig(), "r2r_b2", "pretrain_state_dict_keys_r2r.txt", False)
 
 
+@pytest.mark.parametrize("tag,kw,tasks", [
+    ("tiny_rvr", dict(image_feat_size=768, obj_feat_size=768, obj_prob_size=50,
+                      pretrain_tasks=("mlm", "mrc", "sap", "og")), ("mlm", "mrc", "sap", "og")),
+    ("tiny_objlin", dict(image_feat_size=512, obj_feat_size=640, obj_prob_size=50, num_l_layers=1, num_x_layers=1,
+                         pretrain_tasks=("mrc", "og")), ("mrc", "og")),
+])
+def test_object_token_tasks(tag, kw, tasks):
+    """REVERIE-style object tokens: panorama + BEV object branch, MRC and OG heads (pretrain_cmt.py:272-297,367-389)."""
+    cfg = BevBertConfig.tiny(**kw)
+    g = load_golden(f"tasks_{tag}")
+    sd = rule_state_dict(f"pretrain_state_dict_keys_{tag}.txt")
+    B, seed = int(g["B"]), int(g["seed"])
+    for task in tasks:
+        b = synthetic.make_batch(cfg, task, B, seed=seed, ragged=True)
+        leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        if "mlm_head.predictions.decoder.weight" in leaf:
+            leaf["mlm_head.predictions.decoder.weight"] = leaf["bert.embeddings.word_embeddings.weight"]
+        loss = R.pretrain_forward(leaf, cfg, b, task)
+        assert max_abs(loss.detach().numpy(), g[f"{task}_loss"]) < FP32_TOL, task
+        with torch.no_grad():
+            outs = R.pretrain_forward(sd, cfg, b, task, compute_loss=False)
+        if task == "mrc":
+            assert outs[0].shape[0] == int(g["mrc_n"]) and max_abs(sub(outs[0], 7), g["mrc_pred_sub"]) < FP32_TOL
+        elif task == "og":
+            assert max_abs(outs.numpy(), g["og_logits"]) < FP32_TOL
+        elif task == "sap":
+            assert max_abs(outs[2].numpy(), g["sap_fused"]) < FP32_TOL
+        loss.mean().backward()
+        seen, sq, n = set(), 0.0, 0
+        for k, v in leaf.items():
+            if v.grad is None or id(v) in seen:
+                continue
+            seen.add(id(v))
+            n += 1
+            sq += float((v.grad.double() ** 2).sum())
+            gk = f"{task}_grad::{k}"
+            if gk in g.files:
+                ref = g[gk]
+                scale = max(1e-6, float(np.abs(ref).max()))
+                assert max_abs(sub(v.grad, 97 if v.numel() > 4096 else 1), ref) < 2e-3 * scale + 1e-7, gk
+        assert n == int(g[f"{task}_n_params_with_grad"]), (task, n)
+        assert abs(sq - float(g[f"{task}_grad_sqnorm"])) < 1e-3 * float(g[f"{task}_grad_sqnorm"])
+
+
 def test_nav_api():
     cfg = BevBertConfig.tiny()
     g = load_golden("nav_tiny")

@@ -71,6 +71,13 @@ class BevBertConfig:
         return cls(vocab_size=250002, max_position_embeddings=514, **kw)
 
     @classmethod
+    def reverie(cls, **kw):
+        # configs/rvr_model.json: ImageNet ViT features (768) + object tokens; tasks of scripts/pt_rvr.bash
+        d = dict(image_feat_size=768, obj_feat_size=768, obj_prob_size=1000, pretrain_tasks=("mlm", "mrc", "sap", "og"))
+        d.update(kw)
+        return cls(**d)
+
+    @classmethod
     def tiny(cls, **kw):
         """Small depth/vocab for golden fixtures and CPU tests (widths are kept:
         768 is hard-coded in the reference's BEV embedding)."""

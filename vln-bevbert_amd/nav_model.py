@@ -35,7 +35,7 @@ class GlocalTextPathNavCMT(nn.Module):
             for p in self.img_embeddings.parameters():
                 p.requires_grad = False
         if config.fix_local_branch:
-            for m in (self.local_encoder, self.local_sap_head):
+            for m in (self.local_encoder, self.local_sap_head) + ((self.og_head,) if hasattr(self, "og_head") else ()):
                 for p in m.parameters():
                     p.requires_grad = False
 
@@ -56,22 +56,19 @@ class GlocalTextPathNavCMT(nn.Module):
         return self.lang_encoder(self.embeddings(txt_ids), txt_masks)
 
     def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
-        if obj_img_fts is not None:
-            raise NotImplementedError("object tokens are SURVEY section 8 row f4: not built yet")
         return self.img_embeddings.embed(view_img_fts, loc_fts, nav_types, view_lens,
-                                         self.embeddings.token_type_embeddings)
+                                         self.embeddings.token_type_embeddings, obj_img_fts, obj_lens)
 
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts,
                                     gmap_masks, gmap_pair_dists, gmap_visited_masks, gmap_vpids,
                                     bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, bev_cand_idxs, bev_cand_vpids,
                                     obj_embeds, obj_masks, gmap_visited_masks_host=None):
-        if obj_embeds is not None:
-            raise NotImplementedError("object tokens are SURVEY section 8 row f4: not built yet")
         cd = txt_embeds.dtype
         g_in = self.global_encoder.pos_step_embedding(gmap_img_embeds.to(cd), gmap_step_ids, gmap_pos_fts)
         gmap_embeds = self.global_encoder(txt_embeds, txt_masks, g_in, gmap_masks, gmap_pair_dists)
-        bev_embeds, _ = self.local_encoder(txt_embeds, txt_masks, bev_fts, bev_pos_fts, _all_ones_to_none(bev_masks),
-                                           bev_nav_masks, None, None)
+        bev_embeds, obj_embeds = self.local_encoder(txt_embeds, txt_masks, bev_fts, bev_pos_fts,
+                                                    _all_ones_to_none(bev_masks), bev_nav_masks,
+                                                    None if obj_embeds is None else obj_embeds.to(cd), obj_masks)
         if self.sap_fuse_linear is None:
             fuse_weights = 0.5
         else:
@@ -92,8 +89,11 @@ class GlocalTextPathNavCMT(nn.Module):
         dev = global_logits.device
         fused_logits = fuse_sap_logits(global_logits, local_logits, torch.from_numpy(src).to(dev, non_blocking=True),
                                        torch.from_numpy(vis_c).to(dev, non_blocking=True))
+        obj_logits = None
+        if obj_embeds is not None:                                      # map_nav_src/models/vilmodel.py:873-877
+            obj_logits = self.og_head(obj_embeds).squeeze(2).float().masked_fill(obj_masks.logical_not(), -float("inf"))
         return {"gmap_embeds": gmap_embeds, "global_logits": global_logits, "local_logits": local_logits,
-                "fused_logits": fused_logits, "obj_logits": None}
+                "fused_logits": fused_logits, "obj_logits": obj_logits}
 
     def forward(self, mode, batch, **kwargs):
         if mode == "language":

@@ -209,8 +209,6 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def forward(self, batch, task, compute_loss=True):
         if not any(task.startswith(t) for t in ("mlm", "mrc", "sap", "og", "sem", "masksem")):
             raise ValueError("invalid task")
-        if task.startswith("mrc") or task.startswith("og"):
-            raise NotImplementedError("REVERIE object tasks (mrc / og) are SURVEY section 8 row f4: not built yet")
         batch = dict(batch)     # the reference works on a defaultdict COPY (pretrain_cmt.py:170): the caller's dict is untouched
         self.lift_splat(batch)
         self.drop_feats(batch)
@@ -218,13 +216,44 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             return self.forward_mlm(batch, compute_loss)
         if task.startswith("sap"):
             return self.forward_sap(batch, compute_loss)
+        if task.startswith("mrc"):
+            return self.forward_mrc(batch, compute_loss)
+        if task.startswith("og"):
+            return self.forward_og(batch, compute_loss)
         if task.startswith("masksem"):
             return self.forward_masksem(batch, compute_loss)
         return self.forward_sem(batch, compute_loss)
 
     # -- tasks --------------------------------------------------------------------------------------
+    def _host_kw(self, b):
+        return {"view_lens_host": b.get("traj_vp_view_lens_cpu"), "obj_lens_host": b.get("traj_vp_obj_lens_cpu")}
+
+    def forward_mrc(self, b, compute_loss):
+        """pretrain_cmt.py:272-297: masked-region classification on the object tokens (KL to detector probs)."""
+        _, _, obj_embeds, _ = self.bert(*self._cmt_args(b), return_gmap_embeds=False, **self._host_kw(b))
+        sel = b["vp_obj_mrc_masks"]
+        host = b.get("vp_obj_mrc_masks_cpu")
+        if host is not None:
+            pos = torch.nonzero(host.reshape(-1)).squeeze(1).to(sel.device, non_blocking=True)
+            masked = obj_embeds.reshape(-1, obj_embeds.shape[-1]).index_select(0, pos)
+            targets = b["vp_obj_probs"].reshape(-1, b["vp_obj_probs"].shape[-1]).index_select(0, pos)
+        else:
+            masked, targets = obj_embeds[sel], b["vp_obj_probs"][sel]
+        pred = self.obj_classifier(masked).float()
+        if compute_loss:
+            return F.kl_div(F.log_softmax(pred, dim=-1), targets, reduction="none").sum(dim=1)
+        return pred, targets
+
+    def forward_og(self, b, compute_loss):
+        """pretrain_cmt.py:367-389: object grounding logits over the last viewpoint's objects."""
+        _, _, obj_embeds, obj_masks = self.bert(*self._cmt_args(b), return_gmap_embeds=False, **self._host_kw(b))
+        logits = self.og_head(obj_embeds).squeeze(2).float().masked_fill(obj_masks.logical_not(), -float("inf"))
+        if compute_loss:
+            return F.cross_entropy(logits, b["obj_labels"], reduction="none")
+        return logits
+
     def forward_mlm(self, b, compute_loss):
-        txt_embeds = self.bert.forward_mlm(*self._cmt_args(b), view_lens_host=b.get("traj_vp_view_lens_cpu"))
+        txt_embeds = self.bert.forward_mlm(*self._cmt_args(b), **self._host_kw(b))
         labels = b["txt_labels"]
         host = b.get("txt_labels_cpu")
         if host is not None:        # host-known positions: no nonzero() sync (pretrain_cmt.py:254-256 has one)
@@ -239,7 +268,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
 
     def forward_sap(self, b, compute_loss):
         cfg = self.config
-        gmap_embeds, bev_embeds, _, _ = self.bert(*self._cmt_args(b), view_lens_host=b.get("traj_vp_view_lens_cpu"))
+        gmap_embeds, bev_embeds, _, _ = self.bert(*self._cmt_args(b), **self._host_kw(b))
         if self.sap_fuse_linear is None:
             fuse_weights = 0.5
         else:
@@ -271,7 +300,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         return global_logits, local_logits, fused_logits, b["global_act_labels"], b["local_act_labels"]
 
     def _sem_common(self, b, sel, compute_loss):
-        bev_embeds = self.bert.forward_sem(*self._cmt_args(b), sem_pred_token=self.sem_pred_token)
+        bev_embeds = self.bert.forward_sem(*self._cmt_args(b), sem_pred_token=self.sem_pred_token, **self._host_kw(b))
         masked = bev_embeds[sel]                               # data-dependent row count: one sync, as the reference
         sem_logits = self.local_sem_head(masked).float()
         sem_labels = b["bev_sems"][sel].float()

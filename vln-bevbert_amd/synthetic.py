@@ -78,7 +78,8 @@ def make_sample(rng, i, cfg, n_steps, txt_len, ragged_views=False):
         if t % 2 == 0:
             c.append(f"s{i}")                # seen from several steps -> averaged
         cands.append(c)
-    view_fts, loc_fts, nav_types, view_lens = [], [], [], []
+    view_fts, loc_fts, nav_types, view_lens, obj_fts, obj_lens = [], [], [], [], [], []
+    has_obj = getattr(cfg, "obj_feat_size", 0) > 0
     for t in range(n_steps):
         nv = N_VIEWS + (int(rng.integers(0, 3)) if ragged_views else 0)
         view_fts.append(rng.standard_normal((nv, cfg.image_feat_size)).astype(np.float32))
@@ -86,12 +87,35 @@ def make_sample(rng, i, cfg, n_steps, txt_len, ragged_views=False):
         loc = np.concatenate(
             [np.sin(ang[:, :1]), np.cos(ang[:, :1]), np.sin(ang[:, 1:]), np.cos(ang[:, 1:]),
              np.ones((nv, 3))], 1).astype(np.float32)
-        loc_fts.append(loc)
         nt = [1] * len(cands[t]) + [0] * (nv - len(cands[t]))
+        if has_obj:     # REVERIE: object tokens follow the views (dataset.py:283-321): loc = [angle(4), box(3)], type 2
+            no = int(rng.integers(0, 5)) if ragged_views else 3
+            if t == n_steps - 1 and no == 0 and i % 2 == 0:
+                no = 2          # most samples end on a viewpoint with objects; odd ones may have none
+            obj_fts.append(rng.standard_normal((no, cfg.obj_feat_size)).astype(np.float32))
+            oang = rng.uniform(-math.pi, math.pi, size=(no, 2))
+            oloc = np.concatenate(
+                [np.sin(oang[:, :1]), np.cos(oang[:, :1]), np.sin(oang[:, 1:]), np.cos(oang[:, 1:]),
+                 rng.uniform(0, 1, size=(no, 3))], 1).astype(np.float32)
+            loc = np.concatenate([loc, oloc], 0)
+            nt = nt + [2] * no
+            obj_lens.append(no)
+        loc_fts.append(loc)
         nav_types.append(nt)
         view_lens.append(nv)
     s.update(traj_view_img_fts=view_fts, traj_loc_fts=loc_fts, traj_nav_types=nav_types,
              traj_vp_view_lens=view_lens, traj_vpids=path, traj_cand_vpids=cands)
+    if has_obj:
+        no = obj_lens[-1]
+        logits = rng.standard_normal((no, cfg.obj_prob_size))
+        e = np.exp(logits - logits.max(1, keepdims=True)) if no else logits
+        s.update(traj_obj_img_fts=obj_fts, traj_vp_obj_lens=obj_lens,
+                 vp_obj_probs=(e / e.sum(1, keepdims=True)).astype(np.float32) if no else logits.astype(np.float32),
+                 obj_labels=int(rng.integers(0, no)) if no else -100)
+        mrc_o = rng.random(no) < 0.15
+        if no and not mrc_o.any():
+            mrc_o[int(rng.integers(0, no))] = True
+        s["vp_obj_mrc_masks"] = mrc_o
 
     # ---- global map (get_gmap_inputs): visited in path order, then still-unvisited candidates
     visited, unvisited = {}, {}
@@ -190,6 +214,18 @@ def collate(samples, cfg, task, rng, sems_as="onehot64"):
         _pad_stack([np.asarray(v, dtype=np.int64) for v in flat("traj_nav_types")]))
     b["traj_vpids"] = [s["traj_vpids"] for s in samples]
     b["traj_cand_vpids"] = [s["traj_cand_vpids"] for s in samples]
+    if "traj_obj_img_fts" in samples[0]:            # mrc_collate / og_collate (tasks.py:291-297,471-475)
+        objs = [[o.copy() for o in s["traj_obj_img_fts"]] for s in samples]
+        if task.startswith("mrc"):                  # masked objects of the LAST viewpoint are zeroed (tasks.py:240-242)
+            for o, s in zip(objs, samples):
+                o[-1][s["vp_obj_mrc_masks"]] = 0
+        b["traj_vp_obj_lens"] = torch.tensor(flat("traj_vp_obj_lens"), dtype=torch.long)
+        b["traj_obj_img_fts"] = torch.from_numpy(_pad_stack([o for so in objs for o in so]))
+        if task.startswith("mrc"):
+            b["vp_obj_mrc_masks"] = torch.from_numpy(_pad_stack([s["vp_obj_mrc_masks"] for s in samples], False))
+            b["vp_obj_probs"] = torch.from_numpy(_pad_stack([s["vp_obj_probs"] for s in samples]))
+        if task.startswith("og"):
+            b["obj_labels"] = torch.tensor([s["obj_labels"] for s in samples], dtype=torch.long)
 
     b["gmap_vpids"] = [s["gmap_vpids"] for s in samples]
     b["gmap_lens"] = torch.tensor([len(s["gmap_step_ids"]) for s in samples], dtype=torch.long)
@@ -244,7 +280,7 @@ def make_batch(cfg, task, batch_size, seed=1000, txt_len=80, n_steps=5, ragged=F
     return collate(samples, cfg, task, rng, sems_as=sems_as)
 
 
-HOST_COPIES = ("gmap_visited_masks", "txt_labels", "traj_vp_view_lens")
+HOST_COPIES = ("gmap_visited_masks", "txt_labels", "traj_vp_view_lens", "traj_vp_obj_lens", "vp_obj_mrc_masks")
 
 
 def batch_to(batch, device, non_blocking=True):

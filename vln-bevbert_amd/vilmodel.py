@@ -363,12 +363,29 @@ class ImageEmbeddings(nn.Module):
         self.drop_p = config.hidden_dropout_prob
         self.pano_encoder = TransformerEncoder(config, config.num_pano_layers) if config.num_pano_layers > 0 else None
 
-    def embed(self, view_img_fts, loc_fts, nav_types, view_lens, type_embed_layer):
-        """Shared by forward (pre-training) and forward_panorama_per_step (fine-tuning)."""
+    def embed(self, view_img_fts, loc_fts, nav_types, view_lens, type_embed_layer, obj_img_fts=None, obj_lens=None):
+        """Shared by forward (pre-training) and forward_panorama_per_step (fine-tuning).
+
+        Object tokens (REVERIE / SOON, vilmodel.py:502-516) follow the views of their panorama: the reference
+        concatenates and re-pads per panorama in a Python loop; here it is one gather over
+        [views | objects | zero row] with an index built on the device from the two length vectors."""
         cd = ops._compute(self.img_linear.weight).dtype
         x = ops.linear(view_img_fts.to(cd), self.img_linear.weight)
         e = ops.bias_dropout_residual_layernorm(x, self.img_linear.bias, None, self.img_layer_norm.weight,
                                                 self.img_layer_norm.bias, 1e-12)
+        lens = view_lens
+        if obj_img_fts is not None:
+            lin, ln = (self.img_linear, self.img_layer_norm) if self.obj_linear is None \
+                else (self.obj_linear, self.obj_layer_norm)
+            xo = ops.linear(obj_img_fts.to(cd), lin.weight)
+            eo = ops.bias_dropout_residual_layernorm(xo, lin.bias, None, ln.weight, ln.bias, 1e-12)
+            V, O, L = e.shape[1], eo.shape[1], loc_fts.shape[1]
+            lens = view_lens + obj_lens
+            pos = torch.arange(L, device=e.device)[None, :]
+            vl, tl = view_lens[:, None], lens[:, None]
+            idx = torch.where(pos < vl, pos, torch.where(pos < tl, V + pos - vl, torch.full_like(pos, V + O)))
+            pool = torch.cat([e, eo, e.new_zeros(e.shape[0], 1, e.shape[2])], 1)
+            e = torch.gather(pool, 1, idx[..., None].expand(-1, -1, e.shape[2]))
         loc = _small_k_linear(loc_fts, self.loc_linear, cd)
         e = e + ops.bias_dropout_residual_layernorm(loc, self.loc_linear.bias, None, self.loc_layer_norm.weight,
                                                     self.loc_layer_norm.bias, 1e-12)
@@ -376,17 +393,17 @@ class ImageEmbeddings(nn.Module):
             + embedding_lookup(type_embed_layer, torch.ones(1, 1, dtype=torch.long, device=e.device))
         e = ops.layernorm(e, self.layer_norm.weight, self.layer_norm.bias, 1e-12)
         e = F.dropout(e, self.drop_p, self.training)
-        masks = gen_seq_masks(view_lens, view_img_fts.shape[1])
+        masks = gen_seq_masks(lens, e.shape[1])
         if self.pano_encoder is not None:
             e = self.pano_encoder(e, masks.logical_not())
         return e, masks
 
     def forward(self, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types, traj_step_lens,
                 traj_vp_view_lens, traj_vp_obj_lens, type_embed_layer):
-        if traj_obj_img_fts is not None:
-            raise NotImplementedError("object tokens (REVERIE / SOON configs) are SURVEY section 8 row f4: not built yet")
-        e, _ = self.embed(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, type_embed_layer)
-        return torch.split(e, traj_step_lens, 0), torch.split(traj_vp_view_lens, traj_step_lens, 0)
+        e, _ = self.embed(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, type_embed_layer,
+                          traj_obj_img_fts, traj_vp_obj_lens)
+        lens = traj_vp_view_lens if traj_obj_img_fts is None else traj_vp_view_lens + traj_vp_obj_lens
+        return torch.split(e, traj_step_lens, 0), torch.split(lens, traj_step_lens, 0)
 
 
 class _GatherRows(torch.autograd.Function):
@@ -441,12 +458,22 @@ class LocalBEVEncoder(nn.Module):
         e = e + ops.bias_dropout_residual_layernorm(pos, lin.bias, None, ln.weight, ln.bias, 1e-12)
         return e + embedding_lookup(self.nav_type_embedding, bev_nav_masks.long())
 
+    def with_objects(self, bev_embeds, bev_masks, obj_embeds, obj_masks):
+        """vilmodel.py:601-606: object tokens are appended to the BEV cells (an all-ones BEV mask may come as None)."""
+        if obj_embeds is None:
+            return bev_embeds, bev_masks
+        if bev_masks is None:
+            bev_masks = torch.ones(bev_embeds.shape[:2], dtype=torch.bool, device=bev_embeds.device)
+        return torch.cat([bev_embeds, obj_embeds], 1), torch.cat([bev_masks, obj_masks], 1)
+
     def forward(self, txt_embeds, txt_masks, bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, obj_embeds, obj_masks):
-        if obj_embeds is not None:
-            raise NotImplementedError("object tokens are SURVEY section 8 row f4: not built yet")
         bev_embeds = self.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
-        bev_embeds = self.encoder(txt_embeds, txt_masks, bev_embeds, bev_masks)
-        return bev_embeds, None
+        x, m = self.with_objects(bev_embeds, bev_masks, obj_embeds, obj_masks)
+        x = self.encoder(txt_embeds, txt_masks, x.contiguous(), m)
+        K = self.bev_dim * self.bev_dim
+        if obj_embeds is None:
+            return x, None
+        return x[:, :K], x[:, K:]
 
 
 def build_gmap_csr(traj_step_lens, view_lens_host, traj_vpids, traj_cand_vpids, gmap_vpids, n_views, device):
@@ -535,10 +562,36 @@ class GlocalTextPathCMT(nn.Module):
         txt_masks = gen_seq_masks(txt_lens, txt_ids.shape[1])
         return self.lang_encoder(self.embeddings(txt_ids), txt_masks), txt_masks
 
-    def _traj(self, traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens):
+    def _traj(self, traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts=None,
+              traj_vp_obj_lens=None):
         e, masks = self.img_embeddings.embed(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens,
-                                             self.embeddings.token_type_embeddings)
+                                             self.embeddings.token_type_embeddings, traj_obj_img_fts, traj_vp_obj_lens)
         return e
+
+    @staticmethod
+    def _token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host, obj_lens_host):
+        """Host copy of the per-panorama token counts (views + objects): from the loader's CPU copies when given."""
+        vl = view_lens_host if view_lens_host is not None else traj_vp_view_lens
+        vl = _host_list(vl)
+        if traj_vp_obj_lens is None:
+            return vl, None
+        ol = _host_list(obj_lens_host if obj_lens_host is not None else traj_vp_obj_lens)
+        return [a + b for a, b in zip(vl, ol)], ol
+
+    def _obj_tokens(self, traj, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, obj_lens_host):
+        """vilmodel.py:748-756: the object tokens of every sample's LAST panorama, zero padded, + validity mask."""
+        if traj_vp_obj_lens is None:
+            return None, None
+        ends_host = np.cumsum(traj_step_lens) - 1
+        O = max(1, max(obj_lens_host[e] for e in ends_host))
+        ends = torch.from_numpy(ends_host).to(traj.device, non_blocking=True)
+        vl, ol = traj_vp_view_lens[ends], traj_vp_obj_lens[ends]
+        j = torch.arange(O, device=traj.device)[None, :]
+        valid = j < ol[:, None]
+        idx = torch.where(valid, vl[:, None] + j, torch.zeros_like(j))
+        rows = traj[ends]                                           # (B, L, H)
+        obj = torch.gather(rows, 1, idx[..., None].expand(-1, -1, rows.shape[2]))
+        return obj * valid[..., None].to(obj.dtype), valid
 
     def _gmap_inputs(self, traj_embeds, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids, gmap_vpids,
                      gmap_step_ids, gmap_pos_fts, gmap_lens, view_lens_host=None):
@@ -555,37 +608,48 @@ class GlocalTextPathCMT(nn.Module):
     def forward(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
                 traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
                 gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
-                bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, return_gmap_embeds=True, view_lens_host=None):
-        if traj_obj_img_fts is not None:
-            raise NotImplementedError("object tokens are SURVEY section 8 row f4: not built yet")
+                bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, return_gmap_embeds=True, view_lens_host=None,
+                obj_lens_host=None):
+        has_obj = traj_obj_img_fts is not None
         txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
-        gmap_embeds = None
+        gmap_embeds = obj_embeds = obj_masks = traj = None
+        if return_gmap_embeds or has_obj:
+            traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts,
+                              traj_vp_obj_lens)
+            tok_lens, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host,
+                                                      obj_lens_host)
         if return_gmap_embeds:
-            traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens)
             g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
-                                              gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, view_lens_host)
+                                              gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens)
             gmap_embeds = self.global_encoder(txt_embeds, txt_masks, g_in, g_masks, gmap_pair_dists)
+        if has_obj:
+            obj_embeds, obj_masks = self._obj_tokens(traj, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens,
+                                                     ol_host)
         bev_embeds, obj_embeds = self.local_encoder(txt_embeds, txt_masks, bev_fts, bev_pos_fts,
-                                                    _all_ones_to_none(bev_masks), bev_nav_masks, None, None)
-        return gmap_embeds, bev_embeds, obj_embeds, None
+                                                    _all_ones_to_none(bev_masks), bev_nav_masks, obj_embeds, obj_masks)
+        return gmap_embeds, bev_embeds, obj_embeds, obj_masks
 
     def forward_mlm(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
                     traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
                     gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
-                    bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, view_lens_host=None):
-        if traj_obj_img_fts is not None:
-            raise NotImplementedError("object tokens are SURVEY section 8 row f4: not built yet")
+                    bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, view_lens_host=None, obj_lens_host=None):
         txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
         tm = neg_key_mask(txt_masks)
-        traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens)
+        traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts,
+                          traj_vp_obj_lens)
+        tok_lens, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host, obj_lens_host)
         g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
-                                          gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, view_lens_host)
+                                          gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens)
         gm = neg_key_mask(g_masks)
         g_txt = txt_embeds
         for layer in self.global_encoder.encoder.x_layers:
             g_txt = layer.forward_lang2visn(g_txt, tm, g_in, gm)
         bev_in = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
-        bm = neg_key_mask(_all_ones_to_none(bev_masks))
+        obj_embeds, obj_masks = self._obj_tokens(traj, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, ol_host)
+        bev_in, bev_obj_masks = self.local_encoder.with_objects(bev_in, _all_ones_to_none(bev_masks), obj_embeds,
+                                                                obj_masks)
+        bev_in = bev_in.contiguous()
+        bm = neg_key_mask(bev_obj_masks)
         b_txt = txt_embeds
         for layer in self.local_encoder.encoder.x_layers:
             b_txt = layer.forward_lang2visn(b_txt, tm, bev_in, bm)
@@ -594,12 +658,21 @@ class GlocalTextPathCMT(nn.Module):
     def forward_sem(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
                     traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
                     gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
-                    bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, sem_pred_token=None):
+                    bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, sem_pred_token=None, view_lens_host=None,
+                    obj_lens_host=None):
         bm = _all_ones_to_none(bev_masks)
         if sem_pred_token == "cattn":
             txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
-            # the reference also runs img_embeddings here (vilmodel.py:847-851) but nothing consumes the result
-            bev_embeds, _ = self.local_encoder(txt_embeds, txt_masks, bev_fts, bev_pos_fts, bm, bev_nav_masks, None, None)
+            obj_embeds = obj_masks = None
+            if traj_obj_img_fts is not None:
+                traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens,
+                                  traj_obj_img_fts, traj_vp_obj_lens)
+                _, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host, obj_lens_host)
+                obj_embeds, obj_masks = self._obj_tokens(traj, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens,
+                                                         ol_host)
+            # (without objects the reference still runs img_embeddings here, vilmodel.py:847-851, but nothing consumes it)
+            bev_embeds, _ = self.local_encoder(txt_embeds, txt_masks, bev_fts, bev_pos_fts, bm, bev_nav_masks,
+                                               obj_embeds, obj_masks)
         elif sem_pred_token == "sattn":
             bev_embeds = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
             km = neg_key_mask(bm)
