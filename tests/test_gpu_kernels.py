@@ -78,6 +78,20 @@ def test_splat_mean_bit_exact_and_semantics(ops):
         assert torch.equal(o.cpu(), ref)
 
 
+@pytest.mark.parametrize("dim,res", [(11, 1.0), (14, 0.5), (21, 0.25)])
+def test_lift_bin_other_geometries(ops, dim, res):
+    cfg = BevBertConfig(bev_dim=dim, bev_res=res)
+    b = synthetic.make_batch(cfg, "sap", 3, seed=dim, ragged=True)
+    pc, nod = R.lift_points(b["depths"], b["T_c2w"], b["T_w2c"], b["S_w2c"])
+    want = R.cell_index(pc, nod, dim, res)
+    g = synthetic.batch_to(b, DEV)
+    cell, order, start = ops.bev_lift_bin(g["depths"], g["T_c2w"], g["T_w2c"], g["S_w2c"], ops.pixel_scale(14, DEV),
+                                          dim, res)
+    assert torch.equal(cell.cpu().long(), want)
+    out, _, _ = ops.bev_splat_mean(g["rgbs"].reshape(3, -1, 768), order, start, dim * dim)
+    assert torch.equal(out.cpu(), R.lift_splat(cfg, b)["bev_fts"])
+
+
 def test_splat_golden_edge_cases(ops):
     gld = load_golden("splat_edge")
     pts = torch.from_numpy(gld["pts"])[None].to(DEV)

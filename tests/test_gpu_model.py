@@ -238,6 +238,27 @@ def test_nav_api(env, dtype):
             cmp(out[f"{k}_logits"], g[f"nav_{k}"])
 
 
+@pytest.mark.parametrize("dim,res", [(11, 1.0), (14, 0.5)])
+def test_bev_geometry_variants_against_oracle(env, dim, res):
+    """The path is parametric in the BEV geometry: 11x11 @ 1 m is the continuous-environment fork
+    (bevbert_ce/pretrain/pretrain_src/model/pretrain_cmt.py:16-17), 14x14 the north star's literal shape."""
+    from vln_bevbert_amd import weights
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400, bev_dim=dim, bev_res=res)
+    model = GlocalTextPathCMTPreTraining(cfg)
+    sd = weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd)
+    model.tie_weights()
+    model.finalize(DEV, torch.float32)
+    model.eval()
+    for task in ("sap", "masksem", "mlm"):
+        b = synthetic.make_batch(cfg, task, 3, seed=60 + dim, ragged=True)
+        with torch.no_grad():
+            got = model(synthetic.batch_to(b, DEV), task).cpu()
+            want = R.pretrain_forward(sd, cfg, b, task)
+        assert got.shape == want.shape and max_abs(got.numpy(), want.numpy()) < FP32_TOL, (task, dim)
+
+
 def _oracle_train(cfg, sd0, tasks, batches, lr_fn, wd=0.01, max_norm=5.0):
     """CPU oracle of the reference's hot loop with dropout disabled (train_r2r.py:247-313)."""
     sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
