@@ -71,6 +71,18 @@ def call(name, *args):
     TRACE.setdefault(key, []).append((s, e, args))
 
 
+def _gemm(kind, fn, m, n, k):
+    """Library GEMM (hipBLASLt via torch); when TRACE is armed, time it with HIP events keyed by its shape."""
+    if TRACE is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    out = fn()
+    e.record()
+    TRACE.setdefault(f"gemm:{kind}[M={m},N={n},K={k}]", []).append((s, e, (m, n, k)))
+    return out
+
+
 def _sink(param):
     """fp32 accumulation target of a parameter, or None for plain tensors."""
     return getattr(param, "main_grad", None)
@@ -230,7 +242,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, w_c, b_c):
-        y = F.linear(x, w_c, b_c)
+        y = _gemm("fwd", lambda: F.linear(x, w_c, b_c), x.numel() // x.shape[-1], w_c.shape[0], w_c.shape[1])
         ctx.save_for_backward(x, w_c)
         ctx.params = (weight, bias)
         return y
@@ -241,16 +253,17 @@ class _Linear(torch.autograd.Function):
         weight, bias = ctx.params
         dy2 = dy.reshape(-1, dy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
-        dx = dy2.mm(w_c).view(x.shape) if ctx.needs_input_grad[0] else None
+        M, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
+        dx = _gemm("dgrad", lambda: dy2.mm(w_c), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if weight.requires_grad:
             sink = _sink(weight)
             if sink is not None:
                 _mark_touched(weight)
                 if dy2.dtype == torch.float32:
-                    sink.addmm_(dy2.t(), x2)
+                    _gemm("wgrad", lambda: sink.addmm_(dy2.t(), x2), N, K, M)
                 else:
-                    sink.add_(dy2.t().mm(x2))
+                    sink.add_(_gemm("wgrad", lambda: dy2.t().mm(x2), N, K, M))
             else:
                 gw = dy2.t().mm(x2).to(weight.dtype)
         if bias is not None and bias.requires_grad:
@@ -304,7 +317,8 @@ class _LinearPacked(torch.autograd.Function):
     def forward(ctx, x, pw, pb):
         ctx.save_for_backward(x)
         ctx.packed = (pw, pb)
-        return F.linear(x, pw.compute, pb.compute)
+        return _gemm("fwd", lambda: F.linear(x, pw.compute, pb.compute), x.numel() // x.shape[-1],
+                     pw.compute.shape[0], pw.compute.shape[1])
 
     @staticmethod
     def backward(ctx, dy):
@@ -312,13 +326,14 @@ class _LinearPacked(torch.autograd.Function):
         pw, pb = ctx.packed
         dy2 = dy.reshape(-1, dy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
-        dx = dy2.mm(pw.compute).view(x.shape) if ctx.needs_input_grad[0] else None
+        M, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
+        dx = _gemm("dgrad", lambda: dy2.mm(pw.compute), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
         if pw.requires_grad:
             pw.touch()
             if dy2.dtype == torch.float32:
-                pw.main_grad.addmm_(dy2.t(), x2)
+                _gemm("wgrad", lambda: pw.main_grad.addmm_(dy2.t(), x2), N, K, M)
             else:
-                pw.main_grad.add_(dy2.t().mm(x2))
+                pw.main_grad.add_(_gemm("wgrad", lambda: dy2.t().mm(x2), N, K, M))
             pb.touch()
             C = dy2.shape[1]
             ws = RT.workspace(dy.device, 512 * C)
