@@ -137,6 +137,9 @@ int bevbert_adamw_step(float* params, const float* grads, float* exp_avg, float*
                        const uint8_t* chunk_flags, int* chunk_steps, int64_t n, const float* grad_scale_dev, float lr,
                        float beta1, float beta2, float eps, float weight_decay, hipStream_t stream);
 int bevbert_cast_f32(const float* src, void* dst, int64_t n, int dst_dtype, hipStream_t stream);
+/* sink[i] += sum_{s<S} partials[s*n + i]: reduction of the host-side split-K weight-gradient GEMMs (library batched
+ * GEMM over S chunks of the token axis), fused with the accumulation into the fp32 gradient arena. */
+int bevbert_accum_partials(const void* partials, float* sink, int S, int64_t n, int dtype, hipStream_t stream);
 
 /* test hook: keep-mask (uint8) the kernels derive for n consecutive elements starting at `offset` */
 int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p, uint64_t seed, uint64_t offset,

@@ -289,6 +289,21 @@ __global__ __launch_bounds__(192) void gather_wsum_kernel(const T* __restrict__ 
   }
 }
 
+// sink[i] += sum_s partials[s][i]: the reduction step of the host-side split-K weight-gradient GEMMs, fused with the
+// accumulation into the fp32 gradient arena (replaces a torch sum + add_ pair).  S is small (<= 32).
+template <typename T>
+__global__ __launch_bounds__(256) void accum_partials_kernel(const T* __restrict__ partials, float* __restrict__ sink,
+                                                             int S, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 acc = *reinterpret_cast<const float4*>(sink + i * 4);
+    for (int s = 0; s < S; ++s) {
+      const float4 v = ld4<T>(partials + ((size_t)s * n4 + i) * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(sink + i * 4) = acc;
+  }
+}
+
 // table_grad[ids[r]] += d[r]  (fp32 atomics; the reference's embedding backward is an atomic index_add too)
 template <typename T>
 __global__ __launch_bounds__(192) void embedding_grad_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d,
@@ -589,6 +604,24 @@ BEVBERT_API int bevbert_segment_wsum(const void* src, const int* rowptr, const i
     return BB_EUNSUPPORTED;
   }
   BB_CHECK_LAUNCH("segment_wsum");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_accum_partials(const void* partials, float* sink, int S, int64_t n, int dtype,
+                                       hipStream_t stream) {
+  BB_REQUIRE(n % 4 == 0 && S >= 1, "accum_partials: n must be a multiple of 4 and S >= 1");
+  if (n == 0) return BB_OK;
+  size_t nb = ((size_t)n / 4 + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL(accum_partials_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)partials, sink, S, (size_t)n / 4);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL(accum_partials_kernel<bf16_raw>, dim3(nb), dim3(256), 0, stream, (const bf16_raw*)partials, sink, S, (size_t)n / 4);
+  else {
+    bb_set_error("accum_partials: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("accum_partials");
   return BB_OK;
 }
 

@@ -83,6 +83,38 @@ def _gemm(kind, fn, m, n, k):
     return out
 
 
+def _split_k(M, N, K):
+    """Number of token-axis chunks for a weight-gradient GEMM dW(N x K) = dy^T(N x M) x(M x K).
+
+    The output is small (9..36 tiles of 256x256) and the reduction axis M is long (5 120 .. 28 224 tokens), so a plain
+    GEMM leaves most of the 256 CUs idle (measured 140-250 TFLOP/s); a batched GEMM over S chunks of M fills them
+    (600-880 TFLOP/s, scripts/bench_wgrad.py).  Aim at 144-256 workgroups, keep >= 640 tokens per chunk."""
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    s = 1
+    while s * 2 <= min(16, M // 640) and s * 2 * tiles <= 256 and M % (s * 2) == 0:
+        s *= 2
+    return s
+
+
+def _wgrad_into(sink, dy2, x2):
+    """sink (fp32 arena view, N x K) += dy2^T @ x2 with host-side split-K and a fused partial-sum + accumulate."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    if dy2.dtype == torch.float32:
+        _gemm("wgrad", lambda: sink.addmm_(dy2.t(), x2), N, K, M)
+        return
+    S = _split_k(M, N, K)
+    if S > 1 and dy2.is_contiguous() and x2.is_contiguous():
+        part = _gemm("wgrad", lambda: torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)), N, K, M)
+    else:
+        S = 1
+        part = _gemm("wgrad", lambda: dy2.t().mm(x2), N, K, M)
+    if (N * K) % 4 == 0:
+        call("bevbert_accum_partials", ptr(part), ptr(sink), S, N * K, dtype_code(part), stream())
+    else:
+        sink.add_(part if S == 1 else part.sum(0))
+
+
 def _sink(param):
     """fp32 accumulation target of a parameter, or None for plain tensors."""
     return getattr(param, "main_grad", None)
@@ -260,10 +292,7 @@ class _Linear(torch.autograd.Function):
             sink = _sink(weight)
             if sink is not None:
                 _mark_touched(weight)
-                if dy2.dtype == torch.float32:
-                    _gemm("wgrad", lambda: sink.addmm_(dy2.t(), x2), N, K, M)
-                else:
-                    sink.add_(_gemm("wgrad", lambda: dy2.t().mm(x2), N, K, M))
+                _wgrad_into(sink, dy2, x2)
             else:
                 gw = dy2.t().mm(x2).to(weight.dtype)
         if bias is not None and bias.requires_grad:
@@ -330,10 +359,7 @@ class _LinearPacked(torch.autograd.Function):
         dx = _gemm("dgrad", lambda: dy2.mm(pw.compute), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
         if pw.requires_grad:
             pw.touch()
-            if dy2.dtype == torch.float32:
-                _gemm("wgrad", lambda: pw.main_grad.addmm_(dy2.t(), x2), N, K, M)
-            else:
-                pw.main_grad.add_(_gemm("wgrad", lambda: dy2.t().mm(x2), N, K, M))
+            _wgrad_into(pw.main_grad, dy2, x2)
             pb.touch()
             C = dy2.shape[1]
             ws = RT.workspace(dy.device, 512 * C)
