@@ -83,12 +83,18 @@ def _gemm(kind, fn, m, n, k):
     return out
 
 
+import os as _os
+_SPLITK_ENABLED = _os.environ.get("BEVBERT_SPLITK", "1") == "1"     # A/B knob
+
+
 def _split_k(M, N, K):
     """Number of token-axis chunks for a weight-gradient GEMM dW(N x K) = dy^T(N x M) x(M x K).
 
     The output is small (9..36 tiles of 256x256) and the reduction axis M is long (5 120 .. 28 224 tokens), so a plain
     GEMM leaves most of the 256 CUs idle (measured 140-250 TFLOP/s); a batched GEMM over S chunks of M fills them
     (600-880 TFLOP/s, scripts/bench_wgrad.py).  Aim at 144-256 workgroups, keep >= 640 tokens per chunk."""
+    if not _SPLITK_ENABLED:
+        return 1
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     s = 1
     while s * 2 <= min(16, M // 640) and s * 2 * tiles <= 256 and M % (s * 2) == 0:
