@@ -225,17 +225,23 @@ def main():
                           "by_kernel": dict(sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:12]),
                           "by_gemm": dict(sorted(gemm_rows.items(), key=lambda kv: -kv[1]["ms"])[:24])}
         dom_key, dom = max(rows.items(), key=lambda kv: kv[1]["ms"])
+        traffic = None       # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if measured
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f).get(dom_key)
+        except Exception:
+            pass
         secs = dom["ms"] / 1e3
         if dom["gflop"] > 0:
             ach = dom["gflop"] / 1e3 / secs
             out["roofline"] = {"kernel": dom_key, "bound": "mfma", "achieved": round(ach, 2),
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                                "avg_launch_us": dom["avg_us"], "launches": dom["launches"]}
         else:
             ach = dom["mb"] / 1e3 / secs
             out["roofline"] = {"kernel": dom_key, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "avg_launch_us": dom["avg_us"], "launches": dom["launches"]}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
