@@ -12,8 +12,10 @@
  *     available from bevbert_last_error() (thread-local);
  *   - dtype codes: 0 = float32, 1 = bfloat16, 2 = float16; parameters (bias, gamma, beta) and statistics are always
  *     float32; arithmetic is float32 everywhere except the MFMA operands of the bf16 attention path;
- *   - dropout masks are a pure function of (seed, offset + flat element index): backward entries regenerate the
- *     forward's mask from the same (seed, offset) instead of storing it.
+ *   - dropout masks are a pure function of (seed, offset, flat element index) -- a 32-bit site key from (seed, offset),
+ *     16 random bits per element, two elements per 32-bit mix: backward entries regenerate the forward's mask from
+ *     the same (seed, offset) instead of storing it.  Attention indexes its elements as
+ *     ((b*nh + h)*Lq + q) * Lk2 + k with Lk2 = Lk rounded up to even.
  */
 #ifndef BEVBERT_HIP_H
 #define BEVBERT_HIP_H
