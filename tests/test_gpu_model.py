@@ -97,6 +97,7 @@ def _check_tasks(env, cfg, tag, keys_file, dtype, check_grads=False):
         for task in ("mlm", "sap", "masksem"):
             arena.zero_grad()
             model(mk(task), task).mean().backward()
+            arena.sync()
             sq = float((arena.grads.double() ** 2).sum())
             ref_sq = float(g[f"{task}_grad_sqnorm"])
             assert abs(sq - ref_sq) < (2e-3 if fp32 else 5e-2) * ref_sq, (task, sq, ref_sq)
@@ -166,6 +167,7 @@ def test_object_token_tasks(env, tag, kw, tasks, dtype):
         loss = model(b, task)
         cmp(loss, g[f"{task}_loss"], f"{task}_loss")
         loss.mean().backward()
+        arena.sync()
         with torch.no_grad():
             outs = model(b, task, compute_loss=False)
         if task == "og":

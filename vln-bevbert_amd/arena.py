@@ -131,7 +131,18 @@ class ParamArena:
             call("bevbert_cast_f32", ptr(self.params), ptr(self.shadow), self.numel, lib.dtype_code(self.compute_dtype),
                  stream())
 
+    def sync(self):
+        """Make the current stream wait for the model's side-stream branches (ops.Branches).  Backward kernels write
+        parameter gradients straight into ``grads`` as a side effect autograd does not see, so whoever reads or
+        overwrites the arena next (optimiser, all-reduce, zero_grad, a test) must order itself after them."""
+        if self.device.type == "cuda":
+            from . import ops
+            cur = torch.cuda.current_stream(self.device)
+            for side in ops.Branches.side_streams():
+                cur.wait_stream(side)
+
     def zero_grad(self):
+        self.sync()
         self.grads.zero_()
 
     def load_state_dict_into(self, module, sd, strict=True):
@@ -142,6 +153,7 @@ class ParamArena:
     # ---- optimiser ---------------------------------------------------------------------------
     def clip_and_step(self, lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_norm=5.0, grad_pre_scale=1.0):
         """clip_grad_norm_(max_norm) + AdamW.step (train_r2r.py:295-313) in three launches, no host sync."""
+        self.sync()
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.params)
             self.exp_avg_sq = torch.zeros_like(self.params)

@@ -11,6 +11,7 @@ parameter, so there are no per-parameter AccumulateGrad kernels, no bucket copie
 optimiser sees one flat buffer.  Plain tensors (unit tests) get ordinary returned gradients.
 """
 import math
+import os as _os
 
 import torch
 import torch.nn.functional as F
@@ -43,7 +44,8 @@ class _Runtime:
         self.offset = 0
 
     def workspace(self, device, nfloats):
-        key = (device.index, "ws")
+        # one scratch buffer per (device, stream): branches of the model run concurrently on separate streams
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
         buf = self._ws.get(key)
         if buf is None or buf.numel() < nfloats:
             buf = torch.empty(max(int(nfloats), 512 * 3 * 3072), dtype=torch.float32, device=device)
@@ -52,6 +54,51 @@ class _Runtime:
 
 
 RT = _Runtime()
+
+
+class Branches:
+    """Two-stream execution of independent model branches (MI355X: kernels of the small text / panorama / global-map
+    branches do not fill 256 CUs; overlapping them with each other and with the BEV branch does).
+
+    ``fork()`` makes the side stream wait for everything enqueued so far on the current stream; code inside
+    ``with br.side():`` is enqueued on the side stream; ``join(*tensors)`` makes the current stream wait for the side
+    stream and tells the caching allocator that the given side-allocated tensors are now used on the current stream.
+    Autograd replays every backward op on the stream its forward ran on and inserts the cross-stream waits itself."""
+
+    enabled = _os.environ.get("BEVBERT_STREAMS", "1") == "1"
+    _streams = {}
+
+    def __init__(self, device):
+        self.device = device
+        self.on = Branches.enabled and device.type == "cuda"
+        if self.on:
+            key = device.index
+            if key not in Branches._streams:
+                Branches._streams[key] = torch.cuda.Stream(device)
+            self.stream = Branches._streams[key]
+            self.main = torch.cuda.current_stream(device)
+
+    @classmethod
+    def side_streams(cls):
+        return list(cls._streams.values())
+
+    def fork(self, *tensors):
+        if self.on:
+            self.stream.wait_stream(self.main)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.stream)
+
+    def side(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.on else contextlib.nullcontext()
+
+    def join(self, *tensors):
+        if self.on:
+            self.main.wait_stream(self.stream)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
 TRACE = None     # dict name -> [(start_event, end_event)] while bench.py's kernel-timing pass is active
 
 
@@ -83,7 +130,6 @@ def _gemm(kind, fn, m, n, k):
     return out
 
 
-import os as _os
 _SPLITK_ENABLED = _os.environ.get("BEVBERT_SPLITK", "1") == "1"     # A/B knob
 
 

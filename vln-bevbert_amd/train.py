@@ -82,6 +82,8 @@ class GradReducer:
         view = self.flat[lo:hi]
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())     # everything enqueued so far has produced `view`
+            for side in ops.Branches.side_streams():                 # ... including the model's side-stream branches
+                self.stream.wait_stream(side)
             with torch.cuda.stream(self.stream):
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -138,6 +140,7 @@ class PretrainTrainer:
         loss_vec = self.model(batch, task, compute_loss=True)
         loss = loss_vec.mean()                                                   # train_r2r.py:263
         loss.backward()
+        self.arena.sync()                      # side-stream branches have written their gradients
         self.reducer.finish()
         lr = warmup_linear_lr(self.global_step, self.lr, self.warmup, self.total)
         self.arena.clip_and_step(lr, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)

@@ -611,41 +611,61 @@ class GlocalTextPathCMT(nn.Module):
                 bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, return_gmap_embeds=True, view_lens_host=None,
                 obj_lens_host=None):
         has_obj = traj_obj_img_fts is not None
-        txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
+        br = ops.Branches(txt_ids.device)
         gmap_embeds = obj_embeds = obj_masks = traj = None
-        if return_gmap_embeds or has_obj:
-            traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts,
-                              traj_vp_obj_lens)
+        need_traj = return_gmap_embeds or has_obj
+        # side stream: panorama encoder (independent of the text);  current stream: text encoder
+        br.fork(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts, traj_vp_obj_lens)
+        if need_traj:
+            with br.side():
+                traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts,
+                                  traj_vp_obj_lens)
             tok_lens, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host,
                                                       obj_lens_host)
-        if return_gmap_embeds:
-            g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
-                                              gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens)
-            gmap_embeds = self.global_encoder(txt_embeds, txt_masks, g_in, g_masks, gmap_pair_dists)
-        if has_obj:
+        txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
+        if has_obj:             # the object tokens feed the BEV branch: they are needed on the current stream
+            br.join(traj)
             obj_embeds, obj_masks = self._obj_tokens(traj, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens,
                                                      ol_host)
+        # side stream: global-map encoder (tiny kernels);  current stream: BEV encoder (28 224-row kernels)
+        if return_gmap_embeds:
+            br.fork(txt_embeds, txt_masks, gmap_step_ids, gmap_pos_fts, gmap_lens, gmap_pair_dists, traj)
+            with br.side():
+                g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids,
+                                                  traj_cand_vpids, gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens,
+                                                  tok_lens)
+                gmap_embeds = self.global_encoder(txt_embeds, txt_masks, g_in, g_masks, gmap_pair_dists)
         bev_embeds, obj_embeds = self.local_encoder(txt_embeds, txt_masks, bev_fts, bev_pos_fts,
                                                     _all_ones_to_none(bev_masks), bev_nav_masks, obj_embeds, obj_masks)
+        br.join(gmap_embeds)
         return gmap_embeds, bev_embeds, obj_embeds, obj_masks
 
     def forward_mlm(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
                     traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
                     gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
                     bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, view_lens_host=None, obj_lens_host=None):
+        br = ops.Branches(txt_ids.device)
+        br.fork(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts, traj_vp_obj_lens)
+        with br.side():         # panorama encoder next to the text encoder
+            traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts,
+                              traj_vp_obj_lens)
         txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
         tm = neg_key_mask(txt_masks)
-        traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts,
-                          traj_vp_obj_lens)
         tok_lens, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host, obj_lens_host)
-        g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
-                                          gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens)
-        gm = neg_key_mask(g_masks)
-        g_txt = txt_embeds
-        for layer in self.global_encoder.encoder.x_layers:
-            g_txt = layer.forward_lang2visn(g_txt, tm, g_in, gm)
+        # side stream: text queries over the global map;  current stream: text queries over the BEV (+ objects)
+        br.fork(txt_embeds, tm, gmap_step_ids, gmap_pos_fts, gmap_lens)
+        with br.side():
+            g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
+                                              gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens)
+            gm = neg_key_mask(g_masks)
+            g_txt = txt_embeds
+            for layer in self.global_encoder.encoder.x_layers:
+                g_txt = layer.forward_lang2visn(g_txt, tm, g_in, gm)
         bev_in = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
-        obj_embeds, obj_masks = self._obj_tokens(traj, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, ol_host)
+        obj_embeds = obj_masks = None
+        if traj_obj_img_fts is not None:
+            br.join(traj)
+            obj_embeds, obj_masks = self._obj_tokens(traj, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, ol_host)
         bev_in, bev_obj_masks = self.local_encoder.with_objects(bev_in, _all_ones_to_none(bev_masks), obj_embeds,
                                                                 obj_masks)
         bev_in = bev_in.contiguous()
@@ -653,6 +673,7 @@ class GlocalTextPathCMT(nn.Module):
         b_txt = txt_embeds
         for layer in self.local_encoder.encoder.x_layers:
             b_txt = layer.forward_lang2visn(b_txt, tm, bev_in, bm)
+        br.join(g_txt)
         return g_txt + b_txt
 
     def forward_sem(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
