@@ -65,7 +65,10 @@ class Branches:
     stream and tells the caching allocator that the given side-allocated tensors are now used on the current stream.
     Autograd replays every backward op on the stream its forward ran on and inserts the cross-stream waits itself."""
 
-    enabled = _os.environ.get("BEVBERT_STREAMS", "1") == "1"
+    # measured on MI355X (in-run A/B, batch 64): 26.9-27.9 ms/step with the side stream vs 23.7-24.8 without --
+    # the 28 224-row GEMMs already fill the chip and the extra cross-stream waits cost more than the overlap buys,
+    # so the side stream is OFF by default (BEVBERT_STREAMS=1 turns it on, e.g. for small batches)
+    enabled = _os.environ.get("BEVBERT_STREAMS", "0") == "1"
     _streams = {}
 
     def __init__(self, device):
