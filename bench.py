@@ -187,10 +187,12 @@ def main():
         "final_loss": round(float(losses[-1].item()), 4),
     }
 
-    if rank == 0 and not a.no_kernel_pass:
-        # ---- per-kernel timing pass (not part of the timed region above): HIP events around every C-ABI launch
+    if not a.no_kernel_pass:
+        # ---- per-kernel timing pass (not part of the timed region above): HIP events around every C-ABI launch.
+        # Every rank runs the three steps (they contain the gradient all-reduce); only rank 0 records.
         log("kernel timing pass")
-        ops.TRACE = {}
+        if rank == 0:
+            ops.TRACE = {}
         prof_start = torch.cuda.Event(enable_timing=True)
         prof_end = torch.cuda.Event(enable_timing=True)
         prof_start.record()
@@ -198,6 +200,7 @@ def main():
             trainer.step(t, batches[t][0])
         prof_end.record()
         torch.cuda.synchronize()
+    if rank == 0 and not a.no_kernel_pass:
         trace, ops.TRACE = ops.TRACE, None
         total_ms = prof_start.elapsed_time(prof_end)
         rows = {}

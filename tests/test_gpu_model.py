@@ -332,3 +332,36 @@ def test_training_step_bf16_full_size_runs_and_learns(env):
     for t in ("mlm", "masksem"):
         bb = synthetic.batch_to(synthetic.make_batch(cfg, t, 8, seed=10, sems_as="ids"), DEV)
         assert np.isfinite(float(trainer.step(t, bb)))
+
+
+def test_rccl_reducer_path_single_rank(env):
+    """The data-parallel exchange (side stream, text-embedding hook, in-place all-reduce of arena slices) on real RCCL
+    with a one-rank group: the collectives are identities, so the run must match one without them bit for bit."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from vln_bevbert_amd import weights
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from vln_bevbert_amd.train import PretrainTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+        results = []
+        for force in (False, True):
+            model = GlocalTextPathCMTPreTraining(cfg)
+            model.load_state_dict(weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
+            model.tie_weights()
+            arena = model.finalize(DEV, torch.bfloat16)
+            model.train()
+            model.set_dropout(0.1)
+            tr = PretrainTrainer(model, arena, warmup_steps=2, num_train_steps=20, force_collectives=force)
+            assert tr.reducer.active == force and tr.overlap == force
+            for i, task in enumerate(("sap", "mlm", "masksem", "sap")):
+                tr.step(task, synthetic.batch_to(synthetic.make_batch(cfg, task, 2, seed=80 + i, ragged=True), DEV))
+            torch.cuda.synchronize()
+            results.append(arena.params.clone())
+        assert torch.equal(results[0], results[1])
+    finally:
+        dist.destroy_process_group()

@@ -66,13 +66,15 @@ class TaskSampler:
 class GradReducer:
     """In-place SUM all-reduce of a flat gradient buffer in [split, end) then [0, split) (see module docstring)."""
 
-    def __init__(self, flat_grads, split, group=None):
+    def __init__(self, flat_grads, split, group=None, force=False):
+        """force=True issues the collectives even for a single-rank group (used to exercise the RCCL path on one GPU)."""
         self.flat = flat_grads
         self.split = int(split)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         self.cuda = flat_grads.is_cuda
-        self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self.stream = torch.cuda.Stream() if (self.cuda and self.active) else None
         self._works = []
         self._phase_a_done = False
 
@@ -91,13 +93,13 @@ class GradReducer:
 
     def phase_a(self, *_):
         """Call when every gradient in [split, end) has been enqueued (tensor hook on the text embeddings)."""
-        if self.world > 1 and not self._phase_a_done:
+        if self.active and not self._phase_a_done:
             self._phase_a_done = True
             self._launch(self.split, self.flat.numel())
 
     def finish(self):
         """Call after backward: reduces what phase A did not cover and joins the side stream."""
-        if self.world > 1:
+        if self.active:
             if not self._phase_a_done:
                 self._launch(0, self.flat.numel())
             else:
@@ -112,7 +114,8 @@ class GradReducer:
 
 class PretrainTrainer:
     def __init__(self, model, arena, learning_rate=5e-5, warmup_steps=10000, num_train_steps=100000,
-                 betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0, seed=0, rank=0, world_size=1, overlap=True):
+                 betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0, seed=0, rank=0, world_size=1, overlap=True,
+                 force_collectives=False):
         self.model, self.arena = model, arena
         self.lr, self.warmup, self.total = learning_rate, warmup_steps, num_train_steps
         self.betas, self.wd, self.grad_norm = betas, weight_decay, grad_norm
@@ -122,8 +125,8 @@ class PretrainTrainer:
                         if n.startswith("bert.local_encoder") or n.startswith("bert.global_encoder")
                         or not n.startswith("bert."))
         # the arena keeps registration order: embeddings, lang_encoder, img_embeddings come before the map encoders
-        self.reducer = GradReducer(arena.grads, first_map)
-        self.overlap = overlap and world_size > 1
+        self.reducer = GradReducer(arena.grads, first_map, force=force_collectives)
+        self.overlap = overlap and self.reducer.active
         if self.overlap:
             model.bert.lang_encoder.register_forward_hook(self._hook_text)
 
