@@ -6,7 +6,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless marked "host"; the caller owns all memory, nothing is allocated,
- *     retained or freed here; no global state => re-entrant, thread-safe per stream;
+ *     retained or freed here; the only global state is bevbert_gemm's mutex-guarded plan cache (library handle +
+ *     per-shape descriptors) => re-entrant, thread-safe per stream;
  *   - `stream` is a hipStream_t (PyTorch-ROCm: torch.cuda.current_stream().cuda_stream); launches are asynchronous;
  *   - return value 0 = ok, <0 = error (-1 invalid argument, -2 launch failure, -3 unsupported); the message is
  *     available from bevbert_last_error() (thread-local);
@@ -142,6 +143,41 @@ int bevbert_cast_f32(const float* src, void* dst, int64_t n, int dst_dtype, hipS
 /* sink[i] += sum_{s<S} partials[s*n + i]: reduction of the host-side split-K weight-gradient GEMMs (library batched
  * GEMM over S chunks of the token axis), fused with the accumulation into the fp32 gradient arena. */
 int bevbert_accum_partials(const void* partials, float* sink, int S, int64_t n, int dtype, hipStream_t stream);
+
+/* ---- library GEMM (hipBLASLt) with cached per-shape plans ---------------------------------------------------------
+ * Replaces every nn.Linear matmul of the path (pretrain_src/model/vilmodel.py:92-94,314-316 query/key/value,
+ * :146,:171,:185,:247,:261,:281 dense/decoder layers, :469-475,:542,:577-581,:621 input projections;
+ * pretrain_cmt.py:38-68 prediction heads) and their two backward GEMMs, which PyTorch dispatches to the same
+ * library at ~4x the host cost per call.
+ *   C[M x N] = alpha * op(A)[M x K] . op(B)[K x N] (+ bias[N]),  row-major, optionally strided-batched.
+ *   opA == 0: A stored M x K with row stride lda;  opA == 1: A stored K x M (row stride lda), used transposed.
+ *   opB == 0: B stored K x N with row stride ldb;  opB == 1: B stored N x K (row stride ldb), used transposed.
+ * in_dtype in {F32, BF16}; out_dtype == in_dtype or F32; bias (may be NULL) has dtype bias_dtype (F32 or out_dtype).
+ * autotune > 1: on the first call of a shape, time the library's top `autotune` (<= 64) heuristic candidates on the
+ * given operands (the product is recomputed, beta == 0) and keep the fastest.  Returns BB_EUNSUPPORTED (-3) when the
+ * library has no kernel for the problem.
+ * bevbert_gemm_plan / bevbert_gemm_run split the same call in two so that the per-call path carries 8 arguments:
+ * plan returns an id >= 0 (cached by problem; bias_dtype < 0 = no bias; accumulate != 0: C += product, used by the
+ * weight-gradient GEMMs that add into the fp32 gradient arena) or a negative error; run executes it (and autotunes
+ * on its first call).  `workspace_bytes` at run time must be >= the value the plan was made with. */
+int bevbert_gemm(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int opA, int opB,
+                 int64_t lda, int64_t ldb, int64_t ldc, int batch, int64_t stride_a, int64_t stride_b,
+                 int64_t stride_c, int in_dtype, int out_dtype, int bias_dtype, float alpha, void* workspace,
+                 int64_t workspace_bytes, int autotune, hipStream_t stream);
+int bevbert_gemm_plan(int M, int N, int K, int opA, int opB, int64_t lda, int64_t ldb, int64_t ldc, int batch,
+                      int64_t stride_a, int64_t stride_b, int64_t stride_c, int in_dtype, int out_dtype, int bias_dtype,
+                      int accumulate, int64_t workspace_bytes, int autotune);
+int bevbert_gemm_run(int plan, const void* A, const void* B, void* C, const void* bias, void* workspace,
+                     int64_t workspace_bytes, hipStream_t stream);
+int bevbert_gemm_plan_count(void);
+
+/* y = residual + dropout(x) over n (multiple of 4) elements; residual may be NULL, y may alias x when the dtypes match.
+ * Replaces the bare nn.Dropout sites of the path: feature dropout of the loader's fp32 features fused with their cast
+ * to the compute dtype (pretrain_cmt.py:102-106 drop_feats; map_nav_src/models/model.py:30-36), the embedding dropout
+ * (vilmodel.py:76, :494-496) and the two residual dropouts of TransformerEncoderLayer.forward_pre
+ * (transformer.py:170-182).  The backward of x is the same call on dy with residual = NULL. */
+int bevbert_dropout_add(const void* x, const void* residual, void* y, int64_t n, int in_dtype, int out_dtype,
+                        float drop_p, uint64_t seed, uint64_t offset, hipStream_t stream);
 
 /* test hook: keep-mask (uint8) the kernels derive for n consecutive elements starting at `offset` */
 int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p, uint64_t seed, uint64_t offset,

@@ -423,3 +423,83 @@ def test_grad_clip_coefficient(ops):
     assert abs(float(arena.grad_norm()) - norm) < 1e-3 * norm
     coef = float(arena._scalars[1])
     assert abs(coef - 0.5 * min(1.0, 5.0 / (norm + 1e-6))) < 1e-6
+
+
+# ----------------------------------------------------------------------------- library GEMM through the C ABI
+GEMM_CASES = [  # (rows, out_features, in_features)
+    (5120, 768, 768), (28224, 2304, 768), (28224, 768, 3072), (3, 1, 768), (130, 40, 768), (2352, 768, 2048),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lt_gemm_linear_fwd_dgrad_wgrad(ops, M, N, K, dtype):
+    """bevbert_gemm (direct hipBLASLt) against fp64 matmuls for the three GEMMs of a Linear layer."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(DEV, dtype)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV, dtype)
+    b = torch.randn(N, generator=g).to(DEV, dtype)
+    dy = torch.randn(M, N, generator=g).to(DEV, dtype)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    from vln_bevbert_amd import lib
+    before = lib.load().bevbert_gemm_plan_count()
+    y = ops._linear_fwd(x, w, b)
+    ref = x.double() @ w.double().t() + b.double()
+    assert y.dtype == dtype and rel_err(y, ref) < tol
+    dx = ops._linear_dgrad(dy, w)
+    assert rel_err(dx, dy.double() @ w.double()) < tol
+    dw = ops._linear_wgrad(dy, x)
+    assert rel_err(dw, dy.double().t() @ x.double()) < tol
+    if not ops._LT_UNSUPPORTED:
+        assert lib.load().bevbert_gemm_plan_count() >= before + 3      # the C-ABI path ran, not torch
+    # cached plan: same answer on the second call, and a strided (row-sliced) input is honoured
+    assert torch.equal(ops._linear_fwd(x, w, b), y)
+    wide = torch.randn(M, K + 64, generator=g).to(DEV, dtype)
+    ys = ops._linear_fwd(wide[:, :K], w, None)
+    assert rel_err(ys, wide[:, :K].double() @ w.double().t()) < tol
+
+
+def test_lt_gemm_split_k_wgrad_into_sink(ops):
+    """Strided-batch split-K partials + fused accumulate == one big dW GEMM (bf16 operands, fp32 sink)."""
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 28224, 768, 768
+    x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    dy = (torch.randn(M, N, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    sink = torch.ones(N, K, device=DEV)
+    assert ops._split_k(M, N, K) > 1
+    ops._wgrad_into(sink, dy, x)
+    ref = 1.0 + dy.double().t() @ x.double()
+    assert rel_err(sink, ref) < 1e-2
+    sink32 = torch.ones(N, K, device=DEV)
+    ops._wgrad_into(sink32, dy.float(), x.float())
+    assert rel_err(sink32, 1.0 + dy.float().double().t() @ x.float().double()) < 1e-4
+
+
+@pytest.mark.parametrize("in_dtype,out_dtype", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                                (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_dropout_add_matches_exported_mask(ops, in_dtype, out_dtype, with_res):
+    """y = residual + dropout(x) against the library's own keep-mask hook (same (seed, offset) stream), fwd + bwd."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 5, 768, generator=g).to(DEV, in_dtype).requires_grad_(True)
+    res = torch.randn(37, 5, 768, generator=g).to(DEV, out_dtype).requires_grad_(True) if with_res else None
+    p = 0.1
+    ops.RT.new_step(1234)
+    ops.RT.offset = 4096
+    y = ops.dropout(x, p, True, residual=res, out_dtype=out_dtype)
+    keep = ops.dropout_keep_mask(x.numel(), p, 1234, 4096, DEV).view_as(x).float()
+    assert 0.88 < float(keep.mean()) < 0.92
+    ref = x.detach().float() * keep / (1 - p)
+    if with_res:
+        ref = ref + res.detach().float()
+    tol = 1e-6 if out_dtype == torch.float32 else 1e-2
+    assert y.dtype == out_dtype and rel_err(y, ref) < tol
+    dy = torch.randn(y.shape, generator=g).to(DEV, out_dtype)
+    grads = torch.autograd.grad(y, (x, res) if with_res else (x,), dy)
+    assert grads[0].dtype == in_dtype and rel_err(grads[0], dy.float() * keep / (1 - p)) < tol
+    if with_res:
+        assert torch.equal(grads[1], dy)
+    # eval mode / p == 0: identity (+ cast, + residual)
+    y0 = ops.dropout(x, p, False, residual=res, out_dtype=out_dtype)
+    ref0 = x.detach().to(out_dtype) if not with_res else res.detach() + x.detach().to(out_dtype)
+    assert torch.equal(y0.detach(), ref0)

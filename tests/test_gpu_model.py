@@ -336,9 +336,9 @@ def test_training_step_bf16_full_size_runs_and_learns(env):
 
 def test_rccl_reducer_path_single_rank(env):
     """The data-parallel exchange (side stream, text-embedding hook, in-place all-reduce of arena slices) on real RCCL
-    with a one-rank group: the collectives are identities, so the run must match one without them (up to the
-    run-to-run noise of the fp32 atomics in the embedding / graph-bias gradients, which Adam's sign-like first steps
-    turn into at most +-lr per step on near-zero gradients)."""
+    with a one-rank group: the collectives are identities, so the run must match one without them.  Every dropout
+    mask comes from the library's counter-based stream (seed, step), so two runs differ only by the summation order
+    of the fp32 atomics in the embedding / graph-bias gradients (measured: <= 1e-8 on 1-3 of 52 M parameters)."""
     import os
     import socket
     import torch.distributed as dist
@@ -364,7 +364,6 @@ def test_rccl_reducer_path_single_rank(env):
                 tr.step(task, synthetic.batch_to(synthetic.make_batch(cfg, task, 2, seed=80 + i, ragged=True), DEV))
             torch.cuda.synchronize()
             results.append(arena.params.clone())
-        assert float((results[0] - results[1]).abs().max()) < 5e-4
-        assert float((results[0] - results[1]).abs().mean()) < 1e-6
+        assert float((results[0] - results[1]).abs().max()) < 1e-6
     finally:
         dist.destroy_process_group()

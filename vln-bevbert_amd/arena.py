@@ -137,9 +137,11 @@ class ParamArena:
         overwrites the arena next (optimiser, all-reduce, zero_grad, a test) must order itself after them."""
         if self.device.type == "cuda":
             from . import ops
-            cur = torch.cuda.current_stream(self.device)
-            for side in ops.Branches.side_streams():
-                cur.wait_stream(side)
+            sides = ops.Branches.side_streams()
+            if sides:
+                cur = torch.cuda.current_stream(self.device)
+                for side in sides:
+                    cur.wait_stream(side)
 
     def zero_grad(self):
         self.sync()

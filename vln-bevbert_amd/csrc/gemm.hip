@@ -1,0 +1,246 @@
+// Library GEMMs (hipBLASLt) behind the C ABI, with cached per-shape plans.
+//
+// The Linear layers of the path stay on the vendor BLAS (north star: hand-written MFMA only for the attention
+// contractions).  Going through PyTorch's dispatcher costs ~28 us of HOST time per GEMM (at ~330 GEMMs per training step
+// that is 9 ms, and the step is host-bound at batch 64), so the path calls hipBLASLt directly: one hash lookup, one
+// attribute write for the bias pointer, one hipblasLtMatmul.  Plans (descriptor + layouts + algorithm) are created on
+// first use; the algorithm is the fastest of the library's top `autotune` heuristic candidates, timed once on the real operands
+// (beta == 0 products are simply recomputed in place; accumulating plans are timed into a temporary).
+//
+// Row-major convention of the entry point:
+//   C[M x N] = alpha * op(A)[M x K] . op(B)[K x N] (+ bias[N] broadcast over rows),   batch-strided optionally
+//   opA == 0: A is stored M x K (lda);  opA == 1: A is stored K x M (lda) and used transposed.  Same for B (K x N / N x K).
+// hipBLASLt is column-major, so the call is issued as C^T = op(B)^T . op(A)^T on the same memory.
+#include <hipblaslt/hipblaslt.h>
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  std::vector<hipblasLtMatmulHeuristicResult_t> cand;   // untimed candidates until the first run
+  int64_t ws_limit = 0;
+  size_t c_bytes = 0;
+  int id = -1;
+  bool ok = false, tuned = false, has_bias = false, accumulate = false;
+};
+
+hipblasLtHandle_t g_handle = nullptr;
+std::mutex g_mu;
+std::unordered_map<std::string, Plan> g_plans;
+
+hipDataType hip_dtype(int dt) { return dt == BB_F32 ? HIP_R_32F : (dt == BB_BF16 ? HIP_R_16BF : HIP_R_16F); }
+
+bool layout(hipblasLtMatrixLayout_t* l, hipDataType t, uint64_t rows, uint64_t cols, int64_t ld, int batch,
+            int64_t stride) {
+  if (hipblasLtMatrixLayoutCreate(l, t, rows, cols, ld) != HIPBLAS_STATUS_SUCCESS) return false;
+  if (batch > 1) {
+    int32_t bc = batch;
+    if (hipblasLtMatrixLayoutSetAttribute(*l, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)) != HIPBLAS_STATUS_SUCCESS) return false;
+    if (hipblasLtMatrixLayoutSetAttribute(*l, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &stride, sizeof(stride)) != HIPBLAS_STATUS_SUCCESS) return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+namespace {
+
+std::vector<Plan*> g_plan_list;   // plan id -> plan (ids are handed to the host so that the per-call path is 8 arguments)
+
+struct Problem {
+  int M, N, K, opA, opB;
+  int64_t lda, ldb, ldc;
+  int batch;
+  int64_t sa, sb, sc;
+  int in_dtype, out_dtype, bias_dtype;   // bias_dtype < 0: no bias
+  int accumulate;                        // C += product (beta = 1) instead of C = product
+};
+
+int make_plan(const Problem& q, int64_t workspace_bytes, int autotune) {
+  char keybuf[256];
+  snprintf(keybuf, sizeof(keybuf), "%d.%d.%d.%d.%d.%ld.%ld.%ld.%d.%ld.%ld.%ld.%d.%d.%d.%d", q.M, q.N, q.K, q.opA, q.opB,
+           (long)q.lda, (long)q.ldb, (long)q.ldc, q.batch, (long)q.sa, (long)q.sb, (long)q.sc, q.in_dtype,
+           q.out_dtype, q.bias_dtype, q.accumulate);
+  const std::string key(keybuf);
+  if (g_handle == nullptr && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) {
+    bb_set_error("gemm: hipblasLtCreate failed");
+    return BB_ELAUNCH;
+  }
+  auto it = g_plans.find(key);
+  if (it != g_plans.end()) return it->second.id;
+  Plan p;
+  const hipDataType tin = hip_dtype(q.in_dtype), tout = hip_dtype(q.out_dtype);
+  bool good = hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
+  // column-major view: first operand comes from B, second from A (see the header comment)
+  const hipblasOperation_t ta = q.opB ? HIPBLAS_OP_T : HIPBLAS_OP_N, tb = q.opA ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+  good = good && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)) == HIPBLAS_STATUS_SUCCESS;
+  good = good && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)) == HIPBLAS_STATUS_SUCCESS;
+  if (q.bias_dtype >= 0) {
+    const hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_BIAS;
+    const hipDataType bt = hip_dtype(q.bias_dtype);
+    good = good && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep)) == HIPBLAS_STATUS_SUCCESS;
+    good = good && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)) == HIPBLAS_STATUS_SUCCESS;
+  }
+  // first operand: opB == 0 -> view (N x K, ld ldb) used as is; opB == 1 -> view (K x N, ld ldb) used transposed
+  good = good && (q.opB ? layout(&p.la, tin, q.K, q.N, q.ldb, q.batch, q.sb) : layout(&p.la, tin, q.N, q.K, q.ldb, q.batch, q.sb));
+  // second operand: opA == 0 -> view (K x M, ld lda); opA == 1 -> view (M x K, ld lda) used transposed
+  good = good && (q.opA ? layout(&p.lb, tin, q.M, q.K, q.lda, q.batch, q.sa) : layout(&p.lb, tin, q.K, q.M, q.lda, q.batch, q.sa));
+  good = good && layout(&p.lc, tout, q.N, q.M, q.ldc, q.batch, q.sc);
+  const int want = autotune > 1 ? (autotune > 64 ? 64 : autotune) : 1;
+  p.cand.resize(want);
+  int found = 0;
+  if (good) {
+    hipblasLtMatmulPreference_t pref = nullptr;
+    good = hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS;
+    const uint64_t wsb = (uint64_t)workspace_bytes;
+    good = good && hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof(wsb)) == HIPBLAS_STATUS_SUCCESS;
+    good = good && hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.la, p.lb, p.lc, p.lc, pref, want, p.cand.data(),
+                                                   &found) == HIPBLAS_STATUS_SUCCESS;
+    if (pref) hipblasLtMatmulPreferenceDestroy(pref);
+  }
+  p.cand.resize(good && found > 0 ? found : 0);
+  p.ok = !p.cand.empty();
+  p.tuned = p.cand.size() <= 1;
+  p.has_bias = q.bias_dtype >= 0;
+  p.accumulate = q.accumulate != 0;
+  p.c_bytes = (size_t)(q.batch > 1 ? q.batch * q.sc : q.M * q.ldc) * (q.out_dtype == BB_F32 ? 4 : 2);
+  p.ws_limit = workspace_bytes;
+  if (p.ok) p.algo = p.cand[0].algo;
+  p.id = (int)g_plan_list.size();
+  Plan* stored = &g_plans.emplace(key, std::move(p)).first->second;   // unordered_map nodes are address-stable
+  g_plan_list.push_back(stored);
+  if (!stored->ok) {
+    bb_set_error("gemm: hipBLASLt has no algorithm for M=%d N=%d K=%d opA=%d opB=%d dtype %d->%d", q.M, q.N, q.K, q.opA,
+                 q.opB, q.in_dtype, q.out_dtype);
+  }
+  return stored->id;
+}
+
+// time the candidates once on the real operands and keep the fastest.  beta == 0: the product is simply recomputed in
+// place; accumulate plans are timed into a temporary so that C is not touched.
+void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, int64_t workspace_bytes,
+               hipStream_t stream) {
+  const float alpha = 1.f, beta0 = p.accumulate ? 1.f : 0.f;
+  void* scratch = nullptr;
+  if (p.accumulate) {
+    if (hipMalloc(&scratch, p.c_bytes) != hipSuccess || hipMemsetAsync(scratch, 0, p.c_bytes, stream) != hipSuccess) {
+      if (scratch) (void)hipFree(scratch);
+      p.algo = p.cand[0].algo;      // cannot time: keep the heuristic's first choice
+      p.tuned = true;
+      return;
+    }
+    C = scratch;
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float best_ms = 1e30f;
+  int best = 0;
+  for (size_t i = 0; i < p.cand.size(); ++i) {
+    if (p.cand[i].state != HIPBLAS_STATUS_SUCCESS || (int64_t)p.cand[i].workspaceSize > workspace_bytes) continue;
+    bool run_ok = true;
+    for (int rep = 0; rep < 6 && run_ok; ++rep) {
+      if (rep == 1) (void)hipEventRecord(e0, stream);
+      run_ok = hipblasLtMatmul(g_handle, p.desc, &alpha, B, p.la, A, p.lb, &beta0, C, p.lc, C, p.lc, &p.cand[i].algo,
+                               workspace, workspace_bytes, stream) == HIPBLAS_STATUS_SUCCESS;
+    }
+    if (!run_ok) continue;
+    (void)hipEventRecord(e1, stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best_ms) { best_ms = ms; best = (int)i; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (scratch) (void)hipFree(scratch);
+  p.algo = p.cand[best].algo;
+  p.tuned = true;
+  p.cand.clear();
+  p.cand.shrink_to_fit();
+}
+
+int run_plan(Plan& p, const void* A, const void* B, void* C, const void* bias, float alpha, void* workspace,
+             int64_t workspace_bytes, hipStream_t stream) {
+  if (!p.ok) {
+    bb_set_error("gemm: plan %d has no algorithm", p.id);
+    return BB_EUNSUPPORTED;
+  }
+  BB_REQUIRE((bias != nullptr) == p.has_bias, "gemm: plan %d was made %s a bias", p.id, p.has_bias ? "with" : "without");
+  BB_REQUIRE(workspace_bytes >= p.ws_limit, "gemm: plan %d needs the %ld-byte workspace it was planned with", p.id, (long)p.ws_limit);
+  if (p.has_bias &&
+      hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) {
+    bb_set_error("gemm: cannot set the bias pointer");
+    return BB_ELAUNCH;
+  }
+  if (!p.tuned) tune_plan(p, A, B, C, workspace, workspace_bytes, stream);
+  const float beta0 = p.accumulate ? 1.f : 0.f;
+  const hipblasStatus_t st = hipblasLtMatmul(g_handle, p.desc, &alpha, B, p.la, A, p.lb, &beta0, C, p.lc, C, p.lc,
+                                             &p.algo, workspace, workspace_bytes, stream);
+  if (st != HIPBLAS_STATUS_SUCCESS) {
+    bb_set_error("gemm: hipblasLtMatmul failed with status %d (plan %d)", (int)st, p.id);
+    return BB_ELAUNCH;
+  }
+  return BB_OK;
+}
+
+int check_problem(const Problem& q) {
+  BB_REQUIRE(q.M > 0 && q.N > 0 && q.K > 0 && q.batch >= 1, "gemm: empty problem M=%d N=%d K=%d batch=%d", q.M, q.N, q.K, q.batch);
+  BB_REQUIRE(q.in_dtype == BB_F32 || q.in_dtype == BB_BF16, "gemm: input dtype %d unsupported", q.in_dtype);
+  BB_REQUIRE(q.out_dtype == BB_F32 || q.out_dtype == q.in_dtype, "gemm: output dtype %d unsupported", q.out_dtype);
+  BB_REQUIRE(q.bias_dtype < 0 || q.bias_dtype == BB_F32 || q.bias_dtype == q.out_dtype, "gemm: bias dtype %d unsupported", q.bias_dtype);
+  return BB_OK;
+}
+
+}  // namespace
+
+// Plan a GEMM: returns a plan id >= 0 (also for problems the library cannot run: bevbert_gemm_run then returns
+// BB_EUNSUPPORTED), or a negative error code.  bias_dtype < 0: no bias epilogue.
+BEVBERT_API int bevbert_gemm_plan(int M, int N, int K, int opA, int opB, int64_t lda, int64_t ldb, int64_t ldc,
+                                  int batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, int in_dtype,
+                                  int out_dtype, int bias_dtype, int accumulate, int64_t workspace_bytes,
+                                  int autotune) {
+  const Problem q{M, N, K, opA, opB, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, in_dtype, out_dtype,
+                  bias_dtype < 0 ? -1 : bias_dtype, accumulate != 0};
+  const int rc = check_problem(q);
+  if (rc != BB_OK) return rc;
+  std::lock_guard<std::mutex> lock(g_mu);
+  return make_plan(q, workspace_bytes, autotune);
+}
+
+BEVBERT_API int bevbert_gemm_run(int plan, const void* A, const void* B, void* C, const void* bias, void* workspace,
+                                 int64_t workspace_bytes, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  BB_REQUIRE(plan >= 0 && plan < (int)g_plan_list.size(), "gemm: unknown plan id %d", plan);
+  return run_plan(*g_plan_list[plan], A, B, C, bias, 1.f, workspace, workspace_bytes, stream);
+}
+
+// One-shot form: plan (cached by problem) + run.
+BEVBERT_API int bevbert_gemm(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int opA,
+                             int opB, int64_t lda, int64_t ldb, int64_t ldc, int batch, int64_t stride_a,
+                             int64_t stride_b, int64_t stride_c, int in_dtype, int out_dtype, int bias_dtype,
+                             float alpha, void* workspace, int64_t workspace_bytes, int autotune,
+                             hipStream_t stream) {
+  const Problem q{M, N, K, opA, opB, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, in_dtype, out_dtype,
+                  bias != nullptr ? bias_dtype : -1, 0};
+  const int rc = check_problem(q);
+  if (rc != BB_OK) return rc;
+  std::lock_guard<std::mutex> lock(g_mu);
+  const int id = make_plan(q, workspace ? workspace_bytes : 0, autotune);
+  if (id < 0) return id;
+  return run_plan(*g_plan_list[id], A, B, C, bias, alpha, workspace, workspace_bytes, stream);
+}
+
+BEVBERT_API int bevbert_gemm_plan_count(void) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  return (int)g_plans.size();
+}

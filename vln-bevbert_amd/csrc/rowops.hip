@@ -408,6 +408,28 @@ __global__ __launch_bounds__(256) void cast_f32_kernel(const float* __restrict__
     st4<TO>(dst + i * 4, *reinterpret_cast<const float4*>(src + i * 4));
 }
 
+// y = residual + dropout(x)   (residual optional; input and output dtypes independent: fuses the fp32 -> bf16 cast of
+// the loader's features into their feature dropout).  Mask = the library's counter-based stream (common.h).
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const TI* __restrict__ x, const TO* __restrict__ residual,
+                                                          TO* __restrict__ y, size_t n4, float keep_scale,
+                                                          uint32_t thr, uint32_t key) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 a = ld4<TI>(x + i * 4);
+    const uint32_t pr = (uint32_t)(i * 2);
+    const uint32_t b0 = bb_pair_bits(key, pr), b1 = bb_pair_bits(key, pr + 1);
+    a.x = bb_keep_lo(b0, thr) ? a.x * keep_scale : 0.f;
+    a.y = bb_keep_hi(b0, thr) ? a.y * keep_scale : 0.f;
+    a.z = bb_keep_lo(b1, thr) ? a.z * keep_scale : 0.f;
+    a.w = bb_keep_hi(b1, thr) ? a.w * keep_scale : 0.f;
+    if (residual != nullptr) {
+      const float4 r = ld4<TO>(residual + i * 4);
+      a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    }
+    st4<TO>(y + i * 4, a);
+  }
+}
+
 // =============================================================================================
 // C ABI
 // =============================================================================================
@@ -679,5 +701,31 @@ BEVBERT_API int bevbert_cast_f32(const float* src, void* dst, int64_t n, int dst
     return BB_EUNSUPPORTED;
   }
   BB_CHECK_LAUNCH("cast_f32");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_dropout_add(const void* x, const void* residual, void* y, int64_t n, int in_dtype,
+                                    int out_dtype, float drop_p, uint64_t seed, uint64_t offset, hipStream_t stream) {
+  BB_REQUIRE(n % 4 == 0 && n < ((int64_t)1 << 32), "dropout_add: n=%ld must be a multiple of 4 below 2^32", (long)n);
+  BB_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "dropout_add: p=%f out of range", drop_p);
+  if (n == 0) return BB_OK;
+  size_t nb = ((size_t)n / 4 + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  const float ks = 1.0f / (1.0f - drop_p);
+  const uint32_t thr = bb_drop_threshold(drop_p), key = bb_site_key(seed, offset);
+#define GO(TI, TO)                                                                                                   \
+  hipLaunchKernelGGL((dropout_add_kernel<TI, TO>), dim3(nb), dim3(256), 0, stream, (const TI*)x, (const TO*)residual, \
+                     (TO*)y, (size_t)n / 4, ks, thr, key)
+  if (in_dtype == BB_F32 && out_dtype == BB_F32) GO(float, float);
+  else if (in_dtype == BB_F32 && out_dtype == BB_BF16) GO(float, bf16_raw);
+  else if (in_dtype == BB_BF16 && out_dtype == BB_BF16) GO(bf16_raw, bf16_raw);
+  else if (in_dtype == BB_F16 && out_dtype == BB_F16) GO(_Float16, _Float16);
+  else if (in_dtype == BB_F32 && out_dtype == BB_F16) GO(float, _Float16);
+  else {
+    bb_set_error("dropout_add: dtype pair %d -> %d unsupported", in_dtype, out_dtype);
+    return BB_EUNSUPPORTED;
+  }
+#undef GO
+  BB_CHECK_LAUNCH("dropout_add");
   return BB_OK;
 }

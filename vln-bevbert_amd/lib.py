@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbevbert_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "capi.hip"]
+SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "gemm.hip", "capi.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bevbert_hip.h")
 
 F32, BF16, F16 = 0, 1, 2
@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-o", LIB_PATH] + srcs
+           "-o", LIB_PATH] + srcs + ["-lhipblaslt"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
@@ -76,6 +76,10 @@ _PROTOS = {
     "bevbert_cast_f32": [_P, _P, _I64, _I, _P],
     "bevbert_accum_partials": [_P, _P, _I, _I64, _I, _P],
     "bevbert_dropout_keep_mask": [_P, _I64, _F, _U64, _U64, _P],
+    "bevbert_gemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I, _I, _I, _F, _P,
+                     _I64, _I, _P],
+    "bevbert_dropout_add": [_P, _P, _P, _I64, _I, _I, _F, _U64, _U64, _P],
+    "bevbert_gemm_run": [_I, _P, _P, _P, _P, _P, _I64, _P],
 }
 
 
@@ -94,6 +98,9 @@ def load():
     lib.bevbert_version.restype = _I
     lib.bevbert_colsum_workspace_floats.restype = _I64
     lib.bevbert_colsum_workspace_floats.argtypes = [_I]
+    lib.bevbert_gemm_plan_count.restype = _I
+    lib.bevbert_gemm_plan.restype = _I
+    lib.bevbert_gemm_plan.argtypes = [_I, _I, _I, _I, _I, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I, _I, _I, _I, _I64, _I]
     for name, args in _PROTOS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -102,11 +109,16 @@ def load():
     return lib
 
 
+_fns = {}
+
+
 def call(name, *args):
-    lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
-        raise BevBertHipError(f"{name} failed ({rc}): {lib.bevbert_last_error().decode()}")
+        raise BevBertHipError(f"{name} failed ({rc}): {load().bevbert_last_error().decode()}")
 
 
 def ptr(t):
@@ -119,5 +131,14 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_device_index = None
+
+
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on this process's GPU (one process per GPU: the device index is read
+    once; torch.cuda.current_stream() costs ~3 us of host time per call, the raw getter ~0.2 us)."""
+    global _device_index
+    if _device_index is None:
+        _device_index = torch.cuda.current_device()
+    return _raw_stream(_device_index)

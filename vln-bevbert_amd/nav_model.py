@@ -125,12 +125,12 @@ class VLNBert(nn.Module):
         if mode == "language":
             return self.vln_bert(mode, batch)
         if mode == "panorama":
-            batch["view_img_fts"] = F.dropout(batch["view_img_fts"], self.feat_dropout, self.training)
+            batch["view_img_fts"] = ops.dropout(batch["view_img_fts"], self.feat_dropout, self.training)
             if batch.get("obj_img_fts") is not None:
-                batch["obj_img_fts"] = F.dropout(batch["obj_img_fts"], self.feat_dropout, self.training)
+                batch["obj_img_fts"] = ops.dropout(batch["obj_img_fts"], self.feat_dropout, self.training)
             return self.vln_bert(mode, batch)
         if mode == "navigation":
-            batch["bev_fts"] = F.dropout(batch["bev_fts"], self.feat_dropout, self.training)   # model.py:36
+            batch["bev_fts"] = ops.dropout(batch["bev_fts"], self.feat_dropout, self.training)   # model.py:36
             return self.vln_bert(mode, batch)
         raise NotImplementedError("wrong mode: %s" % mode)
 

@@ -1,7 +1,7 @@
 """Torch-facing wrappers over the C ABI (include/bevbert_hip.h) and their autograd Functions.
 
-PyTorch here is plumbing: device memory, streams, the library GEMMs (hipBLASLt behind torch.mm/F.linear -- the
-north star keeps Linear layers on the vendor BLAS) and the autograd tape.  Everything else on the hot path --
+PyTorch here is plumbing: device memory, streams and the autograd tape.  The Linear layers stay on the vendor BLAS
+(north star) but are issued to hipBLASLt directly through the C ABI (bevbert_gemm, cached per-shape plans).  Everything else on the hot path --
 attention, bias/dropout/residual/LayerNorm, bias+GELU, the BEV splat, gmap aggregation, the optimiser -- is a
 hand-written HIP kernel reached through ``lib.call``.  Nothing in this file has a CPU or eager fallback.
 
@@ -33,6 +33,7 @@ class _Runtime:
         self.offset = 0
         self.attn_impl = 0      # 0 auto, 1 exact kernels, 2 MFMA kernels
         self._ws = {}
+        self._ws_ptr = {}
 
     def next_offset(self, n):
         off = self.offset
@@ -45,7 +46,7 @@ class _Runtime:
 
     def workspace(self, device, nfloats):
         # one scratch buffer per (device, stream): branches of the model run concurrently on separate streams
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        key = stream()
         buf = self._ws.get(key)
         if buf is None or buf.numel() < nfloats:
             buf = torch.empty(max(int(nfloats), 512 * 3 * 3072), dtype=torch.float32, device=device)
@@ -53,6 +54,18 @@ class _Runtime:
         return buf
 
 
+    def gemm_workspace(self, device, stream_handle):
+        """device pointer of the hipBLASLt workspace of a stream"""
+        key = ("lt", stream_handle)
+        p = self._ws_ptr.get(key)
+        if p is None:
+            buf = torch.empty(_LT_WS_BYTES, dtype=torch.uint8, device=device)
+            self._ws[key] = buf
+            p = self._ws_ptr[key] = buf.data_ptr()
+        return p
+
+
+_LT_WS_BYTES = 32 << 20
 RT = _Runtime()
 
 
@@ -133,6 +146,101 @@ def _gemm(kind, fn, m, n, k):
     return out
 
 
+# Library GEMMs go straight to hipBLASLt through the C ABI (bevbert_gemm): ~7 us of host time per call instead of the
+# ~28 us of torch.mm / F.linear dispatch -- the training step is host-bound at batch 64 (bench.py reports both clocks).
+# BEVBERT_LT_GEMM=0 routes them through torch instead (same library underneath); A/B knob.
+_LT_ENABLED = _os.environ.get("BEVBERT_LT_GEMM", "1") == "1"
+_LT_AUTOTUNE = int(_os.environ.get("BEVBERT_LT_AUTOTUNE", "16"))
+_LT_UNSUPPORTED = set()
+
+
+_LT_PLANS = {}
+
+
+def _lt_gemm(a, b, out, bias, M, N, K, opA, opB, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, accumulate=0):
+    """out (+)= op(a) . op(b) (+ bias) on hipBLASLt via the C ABI; False if the library has no kernel for the shape."""
+    key = (M, N, K, opA, opB, lda, ldb, ldc, batch, a.dtype, out.dtype, None if bias is None else bias.dtype,
+           accumulate)
+    plan = _LT_PLANS.get(key)
+    if plan is None:
+        plan = lib.load().bevbert_gemm_plan(M, N, K, opA, opB, lda, ldb, ldc, batch, sa, sb, sc, dtype_code(a),
+                                            dtype_code(out), -1 if bias is None else dtype_code(bias), accumulate,
+                                            _LT_WS_BYTES, _LT_AUTOTUNE)
+        if plan < 0:
+            raise lib.BevBertHipError(f"bevbert_gemm_plan failed ({plan}): {lib.load().bevbert_last_error().decode()}")
+        _LT_PLANS[key] = plan
+    if plan in _LT_UNSUPPORTED:
+        return False
+    st = stream()
+    rc = _LT_RUN(plan, a.data_ptr(), b.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(),
+                 RT.gemm_workspace(a.device, st), _LT_WS_BYTES, st)
+    if rc == -3:
+        _LT_UNSUPPORTED.add(plan)
+        return False
+    if rc != 0:
+        raise lib.BevBertHipError(f"bevbert_gemm_run failed ({rc}): {lib.load().bevbert_last_error().decode()}")
+    return True
+
+
+def _LT_RUN(*args):
+    global _LT_RUN
+    _LT_RUN = lib.load().bevbert_gemm_run        # bind once; later calls go straight to the ctypes function
+    return _LT_RUN(*args)
+
+
+def _rows(t):
+    """2-D row-major view (rows, C) of a tensor with unit inner stride and its row stride."""
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(1) != 1 or (t2.shape[0] > 1 and t2.stride(0) < t2.shape[1]):
+        t2 = t2.contiguous()
+    return t2, (t2.stride(0) if t2.shape[0] > 1 else t2.shape[1])
+
+
+def _lt_ok(*ts):
+    return _LT_ENABLED and all(t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) for t in ts)
+
+
+def _linear_fwd(x, w_c, b_c):
+    """y = x w_c^T (+ b_c)."""
+    N, K = w_c.shape
+    if _lt_ok(x, w_c) and x.dtype == w_c.dtype and w_c.stride(1) == 1 and x.numel() > 0:
+        x2, lda = _rows(x)
+        M = x2.shape[0]
+        y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        if _lt_gemm(x2, w_c, y, b_c, M, N, K, 0, 1, lda, w_c.stride(0), N):
+            return y
+    return F.linear(x, w_c, b_c)
+
+
+def _linear_dgrad(dy2, w_c):
+    """dx (M x K) = dy2 (M x N) w_c (N x K)."""
+    N, K = w_c.shape
+    if _lt_ok(dy2, w_c) and dy2.dtype == w_c.dtype and w_c.stride(1) == 1 and dy2.numel() > 0:
+        d2, lda = _rows(dy2)
+        M = d2.shape[0]
+        dx = torch.empty(M, K, dtype=dy2.dtype, device=dy2.device)
+        if _lt_gemm(d2, w_c, dx, None, M, K, N, 0, 0, lda, w_c.stride(0), K):
+            return dx
+    return dy2.mm(w_c)
+
+
+def _linear_wgrad(dy2, x2, S=1):
+    """(S x) N x K partial products dy2^T x2 over S equal chunks of the token axis (compute dtype)."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    if _lt_ok(dy2, x2) and dy2.dtype == x2.dtype and M > 0:
+        d2, lda = _rows(dy2)
+        xx, ldb = _rows(x2)
+        if S == 1 or (lda == N and ldb == K):
+            part = torch.empty((S, N, K) if S > 1 else (N, K), dtype=dy2.dtype, device=dy2.device)
+            Ms = M // S
+            if _lt_gemm(d2, xx, part, None, N, K, Ms, 1, 0, lda, ldb, K, S, Ms * lda, Ms * ldb, N * K):
+                return part
+    if S > 1:
+        return torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K))
+    return dy2.t().mm(x2)
+
+
 _SPLITK_ENABLED = _os.environ.get("BEVBERT_SPLITK", "1") == "1"     # A/B knob
 
 
@@ -155,15 +263,13 @@ def _wgrad_into(sink, dy2, x2):
     """sink (fp32 arena view, N x K) += dy2^T @ x2 with host-side split-K and a fused partial-sum + accumulate."""
     M, N = dy2.shape
     K = x2.shape[1]
-    if dy2.dtype == torch.float32:
+    if dy2.dtype == torch.float32 and not (_LT_ENABLED and dy2.is_cuda):
         _gemm("wgrad", lambda: sink.addmm_(dy2.t(), x2), N, K, M)
         return
-    S = _split_k(M, N, K)
-    if S > 1 and dy2.is_contiguous() and x2.is_contiguous():
-        part = _gemm("wgrad", lambda: torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)), N, K, M)
-    else:
+    S = _split_k(M, N, K) if dy2.dtype != torch.float32 else 1
+    if not (S > 1 and dy2.is_contiguous() and x2.is_contiguous()):
         S = 1
-        part = _gemm("wgrad", lambda: dy2.t().mm(x2), N, K, M)
+    part = _gemm("wgrad", lambda: _linear_wgrad(dy2, x2, S), N, K, M)
     if (N * K) % 4 == 0:
         call("bevbert_accum_partials", ptr(part), ptr(sink), S, N * K, dtype_code(part), stream())
     else:
@@ -284,6 +390,44 @@ def layernorm(x, gamma, beta, eps):
     return _BiasDropResLN.apply(x.contiguous(), None, None, gamma, beta, eps, 0.0, False)
 
 
+# ----------------------------------------------------------------------------- dropout (+ residual, + cast)
+class _DropoutAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, p, out_dtype):
+        assert x.is_contiguous() and x.numel() % 4 == 0
+        out_dtype = out_dtype or x.dtype
+        y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        if residual is not None:
+            assert residual.is_contiguous() and residual.shape == x.shape and residual.dtype == out_dtype
+        off = RT.next_offset(x.numel())
+        call("bevbert_dropout_add", ptr(x), ptr(residual), ptr(y), x.numel(), dtype_code(x), dtype_code(y), p, RT.seed,
+             off, stream())
+        ctx.cfg = (p, RT.seed, off, x.dtype, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, off, in_dtype, has_res = ctx.cfg
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dy = dy.contiguous()
+            dx = torch.empty_like(dy)
+            call("bevbert_dropout_add", ptr(dy), None, ptr(dx), dy.numel(), dtype_code(dy), dtype_code(dx), p, seed, off,
+                 stream())
+            if dx.dtype != in_dtype:
+                dx = dx.to(in_dtype)
+        return dx, (dy if has_res else None), None, None
+
+
+def dropout(x, p, training, residual=None, out_dtype=None):
+    """residual + nn.Dropout(p)(x) on the library's counter-based mask stream (reproducible from (seed, step) alone);
+    ``out_dtype`` fuses the cast of fp32 loader features to the compute dtype."""
+    if not training or p <= 0.0:
+        y = x if out_dtype is None or out_dtype == x.dtype else x.to(out_dtype)
+        return y if residual is None else residual + y
+    return _DropoutAdd.apply(x.contiguous(), residual, float(p), out_dtype)
+
+
 # ----------------------------------------------------------------------------- K4 bias + GELU
 class _BiasGelu(torch.autograd.Function):
     @staticmethod
@@ -329,7 +473,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, w_c, b_c):
-        y = _gemm("fwd", lambda: F.linear(x, w_c, b_c), x.numel() // x.shape[-1], w_c.shape[0], w_c.shape[1])
+        y = _gemm("fwd", lambda: _linear_fwd(x, w_c, b_c), x.numel() // x.shape[-1], w_c.shape[0], w_c.shape[1])
         ctx.save_for_backward(x, w_c)
         ctx.params = (weight, bias)
         return y
@@ -341,7 +485,7 @@ class _Linear(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         M, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
-        dx = _gemm("dgrad", lambda: dy2.mm(w_c), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = _gemm("dgrad", lambda: _linear_dgrad(dy2, w_c), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if weight.requires_grad:
             sink = _sink(weight)
@@ -349,7 +493,7 @@ class _Linear(torch.autograd.Function):
                 _mark_touched(weight)
                 _wgrad_into(sink, dy2, x2)
             else:
-                gw = dy2.t().mm(x2).to(weight.dtype)
+                gw = _linear_wgrad(dy2, x2).to(weight.dtype)
         if bias is not None and bias.requires_grad:
             sink = _sink(bias)
             C = dy2.shape[1]
@@ -401,7 +545,7 @@ class _LinearPacked(torch.autograd.Function):
     def forward(ctx, x, pw, pb):
         ctx.save_for_backward(x)
         ctx.packed = (pw, pb)
-        return _gemm("fwd", lambda: F.linear(x, pw.compute, pb.compute), x.numel() // x.shape[-1],
+        return _gemm("fwd", lambda: _linear_fwd(x, pw.compute, pb.compute), x.numel() // x.shape[-1],
                      pw.compute.shape[0], pw.compute.shape[1])
 
     @staticmethod
@@ -411,7 +555,7 @@ class _LinearPacked(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         M, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
-        dx = _gemm("dgrad", lambda: dy2.mm(pw.compute), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = _gemm("dgrad", lambda: _linear_dgrad(dy2, pw.compute), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
         if pw.requires_grad:
             pw.touch()
             _wgrad_into(pw.main_grad, dy2, x2)

@@ -189,9 +189,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         return batch
 
     def drop_feats(self, batch):
+        # fp32 loader features leave the dropout in the compute dtype (the cast the input projections need anyway)
+        cd = ops._compute(self.bert.local_encoder.bev_fts_embeddings[0].weight).dtype
         for k in ("traj_view_img_fts", "traj_obj_img_fts", "bev_fts"):
             if batch.get(k) is not None:
-                batch[k] = F.dropout(batch[k], self.feat_dropout, self.training)
+                batch[k] = ops.dropout(batch[k], self.feat_dropout, self.training, out_dtype=cd)
         return batch
 
     # -- dispatcher ---------------------------------------------------------------------------------
@@ -226,7 +228,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
 
     # -- tasks --------------------------------------------------------------------------------------
     def _host_kw(self, b):
-        return {"view_lens_host": b.get("traj_vp_view_lens_cpu"), "obj_lens_host": b.get("traj_vp_obj_lens_cpu")}
+        return {"view_lens_host": b.get("traj_vp_view_lens_cpu"), "obj_lens_host": b.get("traj_vp_obj_lens_cpu"),
+                "gmap_csr": b.get("gmap_csr")}
 
     def forward_mrc(self, b, compute_loss):
         """pretrain_cmt.py:272-297: masked-region classification on the object tokens (KL to detector probs)."""

@@ -293,4 +293,18 @@ def batch_to(batch, device, non_blocking=True):
         out[k] = v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v
         if k in HOST_COPIES and torch.is_tensor(v):
             out[k + "_cpu"] = v
+    if torch.device(device).type == "cuda" and "gmap_vpids" in batch and "traj_loc_fts" in batch:
+        out["gmap_csr"] = gmap_csr(batch, device)
     return out
+
+
+def gmap_csr(batch, device):
+    """Host-side index building of the global-map aggregation (vilmodel.py:632-666 walks the same string ids inside
+    the model forward): done here, with the other host->device copies of the loader, so that the training step itself
+    carries no Python loops over viewpoint ids.  Returns (SegmentCSR, G) for GlocalTextPathCMT's ``gmap_csr``."""
+    from .vilmodel import build_gmap_csr
+    lens = batch["traj_vp_view_lens"]
+    if batch.get("traj_vp_obj_lens") is not None:
+        lens = lens + batch["traj_vp_obj_lens"]
+    return build_gmap_csr(list(batch["traj_step_lens"]), lens.tolist(), batch["traj_vpids"], batch["traj_cand_vpids"],
+                          batch["gmap_vpids"], batch["traj_loc_fts"].shape[1], device)

@@ -58,7 +58,7 @@ class BertEmbeddings(nn.Module):
         y = ops.embed_sum_layernorm(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
                                     self.token_type_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias,
                                     self.eps, 0)
-        return F.dropout(y, self.dropout_p, self.training)
+        return ops.dropout(y, self.dropout_p, self.training)
 
 
 class BertSelfAttention(_Finalizable):
@@ -313,11 +313,11 @@ class TransformerEncoderLayer(nn.Module):
         qkv = ops.linear(h, self.self_attn.in_proj_weight, self.self_attn.in_proj_bias)
         a = ops.attention_self(qkv, key_mask, None, self.nhead, p, tr)
         o = ops.linear(a, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias)
-        src = src + F.dropout(o, p, tr)
+        src = ops.dropout(o, p, tr, residual=src)
         h = ops.layernorm(src, self.norm2.weight, self.norm2.bias, 1e-5)
         f = ops.bias_gelu(ops.linear(h, self.linear1.weight), self.linear1.bias)
-        f = ops.linear(F.dropout(f, p, tr), self.linear2.weight, self.linear2.bias)
-        return src + F.dropout(f, p, tr)
+        f = ops.linear(ops.dropout(f, p, tr), self.linear2.weight, self.linear2.bias)
+        return ops.dropout(f, p, tr, residual=src)
 
 
 class TransformerEncoder(nn.Module):
@@ -392,7 +392,7 @@ class ImageEmbeddings(nn.Module):
         e = e + embedding_lookup(self.nav_type_embedding, nav_types) \
             + embedding_lookup(type_embed_layer, torch.ones(1, 1, dtype=torch.long, device=e.device))
         e = ops.layernorm(e, self.layer_norm.weight, self.layer_norm.bias, 1e-12)
-        e = F.dropout(e, self.drop_p, self.training)
+        e = ops.dropout(e, self.drop_p, self.training)
         masks = gen_seq_masks(lens, e.shape[1])
         if self.pano_encoder is not None:
             e = self.pano_encoder(e, masks.logical_not())
@@ -594,12 +594,16 @@ class GlocalTextPathCMT(nn.Module):
         return obj * valid[..., None].to(obj.dtype), valid
 
     def _gmap_inputs(self, traj_embeds, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids, gmap_vpids,
-                     gmap_step_ids, gmap_pos_fts, gmap_lens, view_lens_host=None):
-        if view_lens_host is None:
-            view_lens_host = _host_list(traj_vp_view_lens)            # one small D2H copy when no host copy is given
+                     gmap_step_ids, gmap_pos_fts, gmap_lens, view_lens_host=None, gmap_csr=None):
         V = traj_embeds.shape[1]
-        csr, G = build_gmap_csr(traj_step_lens, view_lens_host, traj_vpids, traj_cand_vpids, gmap_vpids, V,
-                                traj_embeds.device)
+        if gmap_csr is not None:        # built by the loader (synthetic.batch_to) next to the host->device copies
+            csr, G = gmap_csr
+            assert csr.n_src == traj_embeds.shape[0] * V and csr.n_out == len(traj_step_lens) * G
+        else:
+            if view_lens_host is None:
+                view_lens_host = _host_list(traj_vp_view_lens)        # one small D2H copy when no host copy is given
+            csr, G = build_gmap_csr(traj_step_lens, view_lens_host, traj_vpids, traj_cand_vpids, gmap_vpids, V,
+                                    traj_embeds.device)
         assert G == gmap_step_ids.shape[1]
         flat = traj_embeds.reshape(-1, traj_embeds.shape[-1])
         return self.global_encoder.gmap_input_embedding(flat, csr, G, gmap_step_ids, gmap_pos_fts, gmap_lens)
@@ -609,7 +613,7 @@ class GlocalTextPathCMT(nn.Module):
                 traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
                 gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
                 bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, return_gmap_embeds=True, view_lens_host=None,
-                obj_lens_host=None):
+                obj_lens_host=None, gmap_csr=None):
         has_obj = traj_obj_img_fts is not None
         br = ops.Branches(txt_ids.device)
         gmap_embeds = obj_embeds = obj_masks = traj = None
@@ -633,7 +637,7 @@ class GlocalTextPathCMT(nn.Module):
             with br.side():
                 g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids,
                                                   traj_cand_vpids, gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens,
-                                                  tok_lens)
+                                                  tok_lens, gmap_csr)
                 gmap_embeds = self.global_encoder(txt_embeds, txt_masks, g_in, g_masks, gmap_pair_dists)
         bev_embeds, obj_embeds = self.local_encoder(txt_embeds, txt_masks, bev_fts, bev_pos_fts,
                                                     _all_ones_to_none(bev_masks), bev_nav_masks, obj_embeds, obj_masks)
@@ -643,7 +647,8 @@ class GlocalTextPathCMT(nn.Module):
     def forward_mlm(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
                     traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
                     gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
-                    bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, view_lens_host=None, obj_lens_host=None):
+                    bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, view_lens_host=None, obj_lens_host=None,
+                    gmap_csr=None):
         br = ops.Branches(txt_ids.device)
         br.fork(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts, traj_vp_obj_lens)
         with br.side():         # panorama encoder next to the text encoder
@@ -656,7 +661,7 @@ class GlocalTextPathCMT(nn.Module):
         br.fork(txt_embeds, tm, gmap_step_ids, gmap_pos_fts, gmap_lens)
         with br.side():
             g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
-                                              gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens)
+                                              gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens, gmap_csr)
             gm = neg_key_mask(g_masks)
             g_txt = txt_embeds
             for layer in self.global_encoder.encoder.x_layers:
@@ -680,7 +685,7 @@ class GlocalTextPathCMT(nn.Module):
                     traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
                     gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
                     bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, sem_pred_token=None, view_lens_host=None,
-                    obj_lens_host=None):
+                    obj_lens_host=None, gmap_csr=None):
         bm = _all_ones_to_none(bev_masks)
         if sem_pred_token == "cattn":
             txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
