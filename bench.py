@@ -112,9 +112,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU is visible"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BEVBERT_FORCE_COLLECTIVES=1: run the RCCL exchange (side stream, backward hook, in-place all-reduce) on a one-rank
+    # group too -- a single-GPU stress of the multi-GPU code path, not a benchmark configuration
+    force = os.environ.get("BEVBERT_FORCE_COLLECTIVES") == "1"
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from vln_bevbert_amd import ops, synthetic
@@ -133,7 +137,7 @@ def main():
     arena = model.finalize(dev, cdt)
     model.train()
     model.set_dropout(0.1)                                  # train_r2r.py:157
-    trainer = PretrainTrainer(model, arena, rank=rank, world_size=world)
+    trainer = PretrainTrainer(model, arena, rank=rank, world_size=world, force_collectives=force)
     # the reference draws the task of each step at random with ratio 5:5:1 (MetaLoader); the bench walks that mix as
     # a fixed 11-step cycle so that every run (and every K that is a multiple of 11) times exactly the same work
     cycle = ["mlm", "sap", "mlm", "sap", "mlm", "sap", "masksem", "mlm", "sap", "mlm", "sap"]
@@ -254,10 +258,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, a)
     log("done")
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force:
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)     # after the teardown: the JSON is the last line on stdout
 
 
 def cpu_baseline(cfg, a):

@@ -8,11 +8,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-pass $*"
+BENCH="python $ROOT/bench.py --steps 11 --warmup 11 --no-cpu-baseline --no-kernel-pass $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace_bench.log" 2>&1
 echo "trace rc=$?" >> "$OUT/trace_bench.log"
 find "$OUT/trace" -name '*kernel_stats*' -exec cp {} "$OUT/" \; 2>/dev/null
 python "$ROOT/scripts/summarize_rocprof.py" "$OUT" > "$OUT/summary.txt" 2>&1
+python "$ROOT/scripts/summarize_trace.py" "$OUT/trace" 11 > "$OUT/steps_summary.txt" 2>&1
 rm -rf "$OUT/trace"
 if [ "${PMC:-0}" = "1" ]; then
   for C in FETCH_SIZE WRITE_SIZE; do

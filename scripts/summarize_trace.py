@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Per-step view of a rocprofv3 --kernel-trace CSV: keeps only the last K training steps (delimited by adamw_kernel
+launches, so warm-up and the first-use GEMM autotuning are excluded) and reports wall time, GPU busy time (union of
+kernel intervals), the sum of kernel durations (> busy when streams overlap) and the per-kernel table.
+Usage: summarize_trace.py <dir with *kernel_trace*.csv> [K=11]"""
+import csv
+import glob
+import os
+import sys
+
+d = sys.argv[1]
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 11
+files = glob.glob(os.path.join(d, "**", "*kernel_trace*.csv"), recursive=True)
+if not files:
+    print("no kernel_trace csv under", d)
+    sys.exit(0)
+ev = []
+for f in files:
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
+ev.sort()
+ends = [e for e in ev if e[2].startswith("adamw_kernel")]
+if len(ends) < K + 1:
+    print(f"only {len(ends)} steps in the trace")
+    sys.exit(0)
+t0, t1 = ends[-K - 1][1], ends[-1][1]
+win = [e for e in ev if e[0] >= t0 and e[1] <= t1]
+wall = (t1 - t0) / 1e6
+busy, cur_s, cur_e = 0, None, None
+for s, e, _, _ in win:
+    if cur_e is None or s > cur_e:
+        if cur_e is not None:
+            busy += cur_e - cur_s
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+if cur_e is not None:
+    busy += cur_e - cur_s
+tot = sum(e - s for s, e, _, _ in win)
+
+
+def cls(name):
+    n = name.lower()
+    if any(k in n for k in ("attn_", "ln_fwd", "ln_bwd", "bev_", "colwise", "colsum", "bias_gelu", "gather_wsum",
+                            "adamw", "sumsq", "clip_coef", "cast_f32", "keep_mask", "accum_partials", "dropout_add",
+                            "embedding_grad")):
+        return "custom"
+    if any(k in n for k in ("cijk", "gemm", "tensile", "hipblaslt", "rocblas")):
+        return "gemm"
+    if "nccl" in n or "rccl" in n:
+        return "rccl"
+    return "torch"
+
+
+print(f"last {K} steps: wall {wall:.2f} ms ({wall / K:.2f} ms/step), GPU busy {busy / 1e6 / K:.2f} ms/step "
+      f"({100 * busy / 1e6 / wall:.1f} % of wall), sum of kernel durations {tot / 1e6 / K:.2f} ms/step, "
+      f"{len(win) / K:.0f} launches/step")
+by_q = {}
+for s, e, _, q in win:
+    by_q[q] = by_q.get(q, 0) + (e - s)
+print("per HW queue (ms/step):", {q: round(t / 1e6 / K, 2) for q, t in sorted(by_q.items())})
+by_c, by_k = {}, {}
+for s, e, n, _ in win:
+    by_c[cls(n)] = by_c.get(cls(n), 0) + (e - s)
+    c = by_k.setdefault(n, [0, 0])
+    c[0] += 1
+    c[1] += e - s
+for c, t in sorted(by_c.items(), key=lambda kv: -kv[1]):
+    print(f"  {c:7s} {t / 1e6 / K:8.3f} ms/step  {100 * t / tot:5.1f} %")
+print()
+print(f"{'class':7s} {'calls/step':>10s} {'ms/step':>9s} {'avg_us':>9s} {'%':>6s}  name")
+for n, (c, t) in sorted(by_k.items(), key=lambda kv: -kv[1][1])[:45]:
+    print(f"{cls(n):7s} {c / K:10.1f} {t / 1e6 / K:9.3f} {t / 1e3 / c:9.2f} {100 * t / tot:6.2f}  {n[:110]}")

@@ -137,11 +137,13 @@ class ParamArena:
         overwrites the arena next (optimiser, all-reduce, zero_grad, a test) must order itself after them."""
         if self.device.type == "cuda":
             from . import ops
+            ops.WgradStream.flush_all()
             sides = ops.Branches.side_streams()
             if sides:
                 cur = torch.cuda.current_stream(self.device)
                 for side in sides:
                     cur.wait_stream(side)
+            ops.WgradStream.release()
 
     def zero_grad(self):
         self.sync()

@@ -135,10 +135,22 @@ _raw_stream = torch._C._cuda_getCurrentRawStream
 _device_index = None
 
 
+_override = None
+
+
 def stream():
-    """hipStream_t of torch's current stream on this process's GPU (one process per GPU: the device index is read
-    once; torch.cuda.current_stream() costs ~3 us of host time per call, the raw getter ~0.2 us)."""
+    """hipStream_t the next launch goes to: torch's current stream on this process's GPU, unless a launch-stream
+    override is active (ops.WgradStream).  One process per GPU: the device index is read once;
+    torch.cuda.current_stream() costs ~3 us of host time per call, the raw getter ~0.2 us."""
     global _device_index
+    if _override is not None:
+        return _override
     if _device_index is None:
         _device_index = torch.cuda.current_device()
     return _raw_stream(_device_index)
+
+
+def set_stream_override(handle):
+    """Route every following C-ABI launch to `handle` (a hipStream_t as int) until reset with None."""
+    global _override
+    _override = handle

@@ -118,6 +118,81 @@ class Branches:
 TRACE = None     # dict name -> [(start_event, end_event)] while bench.py's kernel-timing pass is active
 
 
+class WgradStream:
+    """Weight-gradient work (split-K GEMM, partial-sum accumulate, bias column sums) on its own HIP stream.
+
+    Backward's critical path is the dgrad chain; the dW / db kernels only feed the optimiser.  At the 5 120-token shapes
+    of the text branch neither kind fills 256 CUs (<= 240 workgroups per GEMM), so running them concurrently shortens
+    the step.  Events are expensive on the host (~20 us for record + wait), so the work is DEFERRED: backward nodes
+    ``submit`` closures, and every ``BATCH`` submissions from one producing stream are flushed behind a single event
+    (events come from a small reusable pool).  Operands are kept alive until ``release()`` (ParamArena.sync, which
+    also joins the stream) instead of being tracked by the caching allocator -- with 288 GB of HBM the extra lifetime
+    of one backward's activation gradients is free."""
+
+    # not combined with the model-branch side stream: that pairing stalled at batch 64 on the MI355X (unexplained),
+    # and either one alone already recovers the idle CUs (in-run A/B, batch 64: 24.9 ms/step with neither,
+    # 23.3 with this stream, 22.8 with the branch stream)
+    enabled = _os.environ.get("BEVBERT_WGRAD_STREAM", "1") == "1" and not Branches.enabled
+    BATCH = int(_os.environ.get("BEVBERT_WGRAD_BATCH", "6"))
+    stream = None
+    _keep = []
+    _pending = {}        # producing stream handle -> (torch stream, [closures])
+    _events = []
+    _next_event = 0
+
+    @classmethod
+    def active(cls, device):
+        return cls.enabled and TRACE is None and device.type == "cuda"
+
+    @classmethod
+    def submit(cls, device, fn, *keep):
+        """Run ``fn`` (C-ABI launches only) on the weight-gradient stream once its operands -- everything enqueued so
+        far on the current stream -- are ready.  ``keep``: tensors ``fn`` reads or writes, plus the ORIGINAL gradient
+        tensor autograd handed to the node: holding that object keeps its use count above one, which stops the
+        engine from accumulating another gradient into its storage in place while the deferred read is pending."""
+        if not cls.active(device):
+            fn()
+            return
+        h = lib.stream()
+        slot = cls._pending.get(h)
+        if slot is None:
+            slot = cls._pending[h] = (torch.cuda.current_stream(device), [])
+        slot[1].append(fn)
+        cls._keep.extend(keep)
+        if len(slot[1]) >= cls.BATCH:
+            cls._flush(slot)
+
+    @classmethod
+    def _flush(cls, slot):
+        producer, fns = slot
+        if not fns:
+            return
+        if cls.stream is None:
+            cls.stream = torch.cuda.Stream(producer.device)
+            Branches._streams["wgrad"] = cls.stream       # joined by ParamArena.sync / GradReducer like the branches
+            cls._events = [torch.cuda.Event() for _ in range(64)]
+        ev = cls._events[cls._next_event % len(cls._events)]
+        cls._next_event += 1
+        ev.record(producer)
+        cls.stream.wait_event(ev)
+        lib.set_stream_override(cls.stream.cuda_stream)
+        try:
+            for fn in fns:
+                fn()
+        finally:
+            lib.set_stream_override(None)
+            fns.clear()
+
+    @classmethod
+    def flush_all(cls):
+        for slot in cls._pending.values():
+            cls._flush(slot)
+
+    @classmethod
+    def release(cls):
+        cls._keep.clear()
+
+
 def call(name, *args):
     """C-ABI call; when TRACE is armed, bracket the launch with HIP events on the launching stream."""
     if TRACE is None:
@@ -237,8 +312,16 @@ def _linear_wgrad(dy2, x2, S=1):
             if _lt_gemm(d2, xx, part, None, N, K, Ms, 1, 0, lda, ldb, K, S, Ms * lda, Ms * ldb, N * K):
                 return part
     if S > 1:
-        return torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K))
-    return dy2.t().mm(x2)
+        return _on_launch_stream(lambda: torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)))
+    return _on_launch_stream(lambda: dy2.t().mm(x2))
+
+
+def _on_launch_stream(fn):
+    """Run a torch op on the stream the C-ABI launches currently go to (fallback paths inside a WgradStream section)."""
+    if lib._override is None:
+        return fn()
+    with torch.cuda.stream(WgradStream.stream):
+        return fn()
 
 
 _SPLITK_ENABLED = _os.environ.get("BEVBERT_SPLITK", "1") == "1"     # A/B knob
@@ -264,8 +347,8 @@ def _wgrad_into(sink, dy2, x2):
     M, N = dy2.shape
     K = x2.shape[1]
     if dy2.dtype == torch.float32 and not (_LT_ENABLED and dy2.is_cuda):
-        _gemm("wgrad", lambda: sink.addmm_(dy2.t(), x2), N, K, M)
-        return
+        _gemm("wgrad", lambda: _on_launch_stream(lambda: sink.addmm_(dy2.t(), x2)), N, K, M)
+        return None
     S = _split_k(M, N, K) if dy2.dtype != torch.float32 else 1
     if not (S > 1 and dy2.is_contiguous() and x2.is_contiguous()):
         S = 1
@@ -273,7 +356,20 @@ def _wgrad_into(sink, dy2, x2):
     if (N * K) % 4 == 0:
         call("bevbert_accum_partials", ptr(part), ptr(sink), S, N * K, dtype_code(part), stream())
     else:
-        sink.add_(part if S == 1 else part.sum(0))
+        _on_launch_stream(lambda: sink.add_(part if S == 1 else part.sum(0)))
+    return part
+
+
+def _param_grads(w_sink, b_sink, dyc, xc):
+    """dW += dy^T x and db += colsum(dy) into the gradient arena (the deferred body of a Linear's backward)."""
+    if w_sink is not None:
+        part = _wgrad_into(w_sink, dyc, xc)
+        if part is not None and lib._override is not None:
+            WgradStream._keep.append(part)
+    if b_sink is not None:
+        C = dyc.shape[1]
+        ws = RT.workspace(dyc.device, 512 * C)
+        call("bevbert_colsum", ptr(dyc), ptr(b_sink), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 1, stream())
 
 
 def _sink(param):
@@ -487,33 +583,34 @@ class _Linear(torch.autograd.Function):
         M, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
         dx = _gemm("dgrad", lambda: _linear_dgrad(dy2, w_c), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
         gw = gb = None
-        if weight.requires_grad:
-            sink = _sink(weight)
-            if sink is not None:
-                _mark_touched(weight)
-                _wgrad_into(sink, dy2, x2)
-            else:
-                gw = _linear_wgrad(dy2, x2).to(weight.dtype)
-        if bias is not None and bias.requires_grad:
-            sink = _sink(bias)
-            C = dy2.shape[1]
+        w_sink = _sink(weight) if weight.requires_grad else None
+        b_sink = _sink(bias) if (bias is not None and bias.requires_grad) else None
+        C = dy2.shape[1]
+        if weight.requires_grad and w_sink is None:
+            gw = _linear_wgrad(dy2, x2).to(weight.dtype)
+        if bias is not None and bias.requires_grad and (b_sink is None or C % 4 != 0):
             if C % 4 != 0:                                  # e.g. the 1-wide heads: a library reduction is fine
                 s = dy2.float().sum(0)
-                if sink is not None:
+                if b_sink is not None:
                     _mark_touched(bias)
-                    sink.add_(s)
+                    b_sink.add_(s)
+                    b_sink = None
                 else:
                     gb = s.to(bias.dtype)
             else:
                 ws = RT.workspace(dy.device, 512 * C)
                 dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
-                if sink is not None:
-                    _mark_touched(bias)
-                    call("bevbert_colsum", ptr(dyc), ptr(sink), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 1, stream())
-                else:
-                    t = torch.empty(C, dtype=torch.float32, device=dy.device)
-                    call("bevbert_colsum", ptr(dyc), ptr(t), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 0, stream())
-                    gb = t.to(bias.dtype)
+                t = torch.empty(C, dtype=torch.float32, device=dy.device)
+                call("bevbert_colsum", ptr(dyc), ptr(t), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 0, stream())
+                gb = t.to(bias.dtype)
+        if w_sink is not None or b_sink is not None:        # arena parameters: accumulate on the weight-gradient stream
+            dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+            xc = x2 if x2.is_contiguous() else x2.contiguous()
+            if w_sink is not None:
+                _mark_touched(weight)
+            if b_sink is not None:
+                _mark_touched(bias)
+            WgradStream.submit(dy.device, lambda: _param_grads(w_sink, b_sink, dyc, xc), dyc, xc, dy)
         return dx, gw, gb, None, None
 
 
@@ -558,12 +655,11 @@ class _LinearPacked(torch.autograd.Function):
         dx = _gemm("dgrad", lambda: _linear_dgrad(dy2, pw.compute), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
         if pw.requires_grad:
             pw.touch()
-            _wgrad_into(pw.main_grad, dy2, x2)
             pb.touch()
             C = dy2.shape[1]
-            ws = RT.workspace(dy.device, 512 * C)
             dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
-            call("bevbert_colsum", ptr(dyc), ptr(pb.main_grad), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 1, stream())
+            xc = x2 if x2.is_contiguous() else x2.contiguous()
+            WgradStream.submit(dy.device, lambda: _param_grads(pw.main_grad, pb.main_grad, dyc, xc), dyc, xc, dy)
         return dx, None, None
 
 

@@ -82,6 +82,8 @@ class GradReducer:
         if hi <= lo:
             return
         view = self.flat[lo:hi]
+        if self.cuda:
+            ops.WgradStream.flush_all()                              # deferred weight-gradient launches go out first
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())     # everything enqueued so far has produced `view`
             for side in ops.Branches.side_streams():                 # ... including the model's side-stream branches
