@@ -50,7 +50,9 @@ const char* bevbert_arch(void);
  * bevbert_bev_bin_points: same outputs from ready-made ego-frame points (B,P,3) + drop mask (B,P) uint8.
  * bevbert_bev_splat_mean: out[b,cell,:] = mean of feat[b,p,:] over the cell's points (0 if empty);
  *   semantics: sem_ids (B,P) uint8 class ids  XOR  sem_dense (B,P,S) float64 one-hot (the reference's format);
- *   out_sem (B,K,S) uint8 {0,1}, out_sem_mask (B,K) uint8; pass out_sem = NULL to skip semantics. */
+ *   out_sem (B,K,S) uint8 {0,1}, out_sem_mask (B,K) uint8; pass out_sem = NULL to skip semantics.
+ *   sample_rows (B) int32 or NULL: sample b's points are row sample_rows[b] of feat / sem_ids (which then hold N >= B
+ *   rows: a device-resident store of per-viewpoint grid features, dataset.py:110-118, read in place -- no batch copy). */
 int bevbert_bev_lift_bin(const float* depths, const float* T_c2w, const float* T_w2c, const float* S_w2c,
                          const float* pix_scale, int B, int V, int hw, float depth_scale, int dim, float res,
                          float y_clip, int* cell, int* order, int* cell_start, hipStream_t stream);
@@ -58,7 +60,7 @@ int bevbert_bev_bin_points(const float* points, const uint8_t* drop_mask, int B,
                            float y_clip, int* cell, int* order, int* cell_start, hipStream_t stream);
 int bevbert_bev_splat_mean(const void* feat, int feat_dtype, const int* order, const int* cell_start, void* out,
                            int out_dtype, int B, int P, int K, int C, const uint8_t* sem_ids, const double* sem_dense,
-                           int S, uint8_t* out_sem, uint8_t* out_sem_mask, hipStream_t stream);
+                           int S, uint8_t* out_sem, uint8_t* out_sem_mask, const int* sample_rows, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * K2  fused multi-head attention (head_dim 64).

@@ -141,12 +141,17 @@ def pano_layer(sd, p, x, key_pad, nh):
     return x + h
 
 
-def image_embeddings(sd, p, cfg, view_fts, loc_fts, nav_types, view_lens, type_emb_row1, obj_fts=None, obj_lens=None):
-    """vilmodel.py:494-532 ImageEmbeddings.forward incl. the object branch (:502-516) and the pano encoder.
+def image_embeddings(sd, p, cfg, view_fts, loc_fts, nav_types, view_lens, type_emb_row1, obj_fts=None, obj_lens=None,
+                     dep_fts=None):
+    """vilmodel.py:494-532 ImageEmbeddings.forward incl. the object branch (:502-516) and the pano encoder; with
+    ``dep_fts`` the continuous-environment fork's depth-feature term (bevbert_ce/pretrain/pretrain_src/model/
+    vilmodel.py:507-509).
 
     Returns (sum_T, L, H) embeddings, the (sum_T, L) validity mask and the token counts (views + objects).
     """
     img = layer_norm(sd, p + ".img_layer_norm", linear(sd, p + ".img_linear", view_fts))
+    if (p + ".dep_linear.weight") in sd:
+        img = img + layer_norm(sd, p + ".dep_layer_norm", linear(sd, p + ".dep_linear", dep_fts))
     lens = view_lens
     if obj_fts is not None:
         if (p + ".obj_linear.weight") in sd:
@@ -258,7 +263,7 @@ def _common(sd, cfg, b, pfx):
     traj, traj_masks, lens = image_embeddings(
         sd, pfx + "img_embeddings", cfg, b["traj_view_img_fts"], b["traj_loc_fts"], b["traj_nav_types"],
         b["traj_vp_view_lens"], sd[pfx + "embeddings.token_type_embeddings.weight"][1],
-        b.get("traj_obj_img_fts"), b.get("traj_vp_obj_lens"))
+        b.get("traj_obj_img_fts"), b.get("traj_vp_obj_lens"), b.get("traj_view_dep_fts"))
     b["_traj_lens"] = lens
     return txt, txt_masks, traj, traj_masks
 
@@ -421,16 +426,21 @@ def cell_index(pc, no_depth, dim=21, res=0.5):
 
 
 def project_bev(pc, no_depth, feat, sem, dim=21, res=0.5):
-    """bev_utils.py:381-430 project_bev (per-sample loop)."""
+    """bev_utils.py:381-430 project_bev (per-sample loop); sem=None: the continuous-environment fork's variant without
+    semantic maps (bevbert_ce/pretrain/pretrain_src/model/bev_utils.py:382-417)."""
     bevs, sems, sem_masks = [], [], []
     for i in range(pc.shape[0]):
         idx = cell_index(pc[i], no_depth[i], dim, res)
         keep = idx >= 0
         bevs.append(scatter_mean(feat[i][keep], idx[keep], dim * dim))
+        if sem is None:
+            continue
         s = scatter_mean(sem[i][keep], idx[keep], dim * dim)
         s[s > 0] = 1
         sems.append(s)
         sem_masks.append(s.sum(1) > 0)
+    if sem is None:
+        return torch.stack(bevs), None, None
     return torch.stack(bevs), torch.stack(sems), torch.stack(sem_masks)
 
 
@@ -440,10 +450,12 @@ def lift_splat(cfg, batch):
     dim = cfg.bev_dim
     pc, nod = lift_points(batch["depths"], batch["T_c2w"], batch["T_w2c"], batch["S_w2c"], cfg.grid_hw)
     feat = batch["rgbs"].reshape(B, -1, cfg.grid_feat_size).to(torch.float32)
-    sem = batch["sems"]
-    if sem.dim() == 2:                                   # compact class ids -> one-hot
-        sem = F.one_hot(sem.long(), cfg.sem_classes).to(torch.float64)
-    bev, bsem, bsem_m = project_bev(pc, nod, feat, sem.reshape(B, -1, cfg.sem_classes), dim, cfg.bev_res)
+    sem = batch.get("sems")
+    if sem is not None:
+        if sem.dim() == 2:                               # compact class ids -> one-hot
+            sem = F.one_hot(sem.long(), cfg.sem_classes).to(torch.float64)
+        sem = sem.reshape(B, -1, cfg.sem_classes)
+    bev, bsem, bsem_m = project_bev(pc, nod, feat, sem, dim, cfg.bev_res)
     pos = bevpos_polar(dim).reshape(1, dim * dim, 3).expand(B, -1, -1)
     pos = torch.cat([batch["bev_gpos_fts"].expand(-1, dim * dim, -1), pos], -1)
     return dict(bev_fts=bev, bev_masks=torch.ones(B, dim * dim, dtype=torch.bool), bev_pos_fts=pos,

@@ -16,6 +16,8 @@ Shims -- installed before the reference is imported:
     vln_bevbert_amd.weights (key-name seeded) and the MLM decoder is tied by hand.
 
 Usage:  python tests/golden/make_golden.py           (writes tests/golden/*.npz)
+        python tests/golden/make_golden.py --ce      (continuous-environment fork only: its modules are also called
+                                                      ``model.*``, so it needs a process of its own)
 """
 import math
 import os
@@ -65,8 +67,8 @@ def _ref_config(cfg: BevBertConfig):
     return pc
 
 
-def build_ref_pretrain(cfg):
-    sys.path.insert(0, os.path.join(REF, "pretrain_src"))
+def build_ref_pretrain(cfg, src="pretrain_src"):
+    sys.path.insert(0, os.path.join(REF, src))
     from model import bev_utils, pretrain_cmt, vilmodel
 
     def build_projector():
@@ -386,6 +388,44 @@ def gen_keys(ref, tag):
             f.write(f"{k} {tuple(v.shape)}\n")
 
 
+def gen_ce():
+    """bevbert_ce/pretrain/pretrain_src: 11x11 BEV @ 1 m, depth-feature branch, 4-d location features, 2 nav types,
+    tasks mlm + sap, no semantic maps (run_pt/r2r_model_config_dep.json; its pretrain_cmt.py:16-17,100-135)."""
+    print("continuous-environment fork [tiny_ce]")
+    cfg = BevBertConfig.ce(num_l_layers=2, num_x_layers=2, num_pano_layers=1, vocab_size=1200,
+                           max_position_embeddings=128)
+    ref = build_ref_pretrain(cfg, src="bevbert_ce/pretrain/pretrain_src")
+    gen_keys(ref, "tiny_ce")
+    B, seed = 3, 41
+    arrs = {"seed": np.int64(seed), "B": np.int64(B)}
+    for task in ("mlm", "sap"):
+        b = synthetic.make_batch(cfg, task, B, seed=seed, ragged=True)
+        with torch.no_grad():
+            arrs[f"{task}_loss"] = npy(ref(dict(b), task, True))
+            outs = ref(dict(b), task, False)
+        if task == "mlm":
+            arrs["mlm_scores_sub"] = sub(outs, 13)
+        else:
+            arrs.update(sap_global=npy(outs[0]), sap_local=npy(outs[1]), sap_fused=npy(outs[2]))
+        ref.zero_grad(set_to_none=True)
+        ref(dict(b), task, True).mean().backward()
+        arrs[f"{task}_grad_sqnorm"] = np.float64(
+            sum(float((p.grad.double() ** 2).sum()) for p in ref.parameters() if p.grad is not None))
+        arrs[f"{task}_n_params_with_grad"] = np.int64(sum(p.grad is not None for p in ref.parameters()))
+        for k, p in ref.named_parameters():
+            if p.grad is not None and k in CE_GRAD_KEYS:
+                arrs[f"{task}_grad::{k}"] = sub(p.grad, 97 if p.numel() > 4096 else 1)
+    save("tasks_tiny_ce", **arrs)
+
+
+CE_GRAD_KEYS = {
+    "bert.img_embeddings.dep_linear.weight", "bert.img_embeddings.dep_layer_norm.bias",
+    "bert.img_embeddings.loc_linear.weight", "bert.img_embeddings.nav_type_embedding.weight",
+    "bert.local_encoder.bev_fts_embeddings.0.weight", "bert.embeddings.word_embeddings.weight",
+    "sap_fuse_linear.net.3.weight",
+}
+
+
 build_ref_pretrain_cached = {}
 
 
@@ -395,6 +435,9 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     _install_shims()
+    if "--ce" in sys.argv:
+        gen_ce()
+        return
 
     tiny = BevBertConfig.tiny()
     ref = build_ref_pretrain(tiny)

@@ -503,3 +503,22 @@ def test_dropout_add_matches_exported_mask(ops, in_dtype, out_dtype, with_res):
     y0 = ops.dropout(x, p, False, residual=res, out_dtype=out_dtype)
     ref0 = x.detach().to(out_dtype) if not with_res else res.detach() + x.detach().to(out_dtype)
     assert torch.equal(y0.detach(), ref0)
+
+
+def test_splat_reads_store_rows_in_place(ops):
+    """sample_rows: splatting straight out of a (N,P,C) fp16 store == splatting the gathered batch (bit-exact)."""
+    g = torch.Generator().manual_seed(3)
+    N, B, P, C, dim = 9, 5, 2352, 768, 21
+    store = torch.randn(N, P, C, generator=g).to(DEV, torch.float16)
+    sem_store = torch.randint(0, 40, (N, P), generator=g).to(DEV, torch.uint8)
+    rows = torch.tensor([7, 0, 3, 7, 8], dtype=torch.int32, device=DEV)
+    pts = ((torch.rand(B, P, 3, generator=g) - 0.5) * torch.tensor([12.0, 2.0, 12.0])).to(DEV)
+    drop = (torch.rand(B, P, generator=g) < 0.05).to(DEV)
+    cell, order, start = ops.bev_bin_points(pts, drop, dim, 0.5)
+    for out_dtype in (torch.float32, torch.bfloat16):
+        a, a_sem, a_mask = ops.bev_splat_mean(store, order, start, dim * dim, out_dtype=out_dtype, sems=sem_store, rows=rows)
+        gathered = store.index_select(0, rows.long())
+        b, b_sem, b_mask = ops.bev_splat_mean(gathered, order, start, dim * dim, out_dtype=out_dtype,
+                                              sems=sem_store.index_select(0, rows.long()))
+        assert torch.equal(a, b) and torch.equal(a_sem, b_sem) and torch.equal(a_mask, b_mask)
+    assert a.shape == (B, dim * dim, C) and float(a.float().abs().sum()) > 0

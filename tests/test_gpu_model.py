@@ -141,6 +141,8 @@ OBJ_CASES = [
                       pretrain_tasks=("mlm", "mrc", "sap", "og")), ("mlm", "mrc", "sap", "og")),
     ("tiny_objlin", dict(image_feat_size=512, obj_feat_size=640, obj_prob_size=50, num_l_layers=1, num_x_layers=1,
                          pretrain_tasks=("mrc", "og")), ("mrc", "og")),
+    ("tiny_ce", dict(bev_dim=11, bev_res=1.0, depth_feat_size=128, loc_feat_size=4, nav_type_vocab=2, sem_classes=0,
+                     pretrain_tasks=("mlm", "sap")), ("mlm", "sap")),     # continuous-environment fork (bevbert_ce)
 ]
 
 
@@ -367,3 +369,37 @@ def test_rccl_reducer_path_single_rank(env):
         assert float((results[0] - results[1]).abs().max()) < 1e-6
     finally:
         dist.destroy_process_group()
+
+
+def test_batches_from_resident_grid_feature_store(env):
+    """f1: a batch that names rows of a device-resident GridFeatureStore (fp16 features, uint8 class ids, read in place
+    by the splat kernel) gives exactly the losses of the same batch shipped as tensors, and matches the oracle run on
+    the fp16-rounded features."""
+    from vln_bevbert_amd import weights
+    from vln_bevbert_amd.feature_store import GridFeatureStore
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    model = GlocalTextPathCMTPreTraining(cfg)
+    sd = weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd)
+    model.tie_weights()
+    model.finalize(DEV, torch.float32)
+    model.eval()
+    # a "dataset" of 6 viewpoints; each batch draws 3 of them
+    pool = synthetic.make_batch(cfg, "sap", 6, seed=21, ragged=True, sems_as="ids")
+    keys = [f"scan_{i}" for i in range(6)]
+    store = GridFeatureStore(keys, pool["rgbs"], pool["depths"], pool["sems"], DEV)
+    assert store.nbytes() == 6 * (2352 * 768 * 2 + 2352 * 4 + 2352)
+    pick = [4, 1, 5]
+    for task in ("sap", "masksem", "mlm"):
+        b = synthetic.make_batch(cfg, task, 3, seed=33, ragged=True, sems_as="ids")
+        b["rgbs"] = pool["rgbs"][pick].half().float()            # what the store holds, widened
+        b["depths"], b["sems"] = pool["depths"][pick], pool["sems"][pick]
+        with torch.no_grad():
+            as_tensors = model(synthetic.batch_to(b, DEV), task).cpu()
+            via_store = model(store.attach(synthetic.batch_to(b, DEV), [keys[i] for i in pick]), task).cpu()
+            ob = dict(b)
+            ob["sems"] = torch.from_numpy(np.eye(cfg.sem_classes)[b["sems"].reshape(3, -1).numpy()])
+            want = R.pretrain_forward(sd, cfg, ob, task)
+        assert torch.equal(via_store, as_tensors), task
+        assert max_abs(via_store.numpy(), want.numpy()) < FP32_TOL, task

@@ -59,7 +59,9 @@ def test_cpu_tensors_fail_loudly():
 def test_state_dict_keys_match_the_reference():
     from vln_bevbert_amd.nav_model import GlocalTextPathNavCMT, remap_pretrain_checkpoint
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
-    for cfg, f in ((BevBertConfig.tiny(), "pretrain_state_dict_keys_tiny.txt"),):
+    ce = BevBertConfig.ce(num_l_layers=2, num_x_layers=2, num_pano_layers=1, vocab_size=1200, max_position_embeddings=128)
+    for cfg, f in ((ce, "pretrain_state_dict_keys_tiny_ce.txt"),         # continuous-environment fork (bevbert_ce)
+                   (BevBertConfig.tiny(), "pretrain_state_dict_keys_tiny.txt")):
         m = GlocalTextPathCMTPreTraining(cfg)
         assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == read_shapes(f)
         assert m.mlm_head.predictions.decoder.weight is m.bert.embeddings.word_embeddings.weight
@@ -168,3 +170,25 @@ def test_synthetic_batches_are_deterministic_and_rank_distinct():
     assert not torch.equal(a["rgbs"], c["rgbs"])
     assert a["rgbs"].shape == (3, 12, 14, 14, 768) and a["traj_view_img_fts"].shape == (15, 36, 512)
     assert a["sems"].dtype == torch.float64 and (a["txt_labels"] != -1).any(1).all()
+
+
+def test_grid_feature_store_rows_and_attach():
+    """f1: batches are row numbers into a resident store; unknown viewpoints fail loudly."""
+    from vln_bevbert_amd.feature_store import GridFeatureStore
+    rng = np.random.default_rng(0)
+    keys = [f"scan{i // 3}_vp{i}" for i in range(7)]
+    rgbs = rng.standard_normal((7, 12, 14, 14, 8)).astype(np.float16)
+    depths = rng.random((7, 12, 14, 14)).astype(np.float32)
+    sems = rng.integers(0, 40, (7, 12, 14, 14)).astype(np.uint8)
+    st = GridFeatureStore(keys, rgbs, depths, sems, "cpu")
+    assert len(st) == 7 and st.P == 2352 and st.rgbs.shape == (7, 2352, 8) and st.rgbs.dtype == torch.float16
+    assert st.nbytes() == 7 * (2352 * 8 * 2 + 2352 * 4 + 2352)
+    rows = st.rows(["scan1_vp4", "scan0_vp0", "scan1_vp4"])
+    assert rows.dtype == torch.int32 and rows.tolist() == [4, 0, 4]
+    r, d, s = st.gather(rows)
+    assert torch.equal(r[0], torch.from_numpy(rgbs[4].reshape(2352, 8))) and torch.equal(d[1], torch.from_numpy(depths[0]))
+    assert torch.equal(s[2], torch.from_numpy(sems[4].reshape(-1)))
+    b = st.attach({"rgbs": 1, "depths": 2, "sems": 3, "txt_ids": 4}, ["scan2_vp6"])
+    assert set(b) == {"txt_ids", "grid_store", "grid_rows"} and b["grid_rows"].tolist() == [6]
+    with pytest.raises(KeyError, match="not in the grid-feature store"):
+        st.rows(["scan9_vp99"])

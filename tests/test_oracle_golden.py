@@ -135,9 +135,13 @@ def test_tasks_full_r2r_config():
                       pretrain_tasks=("mlm", "mrc", "sap", "og")), ("mlm", "mrc", "sap", "og")),
     ("tiny_objlin", dict(image_feat_size=512, obj_feat_size=640, obj_prob_size=50, num_l_layers=1, num_x_layers=1,
                          pretrain_tasks=("mrc", "og")), ("mrc", "og")),
+    ("tiny_ce", dict(bev_dim=11, bev_res=1.0, depth_feat_size=128, loc_feat_size=4, nav_type_vocab=2, sem_classes=0,
+                     pretrain_tasks=("mlm", "sap")), ("mlm", "sap")),     # continuous-environment fork (bevbert_ce)
 ])
 def test_object_token_tasks(tag, kw, tasks):
-    """REVERIE-style object tokens: panorama + BEV object branch, MRC and OG heads (pretrain_cmt.py:272-297,367-389)."""
+    """REVERIE-style object tokens: panorama + BEV object branch, MRC and OG heads (pretrain_cmt.py:272-297,367-389);
+    and the continuous-environment fork's model (depth-feature branch, 11x11 BEV at 1 m, no semantics), whose golden
+    vectors come from bevbert_ce/pretrain/pretrain_src."""
     cfg = BevBertConfig.tiny(**kw)
     g = load_golden(f"tasks_{tag}")
     sd = rule_state_dict(f"pretrain_state_dict_keys_{tag}.txt")

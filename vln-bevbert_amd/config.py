@@ -26,6 +26,9 @@ class BevBertConfig:
         angle_feat_size=4,
         obj_feat_size=0,
         obj_prob_size=0,
+        depth_feat_size=0,     # continuous-environment fork: DD-PPO depth features per view (bevbert_ce r2r_model_config_dep.json)
+        loc_feat_size=None,    # None -> angle_feat_size + 3 (vilmodel.py:471); the CE fork uses angle_feat_size alone
+        nav_type_vocab=3,      # 0 non-navigable, 1 navigable, 2 object (vilmodel.py:480-481); CE fork: 2
         num_l_layers=9,
         num_x_layers=4,
         num_pano_layers=2,
@@ -57,6 +60,8 @@ class BevBertConfig:
         for k, v in kw.items():
             setattr(self, k, v)
         self.pretrain_tasks = set(self.pretrain_tasks)
+        if self.loc_feat_size is None:
+            self.loc_feat_size = self.angle_feat_size + 3
 
     @classmethod
     def from_json_file(cls, path, **kw):
@@ -74,6 +79,15 @@ class BevBertConfig:
     def reverie(cls, **kw):
         # configs/rvr_model.json: ImageNet ViT features (768) + object tokens; tasks of scripts/pt_rvr.bash
         d = dict(image_feat_size=768, obj_feat_size=768, obj_prob_size=1000, pretrain_tasks=("mlm", "mrc", "sap", "og"))
+        d.update(kw)
+        return cls(**d)
+
+    @classmethod
+    def ce(cls, **kw):
+        """bevbert_ce/pretrain/run_pt/r2r_model_config_dep.json + pretrain_cmt.py:16-17: 11x11 BEV at 1 m, a depth-feature
+        branch in the panorama embedding, 4-d location features, 2 nav types, tasks mlm + sap, no semantics."""
+        d = dict(bev_dim=11, bev_res=1.0, depth_feat_size=128, loc_feat_size=4, nav_type_vocab=2, sem_classes=0,
+                 pretrain_tasks=("mlm", "sap"))
         d.update(kw)
         return cls(**d)
 

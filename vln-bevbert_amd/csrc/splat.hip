@@ -144,13 +144,17 @@ __global__ __launch_bounds__(256) void bev_splat_mean_kernel(const TI* __restric
                                                              const uint8_t* __restrict__ sem_ids,   // (B,P) or null
                                                              const double* __restrict__ sem_dense,  // (B,P,S) or null
                                                              int S, uint8_t* __restrict__ out_sem,  // (B,K,S)
-                                                             uint8_t* __restrict__ out_sem_mask) {  // (B,K)
+                                                             uint8_t* __restrict__ out_sem_mask,    // (B,K)
+                                                             const int* __restrict__ sample_rows) { // (B) or null
   const int cellg = blockIdx.x;  // b*K + cell
   const int b = cellg / K, cell = cellg - b * K;
+  // row of the feature / semantic-id arrays that holds sample b's points: b itself, or -- zero-copy batches drawn
+  // from a device-resident feature store -- the store row of the sample's viewpoint
+  const size_t src = sample_rows != nullptr ? (size_t)sample_rows[b] : (size_t)b;
   const int s0 = cell_start[(size_t)b * (K + 1) + cell];
   const int n = cell_start[(size_t)b * (K + 1) + cell + 1] - s0;
   const int* ord = order + (size_t)b * P + s0;
-  const TI* fb = feat + (size_t)b * P * C;
+  const TI* fb = feat + src * P * C;
   const float inv_denominator = (float)(n > 1 ? n : 1);
 
   for (int c4 = threadIdx.x; c4 * 4 < C; c4 += blockDim.x) {
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void bev_splat_mean_kernel(const TI* __restric
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
       uint8_t flag = 0;
       if (sem_ids != nullptr) {
-        const uint8_t* sb = sem_ids + (size_t)b * P;
+        const uint8_t* sb = sem_ids + src * P;
         for (int i = 0; i < n; ++i) flag |= (uint8_t)(sb[ord[i]] == (uint8_t)c);
       } else {
         // dense (one-hot, fp64 in the reference): mean > 0 -> 1 (bev_utils.py:417-422)
@@ -237,11 +241,11 @@ BEVBERT_API int bevbert_bev_bin_points(const float* points, const uint8_t* drop_
 template <typename TI, typename TO>
 static int launch_splat(const void* feat, const int* order, const int* cell_start, void* out, int B, int P, int K,
                         int C, const uint8_t* sem_ids, const double* sem_dense, int S, uint8_t* out_sem,
-                        uint8_t* out_sem_mask, hipStream_t stream) {
+                        uint8_t* out_sem_mask, const int* sample_rows, hipStream_t stream) {
   const int threads = (C / 4 >= 192) ? 192 : ((C / 4 + 63) / 64) * 64;
   hipLaunchKernelGGL((bev_splat_mean_kernel<TI, TO>), dim3(B * K), dim3(threads < 64 ? 64 : threads), 0, stream,
                      (const TI*)feat, order, cell_start, (TO*)out, P, K, C, sem_ids, sem_dense, S, out_sem,
-                     out_sem_mask);
+                     out_sem_mask, sample_rows);
   BB_CHECK_LAUNCH("bev_splat_mean");
   return BB_OK;
 }
@@ -249,12 +253,14 @@ static int launch_splat(const void* feat, const int* order, const int* cell_star
 BEVBERT_API int bevbert_bev_splat_mean(const void* feat, int feat_dtype, const int* order, const int* cell_start,
                                        void* out, int out_dtype, int B, int P, int K, int C, const uint8_t* sem_ids,
                                        const double* sem_dense, int S, uint8_t* out_sem, uint8_t* out_sem_mask,
-                                       hipStream_t stream) {
+                                       const int* sample_rows, hipStream_t stream) {
   BB_REQUIRE(C % 4 == 0, "bev_splat_mean: C=%d must be a multiple of 4", C);
+  BB_REQUIRE(sample_rows == nullptr || sem_dense == nullptr,
+             "bev_splat_mean: sample_rows indexes feat / sem_ids stores; dense semantics are per batch");
   BB_REQUIRE(out_sem == nullptr || (sem_ids != nullptr) != (sem_dense != nullptr),
              "bev_splat_mean: exactly one of sem_ids / sem_dense when semantics are requested");
 #define GO(TI, TO) \
-  return launch_splat<TI, TO>(feat, order, cell_start, out, B, P, K, C, sem_ids, sem_dense, S, out_sem, out_sem_mask, stream)
+  return launch_splat<TI, TO>(feat, order, cell_start, out, B, P, K, C, sem_ids, sem_dense, S, out_sem, out_sem_mask, sample_rows, stream)
   if (feat_dtype == BB_F32 && out_dtype == BB_F32) GO(float, float);
   if (feat_dtype == BB_F32 && out_dtype == BB_BF16) GO(float, bf16_raw);
   if (feat_dtype == BB_BF16 && out_dtype == BB_F32) GO(bf16_raw, float);

@@ -913,9 +913,12 @@ def bev_bin_points(points, drop_mask, dim, res, y_clip=0.5):
 
 
 @torch.no_grad()
-def bev_splat_mean(feat, order, cell_start, K, out_dtype=None, sems=None, n_classes=40):
-    """feat (B,P,C) f32/bf16/f16 -> (B,K,C); sems: (B,P) uint8 ids or (B,P,S) float64 one-hot or None."""
-    B, P, C = feat.shape
+def bev_splat_mean(feat, order, cell_start, K, out_dtype=None, sems=None, n_classes=40, rows=None):
+    """feat (B,P,C) f32/bf16/f16 -> (B,K,C); sems: (B,P) uint8 ids or (B,P,S) float64 one-hot or None.
+    rows (B) int32: feat / sems are (N,P,...) stores and sample b reads row rows[b] (feature_store.GridFeatureStore)."""
+    _, P, C = feat.shape
+    B = order.shape[0]
+    assert feat.is_contiguous() if rows is not None else True
     feat = feat.contiguous()
     out_dtype = out_dtype or (feat.dtype if feat.dtype != torch.float16 else torch.float32)
     out = torch.empty(B, K, C, dtype=out_dtype, device=feat.device)
@@ -924,13 +927,15 @@ def bev_splat_mean(feat, order, cell_start, K, out_dtype=None, sems=None, n_clas
     if sems is not None:
         if sems.dim() == 2:
             sem_ids = sems.contiguous().to(torch.uint8)
+            assert sem_ids.shape[1] == P and (rows is not None or sem_ids.shape[0] == B)
         else:
             sem_dense = sems.contiguous().to(torch.float64)
             S = sems.shape[-1]
         out_sem = torch.empty(B, K, S, dtype=torch.uint8, device=feat.device)
         out_mask = torch.empty(B, K, dtype=torch.uint8, device=feat.device)
     call("bevbert_bev_splat_mean", ptr(feat), dtype_code(feat), ptr(order), ptr(cell_start), ptr(out),
-         dtype_code(out_dtype), B, P, K, C, ptr(sem_ids), ptr(sem_dense), S, ptr(out_sem), ptr(out_mask), stream())
+         dtype_code(out_dtype), B, P, K, C, ptr(sem_ids), ptr(sem_dense), S, ptr(out_sem), ptr(out_mask),
+         ptr(rows), stream())
     return out, out_sem, out_mask
 
 

@@ -163,26 +163,34 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         return self._proj
 
     def lift_splat(self, batch):
+        """pretrain_cmt.py:114-167.  Grid inputs come either as the reference's per-batch tensors (rgbs, depths, sems)
+        or as rows of a device-resident feature_store.GridFeatureStore ('grid_store' + 'grid_rows', zero-copy)."""
         cfg = self.config
-        rgbs, depths, sems = batch.pop("rgbs"), batch.pop("depths"), batch.pop("sems")
         T_c2w, T_w2c, S_w2c = batch.pop("T_c2w"), batch.pop("T_w2c"), batch.pop("S_w2c")
         bev_gpos_fts = batch.pop("bev_gpos_fts")
-        B = rgbs.shape[0]
+        store, rows = batch.pop("grid_store", None), batch.pop("grid_rows", None)
+        if store is not None:
+            feat, sem_in = store.rgbs, (store.sems if cfg.sem_classes > 0 else None)
+            depths = store.depths.index_select(0, rows.long())          # 9.4 KB per sample
+        else:
+            rgbs, depths, sems = batch.pop("rgbs"), batch.pop("depths"), batch.pop("sems", None)
+            feat = rgbs.reshape(rgbs.shape[0], -1, rgbs.shape[-1])
+            sem_in = None if sems is None else (sems if sems.dim() == 2 else sems.reshape(feat.shape[0], feat.shape[1], -1))
+        B = depths.shape[0]
+        dev = depths.device
         dim, K = cfg.bev_dim, cfg.bev_dim * cfg.bev_dim
-        pix, polar = self._projector(rgbs.device)
+        pix, polar = self._projector(dev)
         cell, order, cell_start = ops.bev_lift_bin(depths, T_c2w, T_w2c, S_w2c, pix, dim, cfg.bev_res)
         cd = ops._compute(self.bert.local_encoder.bev_fts_embeddings[0].weight).dtype
-        feat = rgbs.reshape(B, -1, rgbs.shape[-1])
-        sem_in = sems if sems.dim() == 2 else sems.reshape(B, feat.shape[1], -1)
         bev_fts, bev_sems, bev_sem_masks = ops.bev_splat_mean(feat, order, cell_start, K, out_dtype=cd, sems=sem_in,
-                                                              n_classes=cfg.sem_classes)
+                                                              n_classes=cfg.sem_classes, rows=rows)
         bev_pos_fts = torch.cat([bev_gpos_fts.expand(-1, K, -1), polar[None].expand(B, -1, -1)], dim=-1)
         batch.update({
             "bev_fts": bev_fts,
-            "bev_masks": torch.ones(B, K, dtype=torch.bool, device=rgbs.device),   # pretrain_cmt.py:152
+            "bev_masks": torch.ones(B, K, dtype=torch.bool, device=dev),           # pretrain_cmt.py:152
             "bev_pos_fts": bev_pos_fts,
             "bev_sems": bev_sems,
-            "bev_sem_masks": bev_sem_masks.bool(),
+            "bev_sem_masks": None if bev_sem_masks is None else bev_sem_masks.bool(),
             "_bev_masks_all_ones": True,
             "_bev_cell": cell,
         })
@@ -228,8 +236,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
 
     # -- tasks --------------------------------------------------------------------------------------
     def _host_kw(self, b):
-        return {"view_lens_host": b.get("traj_vp_view_lens_cpu"), "obj_lens_host": b.get("traj_vp_obj_lens_cpu"),
-                "gmap_csr": b.get("gmap_csr")}
+        kw = {"view_lens_host": b.get("traj_vp_view_lens_cpu"), "obj_lens_host": b.get("traj_vp_obj_lens_cpu"),
+              "gmap_csr": b.get("gmap_csr")}
+        if getattr(self.config, "depth_feat_size", 0) > 0:           # continuous-environment fork
+            kw["traj_view_dep_fts"] = b["traj_view_dep_fts"]
+        return kw
 
     def forward_mrc(self, b, compute_loss):
         """pretrain_cmt.py:272-297: masked-region classification on the object tokens (KL to detector probs)."""

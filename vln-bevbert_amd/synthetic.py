@@ -78,15 +78,19 @@ def make_sample(rng, i, cfg, n_steps, txt_len, ragged_views=False):
         if t % 2 == 0:
             c.append(f"s{i}")                # seen from several steps -> averaged
         cands.append(c)
-    view_fts, loc_fts, nav_types, view_lens, obj_fts, obj_lens = [], [], [], [], [], []
+    view_fts, loc_fts, nav_types, view_lens, obj_fts, obj_lens, dep_fts = [], [], [], [], [], [], []
     has_obj = getattr(cfg, "obj_feat_size", 0) > 0
+    dep_size = getattr(cfg, "depth_feat_size", 0)
+    loc_size = getattr(cfg, "loc_feat_size", None) or cfg.angle_feat_size + 3
     for t in range(n_steps):
         nv = N_VIEWS + (int(rng.integers(0, 3)) if ragged_views else 0)
         view_fts.append(rng.standard_normal((nv, cfg.image_feat_size)).astype(np.float32))
         ang = rng.uniform(-math.pi, math.pi, size=(nv, 2))
         loc = np.concatenate(
             [np.sin(ang[:, :1]), np.cos(ang[:, :1]), np.sin(ang[:, 1:]), np.cos(ang[:, 1:]),
-             np.ones((nv, 3))], 1).astype(np.float32)
+             np.ones((nv, 3))], 1).astype(np.float32)[:, :loc_size]
+        if dep_size:        # CE fork: one DD-PPO depth feature per view
+            dep_fts.append(rng.standard_normal((nv, dep_size)).astype(np.float32))
         nt = [1] * len(cands[t]) + [0] * (nv - len(cands[t]))
         if has_obj:     # REVERIE: object tokens follow the views (dataset.py:283-321): loc = [angle(4), box(3)], type 2
             no = int(rng.integers(0, 5)) if ragged_views else 3
@@ -105,6 +109,8 @@ def make_sample(rng, i, cfg, n_steps, txt_len, ragged_views=False):
         view_lens.append(nv)
     s.update(traj_view_img_fts=view_fts, traj_loc_fts=loc_fts, traj_nav_types=nav_types,
              traj_vp_view_lens=view_lens, traj_vpids=path, traj_cand_vpids=cands)
+    if dep_size:
+        s["traj_view_dep_fts"] = dep_fts
     if has_obj:
         no = obj_lens[-1]
         logits = rng.standard_normal((no, cfg.obj_prob_size))
@@ -147,7 +153,7 @@ def make_sample(rng, i, cfg, n_steps, txt_len, ragged_views=False):
     dep = rng.uniform(0, 0.6, size=(V, 1, hw, hw)).astype(np.float32)
     dep[rng.random(dep.shape) < 0.05] = 0.0
     s["depths"] = dep
-    s["sem_ids"] = rng.integers(0, cfg.sem_classes, size=(P,)).astype(np.int64)
+    s["sem_ids"] = rng.integers(0, max(1, cfg.sem_classes), size=(P,)).astype(np.int64)
     xyz = rng.uniform(-5, 5, size=3)
     xyzhe = np.zeros((V, 5), dtype=np.float32)
     xyzhe[:, 0], xyzhe[:, 1], xyzhe[:, 2] = xyz
@@ -210,6 +216,8 @@ def collate(samples, cfg, task, rng, sems_as="onehot64"):
     b["traj_vp_view_lens"] = torch.tensor(flat("traj_vp_view_lens"), dtype=torch.long)
     b["traj_view_img_fts"] = torch.from_numpy(_pad_stack(flat("traj_view_img_fts")))
     b["traj_loc_fts"] = torch.from_numpy(_pad_stack(flat("traj_loc_fts")))
+    if "traj_view_dep_fts" in samples[0]:
+        b["traj_view_dep_fts"] = torch.from_numpy(_pad_stack(flat("traj_view_dep_fts")))
     b["traj_nav_types"] = torch.from_numpy(
         _pad_stack([np.asarray(v, dtype=np.int64) for v in flat("traj_nav_types")]))
     b["traj_vpids"] = [s["traj_vpids"] for s in samples]
@@ -245,7 +253,9 @@ def collate(samples, cfg, task, rng, sems_as="onehot64"):
     b["rgbs"] = torch.from_numpy(np.stack([s["rgbs"] for s in samples]))
     b["depths"] = torch.from_numpy(np.stack([s["depths"] for s in samples]))
     sem_ids = np.stack([s["sem_ids"] for s in samples])
-    if sems_as == "onehot64":
+    if cfg.sem_classes <= 0:            # continuous-environment fork: no semantic maps in the batch
+        pass
+    elif sems_as == "onehot64":
         b["sems"] = torch.from_numpy(np.eye(cfg.sem_classes)[sem_ids])          # float64
     else:
         b["sems"] = torch.from_numpy(sem_ids.astype(np.uint8))

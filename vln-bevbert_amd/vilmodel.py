@@ -351,19 +351,25 @@ class ImageEmbeddings(nn.Module):
         H = config.hidden_size
         self.img_linear = nn.Linear(config.image_feat_size, H)
         self.img_layer_norm = nn.LayerNorm(H, eps=1e-12)
-        self.loc_linear = nn.Linear(config.angle_feat_size + 3, H)
+        self.loc_linear = nn.Linear(getattr(config, "loc_feat_size", config.angle_feat_size + 3), H)
         self.loc_layer_norm = nn.LayerNorm(H, eps=1e-12)
+        if getattr(config, "depth_feat_size", 0) > 0:      # bevbert_ce/pretrain/pretrain_src/model/vilmodel.py:473-477
+            self.dep_linear = nn.Linear(config.depth_feat_size, H)
+            self.dep_layer_norm = nn.LayerNorm(H, eps=1e-12)
+        else:
+            self.dep_linear = self.dep_layer_norm = None
         if config.obj_feat_size > 0 and config.obj_feat_size != config.image_feat_size:
             self.obj_linear = nn.Linear(config.obj_feat_size, H)
             self.obj_layer_norm = nn.LayerNorm(H, eps=1e-12)
         else:
             self.obj_linear = self.obj_layer_norm = None
-        self.nav_type_embedding = nn.Embedding(3, H)
+        self.nav_type_embedding = nn.Embedding(getattr(config, "nav_type_vocab", 3), H)
         self.layer_norm = nn.LayerNorm(H, eps=1e-12)
         self.drop_p = config.hidden_dropout_prob
         self.pano_encoder = TransformerEncoder(config, config.num_pano_layers) if config.num_pano_layers > 0 else None
 
-    def embed(self, view_img_fts, loc_fts, nav_types, view_lens, type_embed_layer, obj_img_fts=None, obj_lens=None):
+    def embed(self, view_img_fts, loc_fts, nav_types, view_lens, type_embed_layer, obj_img_fts=None, obj_lens=None,
+              view_dep_fts=None):
         """Shared by forward (pre-training) and forward_panorama_per_step (fine-tuning).
 
         Object tokens (REVERIE / SOON, vilmodel.py:502-516) follow the views of their panorama: the reference
@@ -373,6 +379,11 @@ class ImageEmbeddings(nn.Module):
         x = ops.linear(view_img_fts.to(cd), self.img_linear.weight)
         e = ops.bias_dropout_residual_layernorm(x, self.img_linear.bias, None, self.img_layer_norm.weight,
                                                 self.img_layer_norm.bias, 1e-12)
+        if self.dep_linear is not None:         # CE fork (its vilmodel.py:507-509): + LN(dep_linear(depth features))
+            assert view_dep_fts is not None, "this configuration (depth_feat_size > 0) needs traj_view_dep_fts"
+            xd = ops.linear(view_dep_fts.to(cd), self.dep_linear.weight)
+            e = e + ops.bias_dropout_residual_layernorm(xd, self.dep_linear.bias, None, self.dep_layer_norm.weight,
+                                                        self.dep_layer_norm.bias, 1e-12)
         lens = view_lens
         if obj_img_fts is not None:
             lin, ln = (self.img_linear, self.img_layer_norm) if self.obj_linear is None \
@@ -399,9 +410,9 @@ class ImageEmbeddings(nn.Module):
         return e, masks
 
     def forward(self, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types, traj_step_lens,
-                traj_vp_view_lens, traj_vp_obj_lens, type_embed_layer):
+                traj_vp_view_lens, traj_vp_obj_lens, type_embed_layer, traj_view_dep_fts=None):
         e, _ = self.embed(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, type_embed_layer,
-                          traj_obj_img_fts, traj_vp_obj_lens)
+                          traj_obj_img_fts, traj_vp_obj_lens, traj_view_dep_fts)
         lens = traj_vp_view_lens if traj_obj_img_fts is None else traj_vp_view_lens + traj_vp_obj_lens
         return torch.split(e, traj_step_lens, 0), torch.split(lens, traj_step_lens, 0)
 
@@ -563,9 +574,10 @@ class GlocalTextPathCMT(nn.Module):
         return self.lang_encoder(self.embeddings(txt_ids), txt_masks), txt_masks
 
     def _traj(self, traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts=None,
-              traj_vp_obj_lens=None):
+              traj_vp_obj_lens=None, traj_view_dep_fts=None):
         e, masks = self.img_embeddings.embed(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens,
-                                             self.embeddings.token_type_embeddings, traj_obj_img_fts, traj_vp_obj_lens)
+                                             self.embeddings.token_type_embeddings, traj_obj_img_fts, traj_vp_obj_lens,
+                                             traj_view_dep_fts)
         return e
 
     @staticmethod
@@ -613,17 +625,18 @@ class GlocalTextPathCMT(nn.Module):
                 traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
                 gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
                 bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, return_gmap_embeds=True, view_lens_host=None,
-                obj_lens_host=None, gmap_csr=None):
+                obj_lens_host=None, gmap_csr=None, traj_view_dep_fts=None):
         has_obj = traj_obj_img_fts is not None
         br = ops.Branches(txt_ids.device)
         gmap_embeds = obj_embeds = obj_masks = traj = None
         need_traj = return_gmap_embeds or has_obj
         # side stream: panorama encoder (independent of the text);  current stream: text encoder
-        br.fork(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts, traj_vp_obj_lens)
+        br.fork(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts, traj_vp_obj_lens,
+                traj_view_dep_fts)
         if need_traj:
             with br.side():
                 traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts,
-                                  traj_vp_obj_lens)
+                                  traj_vp_obj_lens, traj_view_dep_fts)
             tok_lens, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host,
                                                       obj_lens_host)
         txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
@@ -648,12 +661,13 @@ class GlocalTextPathCMT(nn.Module):
                     traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
                     gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
                     bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, view_lens_host=None, obj_lens_host=None,
-                    gmap_csr=None):
+                    gmap_csr=None, traj_view_dep_fts=None):
         br = ops.Branches(txt_ids.device)
-        br.fork(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts, traj_vp_obj_lens)
+        br.fork(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts, traj_vp_obj_lens,
+                traj_view_dep_fts)
         with br.side():         # panorama encoder next to the text encoder
             traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts,
-                              traj_vp_obj_lens)
+                              traj_vp_obj_lens, traj_view_dep_fts)
         txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
         tm = neg_key_mask(txt_masks)
         tok_lens, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host, obj_lens_host)
@@ -685,14 +699,14 @@ class GlocalTextPathCMT(nn.Module):
                     traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
                     gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
                     bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, sem_pred_token=None, view_lens_host=None,
-                    obj_lens_host=None, gmap_csr=None):
+                    obj_lens_host=None, gmap_csr=None, traj_view_dep_fts=None):
         bm = _all_ones_to_none(bev_masks)
         if sem_pred_token == "cattn":
             txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
             obj_embeds = obj_masks = None
             if traj_obj_img_fts is not None:
                 traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens,
-                                  traj_obj_img_fts, traj_vp_obj_lens)
+                                  traj_obj_img_fts, traj_vp_obj_lens, traj_view_dep_fts)
                 _, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host, obj_lens_host)
                 obj_embeds, obj_masks = self._obj_tokens(traj, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens,
                                                          ol_host)
@@ -720,6 +734,33 @@ def _all_ones_to_none(mask):
 
 
 # ----------------------------------------------------------------------------- arena wiring
+class GlocalTextPathCMTCE(GlocalTextPathCMT):
+    """The continuous-environment fork's positional signatures (bevbert_ce/pretrain/pretrain_src/model/vilmodel.py:717-
+    776,778-840): ``traj_view_dep_fts`` follows ``traj_view_img_fts`` and ``forward`` returns (gmap_embeds, bev_embeds)."""
+
+    def forward(self, txt_ids, txt_lens, traj_view_img_fts, traj_view_dep_fts, traj_obj_img_fts, traj_loc_fts,
+                traj_nav_types, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
+                gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
+                bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, return_gmap_embeds=True, **host_kw):
+        g, b, _, _ = super().forward(txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts,
+                                     traj_nav_types, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids,
+                                     traj_cand_vpids, gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists,
+                                     gmap_vpids, bev_fts, bev_pos_fts, bev_masks, bev_nav_masks,
+                                     return_gmap_embeds=return_gmap_embeds, traj_view_dep_fts=traj_view_dep_fts,
+                                     **host_kw)
+        return g, b
+
+    def forward_mlm(self, txt_ids, txt_lens, traj_view_img_fts, traj_view_dep_fts, traj_obj_img_fts, traj_loc_fts,
+                    traj_nav_types, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids,
+                    gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids,
+                    bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, **host_kw):
+        return super().forward_mlm(txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts,
+                                   traj_nav_types, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids,
+                                   traj_cand_vpids, gmap_lens, gmap_step_ids, gmap_pos_fts, gmap_pair_dists,
+                                   gmap_vpids, bev_fts, bev_pos_fts, bev_masks, bev_nav_masks,
+                                   traj_view_dep_fts=traj_view_dep_fts, **host_kw)
+
+
 def arena_groups(module):
     groups = []
     for name, m in module.named_modules():
