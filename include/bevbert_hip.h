@@ -98,6 +98,13 @@ int bevbert_layernorm_bwd(const void* dy, const void* z, const float* mean, cons
                           int H, int dtype, float drop_p, uint64_t seed, uint64_t offset, int accumulate,
                           hipStream_t stream);
 int64_t bevbert_colsum_workspace_floats(int total_cols);
+/* Split form of the parameter-gradient reductions: bevbert_layernorm_bwd / bevbert_bias_gelu_bwd called with NULL
+ * dgamma/dbeta/dbias leave per-block partial sums [bevbert_colsum_partial_rows(rows)][nwhich][C] (nwhich = 3 for
+ * LayerNorm: dgamma, dbeta, dbias; 1 for GELU) in `workspace`; bevbert_colsum_finalize folds them into the outputs
+ * (written, or accumulated when accumulate != 0; NULL outputs are skipped) -- typically on another stream. */
+int bevbert_colsum_partial_rows(int rows);
+int bevbert_colsum_finalize(const float* partials, int nblocks, int nwhich, int C, float* out0, float* out1,
+                            float* out2, int accumulate, hipStream_t stream);
 
 /* K5  BertEmbeddings.forward (vilmodel.py:62-77): y = LayerNorm(word[ids] + pos[row % L] + type_row) (+dropout). */
 int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const void* pos, const void* type_row,

@@ -520,6 +520,19 @@ static int colwise_blocks(int rows) {
 // workspace: >= bevbert_colsum_workspace_floats(3*H) floats
 BEVBERT_API int64_t bevbert_colsum_workspace_floats(int total_cols) { return (int64_t)512 * total_cols; }
 
+// Two-stage column reductions, split: layernorm_bwd / bias_gelu_bwd called with NULL parameter-gradient outputs leave
+// their per-block partial sums in `workspace` ([bevbert_colsum_partial_rows(rows)][nwhich][C] floats); this entry is the
+// second stage.  The host runs it on the weight-gradient stream, off the activation-gradient critical path.
+BEVBERT_API int bevbert_colsum_partial_rows(int rows) { return colwise_blocks(rows); }
+
+BEVBERT_API int bevbert_colsum_finalize(const float* partials, int nblocks, int nwhich, int C, float* out0, float* out1,
+                                        float* out2, int accumulate, hipStream_t stream) {
+  BB_REQUIRE(nblocks >= 1 && nwhich >= 1 && nwhich <= 3 && C >= 1, "colsum_finalize: bad shape (%d, %d, %d)", nblocks, nwhich, C);
+  launch_finalize(partials, nblocks, nwhich, C, out0, out1, out2, accumulate, stream);
+  BB_CHECK_LAUNCH("colsum_finalize");
+  return BB_OK;
+}
+
 BEVBERT_API int bevbert_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd,
                                       const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta,
                                       float* dbias, float* workspace, int rows, int H, int dtype, float drop_p,

@@ -78,6 +78,7 @@ _PROTOS = {
     "bevbert_dropout_keep_mask": [_P, _I64, _F, _U64, _U64, _P],
     "bevbert_gemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I, _I, _I, _F, _P,
                      _I64, _I, _P],
+    "bevbert_colsum_finalize": [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     "bevbert_dropout_add": [_P, _P, _P, _I64, _I, _I, _F, _U64, _U64, _P],
     "bevbert_gemm_run": [_I, _P, _P, _P, _P, _P, _I64, _P],
 }
@@ -99,6 +100,8 @@ def load():
     lib.bevbert_colsum_workspace_floats.restype = _I64
     lib.bevbert_colsum_workspace_floats.argtypes = [_I]
     lib.bevbert_gemm_plan_count.restype = _I
+    lib.bevbert_colsum_partial_rows.restype = _I
+    lib.bevbert_colsum_partial_rows.argtypes = [_I]
     lib.bevbert_gemm_plan.restype = _I
     lib.bevbert_gemm_plan.argtypes = [_I, _I, _I, _I, _I, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I, _I, _I, _I, _I64, _I]
     for name, args in _PROTOS.items():

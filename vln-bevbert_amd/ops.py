@@ -134,6 +134,7 @@ class WgradStream:
     # 23.3 with this stream, 22.8 with the branch stream)
     enabled = _os.environ.get("BEVBERT_WGRAD_STREAM", "1") == "1" and not Branches.enabled
     BATCH = int(_os.environ.get("BEVBERT_WGRAD_BATCH", "6"))
+    DEFER_FINALIZE = _os.environ.get("BEVBERT_DEFER_FINALIZE", "1") == "1"      # A/B knob for the split reductions
     stream = None
     _keep = []
     _pending = {}        # producing stream handle -> (torch stream, [closures])
@@ -372,6 +373,17 @@ def _param_grads(w_sink, b_sink, dyc, xc):
         call("bevbert_colsum", ptr(dyc), ptr(b_sink), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 1, stream())
 
 
+_PARTIAL_ROWS = {}
+
+
+def _partial_rows(rows):
+    """number of per-block partial rows the two-stage column reductions produce for `rows` input rows"""
+    nb = _PARTIAL_ROWS.get(rows)
+    if nb is None:
+        nb = _PARTIAL_ROWS[rows] = lib.load().bevbert_colsum_partial_rows(rows)
+    return nb
+
+
 def _sink(param):
     """fp32 accumulation target of a parameter, or None for plain tensors."""
     return getattr(param, "main_grad", None)
@@ -467,8 +479,18 @@ class _BiasDropResLN(torch.autograd.Function):
             dx, dz_ptr = dz, None
         else:
             dz_ptr = dz
-        call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz_ptr), ptr(dx),
-             ptr(dg), ptr(db), ptr(dbi), ptr(ws), rows, H, dtype_code(dy), drop_p, seed, off, ag, stream())
+        if ag == 1 and WgradStream.DEFER_FINALIZE and WgradStream.active(dev):
+            # arena parameters: the kernel leaves its per-block partial sums in a private buffer and the second stage
+            # of the reduction runs on the weight-gradient stream, off the activation-gradient critical path
+            nb = _partial_rows(rows)
+            part = torch.empty(nb * 3 * H, dtype=torch.float32, device=dev)
+            call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz_ptr), ptr(dx),
+                 None, None, None, ptr(part), rows, H, dtype_code(dy), drop_p, seed, off, 1, stream())
+            WgradStream.submit(dev, lambda: call("bevbert_colsum_finalize", ptr(part), nb, 3, H, ptr(dg), ptr(db),
+                                                 ptr(dbi), 1, stream()), part)
+        else:
+            call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz_ptr), ptr(dx),
+                 ptr(dg), ptr(db), ptr(dbi), ptr(ws), rows, H, dtype_code(dy), drop_p, seed, off, ag, stream())
         gx = dx if dx is not None else dz
         gres = dz if has_res else None
         cast = lambda r, p: None if r is None else r.to(p.dtype)
@@ -549,6 +571,14 @@ class _BiasGelu(torch.autograd.Function):
         sink = _sink(bias)
         if sink is not None:
             _mark_touched(bias)
+            if WgradStream.DEFER_FINALIZE and WgradStream.active(dy.device):      # second reduction stage on the weight-gradient stream (see _BiasDropResLN)
+                nb = _partial_rows(rows)
+                part = torch.empty(nb * C, dtype=torch.float32, device=dy.device)
+                call("bevbert_bias_gelu_bwd", ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), None, ptr(part), rows, C,
+                     dtype_code(dy), 1, stream())
+                WgradStream.submit(dy.device, lambda: call("bevbert_colsum_finalize", ptr(part), nb, 1, C, ptr(sink),
+                                                           None, None, 1, stream()), part)
+                return dx, None
             call("bevbert_bias_gelu_bwd", ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), ptr(sink), ptr(ws), rows, C,
                  dtype_code(dy), 1, stream())
             return dx, None
