@@ -96,7 +96,11 @@ class Branches:
 
     @classmethod
     def side_streams(cls):
-        return list(cls._streams.values())
+        out = []
+        for st in cls._streams.values():
+            if all(st is not o for o in out):
+                out.append(st)
+        return out
 
     def fork(self, *tensors):
         if self.on:
@@ -129,10 +133,11 @@ class WgradStream:
     also joins the stream) instead of being tracked by the caching allocator -- with 288 GB of HBM the extra lifetime
     of one backward's activation gradients is free."""
 
-    # not combined with the model-branch side stream: that pairing stalled at batch 64 on the MI355X (unexplained),
-    # and either one alone already recovers the idle CUs (in-run A/B, batch 64: 24.9 ms/step with neither,
-    # 23.3 with this stream, 22.8 with the branch stream)
-    enabled = _os.environ.get("BEVBERT_WGRAD_STREAM", "1") == "1" and not Branches.enabled
+    # With the model-branch side stream on (ops.Branches) the deferred work SHARES that stream: three concurrent streams
+    # (main + branch + a separate weight-gradient stream) stalled at batch 64 on the MI355X (unexplained), two do not.
+    # In-run A/B at batch 64: 24.9 ms/step with neither, 23.3 with this stream alone (22.5 after the LayerNorm / GELU
+    # reduction tails moved here too), 22.8 with the branch stream alone, 23.6-24.5 with both on one shared stream.
+    enabled = _os.environ.get("BEVBERT_WGRAD_STREAM", "1") == "1"
     BATCH = int(_os.environ.get("BEVBERT_WGRAD_BATCH", "6"))
     DEFER_FINALIZE = _os.environ.get("BEVBERT_DEFER_FINALIZE", "1") == "1"      # A/B knob for the split reductions
     stream = None
@@ -169,13 +174,15 @@ class WgradStream:
         if not fns:
             return
         if cls.stream is None:
-            cls.stream = torch.cuda.Stream(producer.device)
+            shared = Branches._streams.get(producer.device.index) if Branches.enabled else None
+            cls.stream = shared if shared is not None else torch.cuda.Stream(producer.device)
             Branches._streams["wgrad"] = cls.stream       # joined by ParamArena.sync / GradReducer like the branches
             cls._events = [torch.cuda.Event() for _ in range(64)]
-        ev = cls._events[cls._next_event % len(cls._events)]
-        cls._next_event += 1
-        ev.record(producer)
-        cls.stream.wait_event(ev)
+        if producer.cuda_stream != cls.stream.cuda_stream:          # same stream: already in order
+            ev = cls._events[cls._next_event % len(cls._events)]
+            cls._next_event += 1
+            ev.record(producer)
+            cls.stream.wait_event(ev)
         lib.set_stream_override(cls.stream.cuda_stream)
         try:
             for fn in fns:
