@@ -162,8 +162,9 @@ int bevbert_accum_partials(const void* partials, float* sink, int S, int64_t n, 
  *   opA == 0: A stored M x K with row stride lda;  opA == 1: A stored K x M (row stride lda), used transposed.
  *   opB == 0: B stored K x N with row stride ldb;  opB == 1: B stored N x K (row stride ldb), used transposed.
  * in_dtype in {F32, BF16}; out_dtype == in_dtype or F32; bias (may be NULL) has dtype bias_dtype (F32 or out_dtype).
- * autotune > 1: on the first call of a shape, time the library's top `autotune` (<= 64) heuristic candidates on the
- * given operands (the product is recomputed, beta == 0) and keep the fastest.  Returns BB_EUNSUPPORTED (-3) when the
+ * autotune > 1: on the first call of a problem, time the library's top `autotune` (<= 64) heuristic candidates on the
+ * given operands (the product is recomputed, beta == 0) and keep the fastest; a problem listed in an imported tuning
+ * table starts with the recorded choice instead.  Returns BB_EUNSUPPORTED (-3) when the
  * library has no kernel for the problem.
  * bevbert_gemm_plan / bevbert_gemm_run split the same call in two so that the per-call path carries 8 arguments:
  * plan returns an id >= 0 (cached by problem; bias_dtype < 0 = no bias; accumulate != 0: C += product, used by the
@@ -179,6 +180,13 @@ int bevbert_gemm_plan(int M, int N, int K, int opA, int opB, int64_t lda, int64_
 int bevbert_gemm_run(int plan, const void* A, const void* B, void* C, const void* bias, void* workspace,
                      int64_t workspace_bytes, hipStream_t stream);
 int bevbert_gemm_plan_count(void);
+/* Tuning table (text): one line "<problem key> <choice> <ncand>" per autotuned plan after a header naming the hipBLASLt
+ * version.  export returns the bytes the text needs (incl. the final 0) and fills buf when cap suffices; import makes
+ * later plans reuse the recorded choice instead of timing candidates (returns the number of rows; -3 when the table
+ * belongs to another library version).  Shipping a table makes runs start tuned and removes run-to-run variation of
+ * the picks (and timing candidates under a profiler is unreliable). */
+int64_t bevbert_gemm_tuning_export(char* buf, int64_t cap);
+int bevbert_gemm_tuning_import(const char* text);
 
 /* y = residual + dropout(x) over n (multiple of 4) elements; residual may be NULL, y may alias x when the dtypes match.
  * Replaces the bare nn.Dropout sites of the path: feature dropout of the loader's fp32 features fused with their cast

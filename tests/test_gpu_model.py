@@ -353,19 +353,22 @@ def test_rccl_reducer_path_single_rank(env):
     try:
         cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
         results = []
-        for force in (False, True):
+        # the first pass only settles the hipBLASLt plans (the first launch of a problem times its candidates and leaves
+        # the product of whichever ran last): the two compared passes must use the final algorithms throughout
+        for force in (None, False, True):
             model = GlocalTextPathCMTPreTraining(cfg)
             model.load_state_dict(weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
             model.tie_weights()
             arena = model.finalize(DEV, torch.bfloat16)
             model.train()
             model.set_dropout(0.1)
-            tr = PretrainTrainer(model, arena, warmup_steps=2, num_train_steps=20, force_collectives=force)
-            assert tr.reducer.active == force and tr.overlap == force
+            tr = PretrainTrainer(model, arena, warmup_steps=2, num_train_steps=20, force_collectives=bool(force))
+            assert tr.reducer.active == bool(force) and tr.overlap == bool(force)
             for i, task in enumerate(("sap", "mlm", "masksem", "sap")):
                 tr.step(task, synthetic.batch_to(synthetic.make_batch(cfg, task, 2, seed=80 + i, ragged=True), DEV))
             torch.cuda.synchronize()
-            results.append(arena.params.clone())
+            if force is not None:
+                results.append(arena.params.clone())
         assert float((results[0] - results[1]).abs().max()) < 1e-6
     finally:
         dist.destroy_process_group()
@@ -396,6 +399,7 @@ def test_batches_from_resident_grid_feature_store(env):
         b["rgbs"] = pool["rgbs"][pick].half().float()            # what the store holds, widened
         b["depths"], b["sems"] = pool["depths"][pick], pool["sems"][pick]
         with torch.no_grad():
+            model(synthetic.batch_to(b, DEV), task)      # settles the hipBLASLt plans of this task's shapes
             as_tensors = model(synthetic.batch_to(b, DEV), task).cpu()
             via_store = model(store.attach(synthetic.batch_to(b, DEV), [keys[i] for i in pick]), task).cpu()
             ob = dict(b)

@@ -13,6 +13,7 @@
 // hipBLASLt is column-major, so the call is issued as C^T = op(B)^T . op(A)^T on the same memory.
 #include <hipblaslt/hipblaslt.h>
 
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -30,12 +31,16 @@ struct Plan {
   int64_t ws_limit = 0;
   size_t c_bytes = 0;
   int id = -1;
+  int choice = -1, ncand = 0;   // index of the chosen candidate in the heuristic's list of `ncand` (tuning table)
+  std::string key;
   bool ok = false, tuned = false, has_bias = false, accumulate = false;
 };
 
 hipblasLtHandle_t g_handle = nullptr;
 std::mutex g_mu;
 std::unordered_map<std::string, Plan> g_plans;
+// imported tuning table: problem key -> (choice, ncand); only honoured when the heuristic returns the same ncand
+std::unordered_map<std::string, std::pair<int, int>> g_tuning;
 
 hipDataType hip_dtype(int dt) { return dt == BB_F32 ? HIP_R_32F : (dt == BB_BF16 ? HIP_R_16BF : HIP_R_16F); }
 
@@ -110,11 +115,26 @@ int make_plan(const Problem& q, int64_t workspace_bytes, int autotune) {
   p.cand.resize(good && found > 0 ? found : 0);
   p.ok = !p.cand.empty();
   p.tuned = p.cand.size() <= 1;
+  p.key = key;
+  p.ncand = (int)p.cand.size();
+  p.choice = p.ok ? 0 : -1;
+  const auto imported = g_tuning.find(key);
+  if (p.ok && !p.tuned && imported != g_tuning.end() && imported->second.second == p.ncand &&
+      imported->second.first >= 0 && imported->second.first < p.ncand) {
+    p.choice = imported->second.first;       // a previous run timed this problem on this library: reuse its pick
+    p.tuned = true;
+  }
   p.has_bias = q.bias_dtype >= 0;
   p.accumulate = q.accumulate != 0;
   p.c_bytes = (size_t)(q.batch > 1 ? q.batch * q.sc : q.M * q.ldc) * (q.out_dtype == BB_F32 ? 4 : 2);
   p.ws_limit = workspace_bytes;
-  if (p.ok) p.algo = p.cand[0].algo;
+  if (p.ok && p.tuned &&
+      (p.cand[p.choice].state != HIPBLAS_STATUS_SUCCESS || (int64_t)p.cand[p.choice].workspaceSize > workspace_bytes)) {
+    p.ok = false;                 // the only / the recorded candidate is not usable here
+    p.choice = -1;
+  }
+  if (p.ok) p.algo = p.cand[p.choice].algo;
+  if (p.tuned) { p.cand.clear(); p.cand.shrink_to_fit(); }
   p.id = (int)g_plan_list.size();
   Plan* stored = &g_plans.emplace(key, std::move(p)).first->second;   // unordered_map nodes are address-stable
   g_plan_list.push_back(stored);
@@ -144,12 +164,12 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   float best_ms = 1e30f;
-  int best = 0;
+  int best = -1;
   for (size_t i = 0; i < p.cand.size(); ++i) {
     if (p.cand[i].state != HIPBLAS_STATUS_SUCCESS || (int64_t)p.cand[i].workspaceSize > workspace_bytes) continue;
     bool run_ok = true;
-    for (int rep = 0; rep < 6 && run_ok; ++rep) {
-      if (rep == 1) (void)hipEventRecord(e0, stream);
+    for (int rep = 0; rep < 10 && run_ok; ++rep) {   // 2 warm-up + 8 timed launches per candidate
+      if (rep == 2) (void)hipEventRecord(e0, stream);
       run_ok = hipblasLtMatmul(g_handle, p.desc, &alpha, B, p.la, A, p.lb, &beta0, C, p.lc, C, p.lc, &p.cand[i].algo,
                                workspace, workspace_bytes, stream) == HIPBLAS_STATUS_SUCCESS;
     }
@@ -163,8 +183,15 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (scratch) (void)hipFree(scratch);
-  p.algo = p.cand[best].algo;
   p.tuned = true;
+  if (best < 0) {                 // no candidate is usable (invalid state / workspace too small / launch failure)
+    p.ok = false;
+    p.choice = -1;
+    p.cand.clear();
+    return;
+  }
+  p.algo = p.cand[best].algo;
+  p.choice = best;
   p.cand.clear();
   p.cand.shrink_to_fit();
 }
@@ -182,7 +209,13 @@ int run_plan(Plan& p, const void* A, const void* B, void* C, const void* bias, f
     bb_set_error("gemm: cannot set the bias pointer");
     return BB_ELAUNCH;
   }
-  if (!p.tuned) tune_plan(p, A, B, C, workspace, workspace_bytes, stream);
+  if (!p.tuned) {
+    tune_plan(p, A, B, C, workspace, workspace_bytes, stream);
+    if (!p.ok) {
+      bb_set_error("gemm: none of the library's candidates for plan %d can run", p.id);
+      return BB_EUNSUPPORTED;
+    }
+  }
   const float beta0 = p.accumulate ? 1.f : 0.f;
   const hipblasStatus_t st = hipblasLtMatmul(g_handle, p.desc, &alpha, B, p.la, A, p.lb, &beta0, C, p.lc, C, p.lc,
                                              &p.algo, workspace, workspace_bytes, stream);
@@ -238,6 +271,56 @@ BEVBERT_API int bevbert_gemm(const void* A, const void* B, void* C, const void* 
   const int id = make_plan(q, workspace ? workspace_bytes : 0, autotune);
   if (id < 0) return id;
   return run_plan(*g_plan_list[id], A, B, C, bias, alpha, workspace, workspace_bytes, stream);
+}
+
+// Tuning table: one line "<problem key> <choice> <ncand>" per autotuned plan, after a header naming the library version.
+// export returns the number of bytes the text needs (incl. the terminating 0) and fills buf when cap is large enough;
+// import replaces the table used by plans created afterwards (a table from another hipBLASLt version is ignored: -3).
+static int lt_version() {
+  int v = 0, ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return -1;   // hipblasLtCreate aborts without a device
+  if (g_handle == nullptr && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return -1;
+  if (hipblasLtGetVersion(g_handle, &v) != HIPBLAS_STATUS_SUCCESS) return -1;
+  return v;
+}
+
+BEVBERT_API int64_t bevbert_gemm_tuning_export(char* buf, int64_t cap) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  std::string text = "# bevbert gemm tuning v1 hipblaslt " + std::to_string(lt_version()) + "\n";
+  std::unordered_map<std::string, std::pair<int, int>> rows = g_tuning;   // keep imported rows of shapes not seen in this run
+  for (const auto& kv : g_plans)
+    if (kv.second.ok && kv.second.tuned && kv.second.ncand > 1) rows[kv.first] = {kv.second.choice, kv.second.ncand};
+  for (const auto& kv : rows)
+    text += kv.first + " " + std::to_string(kv.second.first) + " " + std::to_string(kv.second.second) + "\n";
+  if (buf != nullptr && cap > (int64_t)text.size()) memcpy(buf, text.c_str(), text.size() + 1);
+  return (int64_t)text.size() + 1;
+}
+
+BEVBERT_API int bevbert_gemm_tuning_import(const char* text) {
+  BB_REQUIRE(text != nullptr, "gemm_tuning_import: NULL text");
+  std::lock_guard<std::mutex> lock(g_mu);
+  BB_REQUIRE(lt_version() >= 0, "gemm_tuning_import: no GPU / hipBLASLt handle");
+  const std::string want = "# bevbert gemm tuning v1 hipblaslt " + std::to_string(lt_version());
+  std::string all(text);
+  size_t pos = all.find('\n');
+  if (pos == std::string::npos || all.compare(0, pos, want) != 0) {
+    bb_set_error("gemm_tuning_import: table is not for this hipBLASLt (%s)", want.c_str());
+    return BB_EUNSUPPORTED;
+  }
+  g_tuning.clear();
+  int n = 0;
+  while (pos != std::string::npos && pos + 1 < all.size()) {
+    const size_t end = all.find('\n', pos + 1);
+    const std::string line = all.substr(pos + 1, end == std::string::npos ? std::string::npos : end - pos - 1);
+    pos = end;
+    char key[256];
+    int choice = -1, ncand = 0;
+    if (sscanf(line.c_str(), "%255s %d %d", key, &choice, &ncand) == 3 && key[0] != '#') {
+      g_tuning[key] = {choice, ncand};
+      ++n;
+    }
+  }
+  return n;
 }
 
 BEVBERT_API int bevbert_gemm_plan_count(void) {

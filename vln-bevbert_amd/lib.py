@@ -100,6 +100,10 @@ def load():
     lib.bevbert_colsum_workspace_floats.restype = _I64
     lib.bevbert_colsum_workspace_floats.argtypes = [_I]
     lib.bevbert_gemm_plan_count.restype = _I
+    lib.bevbert_gemm_tuning_export.restype = _I64
+    lib.bevbert_gemm_tuning_export.argtypes = [ctypes.c_char_p, _I64]
+    lib.bevbert_gemm_tuning_import.restype = _I
+    lib.bevbert_gemm_tuning_import.argtypes = [ctypes.c_char_p]
     lib.bevbert_colsum_partial_rows.restype = _I
     lib.bevbert_colsum_partial_rows.argtypes = [_I]
     lib.bevbert_gemm_plan.restype = _I

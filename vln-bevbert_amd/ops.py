@@ -233,11 +233,39 @@ def _gemm(kind, fn, m, n, k):
 # ~28 us of torch.mm / F.linear dispatch -- the training step is host-bound at batch 64 (bench.py reports both clocks).
 # BEVBERT_LT_GEMM=0 routes them through torch instead (same library underneath); A/B knob.
 _LT_ENABLED = _os.environ.get("BEVBERT_LT_GEMM", "1") == "1"
-_LT_AUTOTUNE = int(_os.environ.get("BEVBERT_LT_AUTOTUNE", "16"))
+_LT_AUTOTUNE = int(_os.environ.get("BEVBERT_LT_AUTOTUNE", "32"))
 _LT_UNSUPPORTED = set()
 
 
 _LT_PLANS = {}
+GEMM_TUNING_FILE = _os.environ.get("BEVBERT_GEMM_TUNING",
+                                   _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "gemm_tuning.txt"))
+_tuning_loaded = False
+
+
+def load_gemm_tuning_table(path=None):
+    """Import the shipped hipBLASLt choice table (bevbert_gemm_tuning_import); returns the number of rows (0 when the
+    file is missing or was made with another library version -- the plans then time their candidates on first use)."""
+    global _tuning_loaded
+    _tuning_loaded = True
+    path = path or GEMM_TUNING_FILE
+    if not _os.path.exists(path):
+        return 0
+    with open(path, "rb") as f:
+        n = lib.load().bevbert_gemm_tuning_import(f.read())
+    return max(n, 0)
+
+
+def save_gemm_tuning_table(path):
+    """Write the choices of every plan tuned so far (plus the imported rows) for later runs."""
+    l = lib.load()
+    need = l.bevbert_gemm_tuning_export(None, 0)
+    import ctypes
+    buf = ctypes.create_string_buffer(need)
+    l.bevbert_gemm_tuning_export(buf, need)
+    with open(path, "wb") as f:
+        f.write(buf.value)
+    return buf.value.count(b"\n") - 1
 
 
 def _lt_gemm(a, b, out, bias, M, N, K, opA, opB, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, accumulate=0):
@@ -246,6 +274,8 @@ def _lt_gemm(a, b, out, bias, M, N, K, opA, opB, lda, ldb, ldc, batch=1, sa=0, s
            accumulate)
     plan = _LT_PLANS.get(key)
     if plan is None:
+        if not _tuning_loaded:
+            load_gemm_tuning_table()
         plan = lib.load().bevbert_gemm_plan(M, N, K, opA, opB, lda, ldb, ldc, batch, sa, sb, sc, dtype_code(a),
                                             dtype_code(out), -1 if bias is None else dtype_code(bias), accumulate,
                                             _LT_WS_BYTES, _LT_AUTOTUNE)
