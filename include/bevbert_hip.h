@@ -46,13 +46,17 @@ const char* bevbert_arch(void);
  *
  * bevbert_bev_lift_bin: depths (B,V,hw,hw) stored /depth_scale, T_c2w (B,V,4,4), T_w2c (B,4,4), S_w2c (B,3),
  *   pix_scale (hw) = ((u + .5 - c)/f) fp32.  Outputs: cell (B,P) int32 (cell id = dim*z + x, -1 = dropped),
- *   order (B,P) int32 (point ids sorted by (cell, id)), cell_start (B, dim*dim+1) int32.  P = V*hw*hw <= 8192.
+ *   order (B,P) int32 (point ids sorted by (cell, id)), cell_start (B, dim*dim+1) int32.  P = V*hw*hw <= 24576.
  * bevbert_bev_bin_points: same outputs from ready-made ego-frame points (B,P,3) + drop mask (B,P) uint8.
  * bevbert_bev_splat_mean: out[b,cell,:] = mean of feat[b,p,:] over the cell's points (0 if empty);
  *   semantics: sem_ids (B,P) uint8 class ids  XOR  sem_dense (B,P,S) float64 one-hot (the reference's format);
  *   out_sem (B,K,S) uint8 {0,1}, out_sem_mask (B,K) uint8; pass out_sem = NULL to skip semantics.
- *   sample_rows (B) int32 or NULL: sample b's points are row sample_rows[b] of feat / sem_ids (which then hold N >= B
- *   rows: a device-resident store of per-viewpoint grid features, dataset.py:110-118, read in place -- no batch copy). */
+ *   sample_rows (B, rows_per_sample) int32 or NULL: feat / sem_ids are a device-resident store of per-viewpoint grid
+ *   features ((N, P/rows_per_sample, C) / (N, P/rows_per_sample); dataset.py:110-118) read in place -- no batch copy:
+ *   sample b's points p*P0 .. (p+1)*P0-1 are store row sample_rows[b][p].  rows_per_sample = 1 in pre-training; the
+ *   fine-tuning agent splats the current viewpoint together with its visited neighbours (GraphMap.gather_node_pc,
+ *   map_nav_src/models/graph_utils.py:129-144; agent.py:282-296), rows_per_sample = the batch maximum, short lists
+ *   padded with any valid row whose depths are 0 (those points are dropped by the binning). */
 int bevbert_bev_lift_bin(const float* depths, const float* T_c2w, const float* T_w2c, const float* S_w2c,
                          const float* pix_scale, int B, int V, int hw, float depth_scale, int dim, float res,
                          float y_clip, int* cell, int* order, int* cell_start, hipStream_t stream);
@@ -60,7 +64,8 @@ int bevbert_bev_bin_points(const float* points, const uint8_t* drop_mask, int B,
                            float y_clip, int* cell, int* order, int* cell_start, hipStream_t stream);
 int bevbert_bev_splat_mean(const void* feat, int feat_dtype, const int* order, const int* cell_start, void* out,
                            int out_dtype, int B, int P, int K, int C, const uint8_t* sem_ids, const double* sem_dense,
-                           int S, uint8_t* out_sem, uint8_t* out_sem_mask, const int* sample_rows, hipStream_t stream);
+                           int S, uint8_t* out_sem, uint8_t* out_sem_mask, const int* sample_rows, int rows_per_sample,
+                           hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * K2  fused multi-head attention (head_dim 64).

@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Fine-tune rollout timing (BASELINE.json configs[4]: R2R fine-tune, SAP head, cached trajectories, bs=32, 1 MI355X).
 
-One "episode batch" = language once, then T navigation steps; every step runs the panorama encoder on the current
-viewpoints, lifts + splats the 1-hop grid features into the BEV and runs the navigation mode (global map encoder, BEV
-encoder, SAP heads, logit fusion) -- map_nav_src/r2r/agent.py:194-337 without the simulator and the GraphMap bookkeeping
-(cached trajectories: every step's inputs come from one synthetic pre-training-shaped batch).
+One "episode batch" follows map_nav_src/r2r/agent.py:436-560 without the simulator: language once, then T steps of
+  panorama encoder on the current viewpoints -> node-embedding updates of the B topological maps -> per-step map inputs
+  (graph_map.GraphMapBatch: batched Floyd graphs, device-resident running means) -> lift + splat of the current viewpoint
+  and its visited neighbours straight out of the resident grid-feature store -> navigation mode (global-map encoder,
+  BEV encoder, SAP heads, logit fusion).
+The observation streams are synthetic walks over random viewpoint graphs (synthetic.make_nav_episodes): "cached
+trajectories", i.e. the next viewpoint does not depend on the predicted action.
   --mode infer : torch.no_grad(), eval (validation / test rollouts)
-  --mode train : teacher-forced imitation loss summed over the steps, one backward, clip, AdamW (agent.py:339-420)
-Prints one JSON line (ms per navigation step, episodes per second).  Not the round's bench.py metric."""
+  --mode train : teacher-forced imitation loss summed over the steps, one backward, clip, AdamW (agent.py:339-420,562-600)
+Prints one JSON line (ms per navigation step, episodes per second, share of the host-side map bookkeeping).
+Not the round's bench.py metric."""
 import argparse
 import json
 import os
@@ -21,6 +25,8 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vln_bevbert_amd import ops, synthetic  # noqa: E402
 from vln_bevbert_amd.config import BevBertConfig  # noqa: E402
+from vln_bevbert_amd.feature_store import GridFeatureStore  # noqa: E402
+from vln_bevbert_amd.graph_map import GraphMapBatch  # noqa: E402
 from vln_bevbert_amd.nav_model import VLNBert  # noqa: E402
 from vln_bevbert_amd.pretrain_cmt import bevpos_polar  # noqa: E402
 
@@ -28,11 +34,12 @@ from vln_bevbert_amd.pretrain_cmt import bevpos_polar  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--steps", type=int, default=5, help="navigation steps per episode")
-    ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=6, help="navigation steps per episode")
+    ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", default="infer", choices=["infer", "train"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--nodes", type=int, default=14, help="viewpoints per synthetic scan")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -41,44 +48,69 @@ def main():
     model = VLNBert(cfg)
     arena = model.vln_bert.finalize(dev, cdt)
     model.train(a.mode == "train")
-    B, T = a.batch, a.steps
-    pb = synthetic.make_batch(cfg, "sap", B, seed=5, n_steps=T, sems_as="ids")
-    d = synthetic.batch_to(pb, dev)
-    K = cfg.bev_dim * cfg.bev_dim
+    B, T, K = a.batch, a.steps, cfg.bev_dim * cfg.bev_dim
+    rng = np.random.default_rng(0)
+    g = torch.Generator().manual_seed(0)
+
+    # the "dataset": B scans of `nodes` viewpoints, grid features resident in HBM (fp16)
+    keys = [f"scan{i}_e{i}_v{n}" for i in range(B) for n in range(a.nodes)]
+    N = len(keys)
+    store = GridFeatureStore(keys, torch.randn(N, 12, 196, cfg.grid_feat_size, generator=g).half(),
+                             torch.rand(N, 12, 14, 14, generator=g) * 0.6,
+                             torch.randint(0, 40, (N, 12, 14, 14), generator=g).to(torch.uint8), dev)
+    obs_all, ended_all = synthetic.make_nav_episodes(B, T, seed=1, n_nodes=a.nodes)
+    # instructions and per-step panorama features (36 views: candidates first, agent.py:70-112)
+    txt_ids = torch.randint(1000, 2000, (B, 80), generator=g).to(dev)
+    txt_masks = torch.ones(B, 80, dtype=torch.bool, device=dev)
+    pano = []
+    for t in range(T):
+        nc = [len(ob["candidate"]) for ob in obs_all[t]]
+        nav_types = torch.zeros(B, 36, dtype=torch.long)
+        for i, n in enumerate(nc):
+            nav_types[i, :n] = 1
+        ang = torch.rand(B, 36, 2, generator=g) * 6.28
+        loc = torch.cat([ang[..., :1].sin(), ang[..., :1].cos(), ang[..., 1:].sin(), ang[..., 1:].cos(),
+                         torch.ones(B, 36, 3)], -1)
+        pano.append({"view_img_fts": torch.randn(B, 36, cfg.image_feat_size, generator=g).to(dev), "obj_img_fts": None,
+                     "loc_fts": loc.to(dev), "nav_types": nav_types.to(dev),
+                     "view_lens": torch.full((B,), 36, dtype=torch.long, device=dev), "obj_lens": None})
     pix, polar = ops.pixel_scale(cfg.grid_hw, dev), bevpos_polar(cfg.bev_dim, dev)
-    txt_masks = torch.arange(d["txt_ids"].shape[1], device=dev)[None] < d["txt_lens"][:, None]
-    starts = np.cumsum([0] + pb["traj_step_lens"][:-1])
-    G = int(pb["gmap_lens"].max())
-    gmasks = torch.arange(G, device=dev)[None] < d["gmap_lens"][:, None]
-    cand_vpids = [[None] + c[-1] for c in pb["traj_cand_vpids"]]
-    feat = d["rgbs"].reshape(B, -1, d["rgbs"].shape[-1])
-    bev_pos = torch.cat([d["bev_gpos_fts"].expand(-1, K, -1), polar[None].expand(B, -1, -1)], -1)
+    t_book = [0.0]
 
     def episode():
-        txt = model("language", {"txt_ids": d["txt_ids"], "txt_masks": txt_masks})
+        gm = GraphMapBatch([ob["viewpoint"] for ob in obs_all[0]], cfg.hidden_size, dev, dtype=cdt)
+        gm.update_graph(obs_all[0])
+        txt = model("language", {"txt_ids": txt_ids, "txt_masks": txt_masks})
         loss = 0.0
         for t in range(T):
-            rows = torch.from_numpy(starts + t).to(dev)
-            pano, pmask = model("panorama", {"view_img_fts": d["traj_view_img_fts"][rows], "obj_img_fts": None,
-                                             "loc_fts": d["traj_loc_fts"][rows], "nav_types": d["traj_nav_types"][rows],
-                                             "view_lens": d["traj_vp_view_lens"][rows], "obj_lens": None})
-            # GraphMap.update_node_embed / get_node_embed: the visited node's embedding is the mean of its views
-            node = (pano * pmask[..., None]).sum(1) / pmask.sum(1, keepdim=True)
-            gimg = node[:, None].expand(-1, G, -1).contiguous()
-            _, order, start = ops.bev_lift_bin(d["depths"], d["T_c2w"], d["T_w2c"], d["S_w2c"], pix, cfg.bev_dim,
+            obs, ended = obs_all[t], ended_all[t]
+            h0 = time.perf_counter()
+            if t > 0:
+                gm.update_graph(obs, ended_all[t - 1])
+            gm.set_step_ids(obs, t, ended)
+            t_book[0] += time.perf_counter() - h0
+            pe, pm = model("panorama", pano[t])
+            avg = (pe * pm[..., None]).sum(1) / pm.sum(1, keepdim=True)                       # agent.py:478-479
+            h0 = time.perf_counter()
+            gm.update_node_embeds(obs, [[c["viewpointId"] for c in ob["candidate"]] for ob in obs], avg, pe, ended)
+            gm.remember_views(obs, [f"{ob['scan']}_{ob['viewpoint']}" for ob in obs], store, ended)
+            nav = gm.nav_gmap_variable(obs)
+            bi = gm.bev_inputs(obs, store, pc_order=1, bev_dim=cfg.bev_dim, bev_res=cfg.bev_res)
+            t_book[0] += time.perf_counter() - h0
+            _, order, start = ops.bev_lift_bin(bi["depths"], bi["T_c2w"], bi["T_w2c"], bi["S_w2c"], pix, cfg.bev_dim,
                                                cfg.bev_res)
-            bev_fts, _, _ = ops.bev_splat_mean(feat, order, start, K, out_dtype=cdt)
-            out = model("navigation", {
-                "txt_embeds": txt, "txt_masks": txt_masks, "gmap_img_embeds": gimg,
-                "gmap_step_ids": d["gmap_step_ids"], "gmap_pos_fts": d["gmap_pos_fts"], "gmap_masks": gmasks,
-                "gmap_pair_dists": d["gmap_pair_dists"], "gmap_visited_masks": d["gmap_visited_masks"],
-                "gmap_visited_masks_cpu": d.get("gmap_visited_masks_cpu"),
-                "gmap_vpids": pb["gmap_vpids"], "bev_fts": bev_fts, "bev_pos_fts": bev_pos,
-                "bev_masks": torch.ones(B, K, dtype=torch.bool, device=dev), "bev_nav_masks": d["bev_nav_masks"],
-                "bev_cand_idxs": d["bev_cand_idxs"], "bev_cand_vpids": cand_vpids, "obj_embeds": None,
+            bev_fts, _, _ = ops.bev_splat_mean(store.rgbs, order, start, K, out_dtype=cdt, rows=bi["grid_rows"])
+            nav.update({
+                "txt_embeds": txt, "txt_masks": txt_masks, "bev_fts": bev_fts,
+                "bev_pos_fts": torch.cat([bi["bev_gpos_fts"].expand(-1, K, -1), polar[None].expand(B, -1, -1)], -1),
+                "bev_masks": torch.ones(B, K, dtype=torch.bool, device=dev), "bev_nav_masks": bi["bev_nav_masks"],
+                "bev_cand_idxs": bi["bev_cand_idxs"], "bev_cand_vpids": bi["bev_cand_vpids"], "obj_embeds": None,
                 "obj_masks": None})
-            if a.mode == "train":
-                loss = loss + F.cross_entropy(out["fused_logits"].float(), d["global_act_labels"], reduction="sum")
+            out = model("navigation", nav)
+            if a.mode == "train":       # teacher action: [stop] is always a valid target of the fused logits
+                live = torch.from_numpy(~ended).to(dev)
+                tgt = torch.zeros(B, dtype=torch.long, device=dev)
+                loss = loss + (F.cross_entropy(out["fused_logits"].float(), tgt, reduction="none") * live).sum()
         return loss
 
     def iteration(i):
@@ -94,14 +126,17 @@ def main():
     for i in range(a.warmup):
         iteration(i)
     torch.cuda.synchronize()
+    t_book[0] = 0.0
     t0 = time.perf_counter()
     for i in range(a.iters):
         iteration(a.warmup + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
-    print(json.dumps({"workload": f"R2R fine-tune rollout, {a.mode}, batch {B}, {T} navigation steps, {a.dtype}",
+    print(json.dumps({"workload": f"R2R fine-tune rollout, {a.mode}, batch {B}, {T} navigation steps, {a.dtype}, "
+                                  f"GraphMapBatch + resident grid-feature store ({store.nbytes() / 2 ** 30:.1f} GiB)",
                       "ms_per_episode_batch": round(dt * 1e3, 2), "ms_per_nav_step": round(dt * 1e3 / T, 2),
-                      "episodes_per_s": round(B / dt, 1), "nav_steps_per_s": round(B * T / dt, 1)}))
+                      "episodes_per_s": round(B / dt, 1), "nav_steps_per_s": round(B * T / dt, 1),
+                      "host_map_bookkeeping_ms_per_nav_step": round(t_book[0] / a.iters / T * 1e3, 2)}))
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@ Shims -- installed before the reference is imported:
     vln_bevbert_amd.weights (key-name seeded) and the MLM decoder is tied by hand.
 
 Usage:  python tests/golden/make_golden.py           (writes tests/golden/*.npz)
+        python tests/golden/make_golden.py --graph   (fine-tune GraphMap bookkeeping only)
         python tests/golden/make_golden.py --ce      (continuous-environment fork only: its modules are also called
                                                       ``model.*``, so it needs a process of its own)
 """
@@ -426,6 +427,66 @@ CE_GRAD_KEYS = {
 }
 
 
+def gen_graph():
+    """Fine-tune bookkeeping: the reference's GraphMap / FloydGraph (map_nav_src/models/graph_utils.py) driven through
+    agent.rollout's per-step updates (map_nav_src/r2r/agent.py:447-449,471-494,556-559) on synthetic observation
+    streams; the agent methods themselves (_nav_gmap_variable, _map_cand_to_bev) are restated in oracle/graph_ref.py."""
+    import json
+    print("fine-tune graph bookkeeping (GraphMap / FloydGraph)")
+    sys.path.insert(0, os.path.join(REF, "map_nav_src"))
+    from models import graph_utils
+    from models.bev_utils import transfrom3D
+    from oracle import graph_ref
+    B, T, H, seed = 3, 7, 16, 51
+    obs_all, ended_all = synthetic.make_nav_episodes(B, T, seed)
+    g = torch.Generator().manual_seed(seed)
+    gmaps = [graph_utils.GraphMap(ob["viewpoint"]) for ob in obs_all[0]]
+    for i, ob in enumerate(obs_all[0]):
+        gmaps[i].update_graph(ob)
+    steps = []
+    for t in range(T):
+        obs, ended = obs_all[t], ended_all[t]
+        if t > 0:                                             # agent.py:556-559: new observations extend the graphs
+            for i, ob in enumerate(obs):
+                if not ended_all[t - 1][i]:
+                    gmaps[i].update_graph(ob)
+        for i, gmap in enumerate(gmaps):
+            if not ended[i]:
+                gmap.node_step_ids[obs[i]["viewpoint"]] = t + 1
+        C = max(len(ob["candidate"]) for ob in obs)
+        avg = torch.randn(B, H, generator=g)
+        pano = torch.randn(B, C + 2, H, generator=g)
+        for i, gmap in enumerate(gmaps):                      # agent.py:485-494
+            if not ended[i]:
+                vp = obs[i]["viewpoint"]
+                gmap.update_node_embed(vp, avg[i].clone(), rewrite=True)
+                gmap.update_node_pc(vp, torch.tensor([[float(len(gmap.node_pc))]]) if vp not in gmap.node_pc
+                                    else gmap.node_pc[vp][0], torch.zeros(1, dtype=torch.bool), torch.zeros(1, 1))
+                for j, cc in enumerate(obs[i]["candidate"]):
+                    if not gmap.graph.visited(cc["viewpointId"]):
+                        gmap.update_node_embed(cc["viewpointId"], pano[i, j].clone())
+        nv = graph_ref.nav_gmap_variable(obs, gmaps)
+        rec = {"avg": avg.tolist(), "pano": pano.tolist(), "gmap_vpids": nv["gmap_vpids"],
+               "gmap_step_ids": nv["gmap_step_ids"], "gmap_visited_masks": nv["gmap_visited_masks"],
+               "no_vp_left": nv["no_vp_left"],
+               "gmap_pos_fts": [p.tolist() for p in nv["gmap_pos_fts"]],
+               "gmap_pair_dists": [p.tolist() for p in nv["gmap_pair_dists"]],
+               "gmap_img_embeds": [e.tolist() for e in nv["gmap_img_embeds"]],
+               "gather_order1": [], "cand_cells": [], "start_pos_fts": [], "paths": []}
+        for i, (ob, gmap) in enumerate(zip(obs, gmaps)):
+            pc, _, _ = gmap.gather_node_pc(ob["viewpoint"], 1)            # the stored "pc" is the node's visit index
+            names = list(gmap.node_pc.keys())
+            rec["gather_order1"].append([names[int(v)] for v in pc.reshape(-1).tolist()])
+            cells = graph_ref.map_cand_to_bev(ob, 21, 0.5, transfrom3D)
+            rec["cand_cells"].append((cells[:, 1] * 21 + cells[:, 0]).tolist())
+            rec["start_pos_fts"].append(gmap.get_pos_fts(ob["viewpoint"], [gmap.start_vp], ob["heading"],
+                                                         ob["elevation"]).tolist())
+            rec["paths"].append({vp: gmap.graph.path(ob["viewpoint"], vp) for vp in gmap.node_positions})
+        steps.append(rec)
+    save("graph_nav", seed=np.int64(seed), B=np.int64(B), T=np.int64(T), H=np.int64(H),
+         steps_json=np.array(json.dumps(steps)))
+
+
 build_ref_pretrain_cached = {}
 
 
@@ -438,6 +499,9 @@ def main():
     if "--ce" in sys.argv:
         gen_ce()
         return
+    if "--graph" in sys.argv:
+        gen_graph()
+        return
 
     tiny = BevBertConfig.tiny()
     ref = build_ref_pretrain(tiny)
@@ -448,6 +512,7 @@ def main():
     gen_tasks(ref, tiny, "tiny_b2_fixed", B=2, seed=8, ragged=False, with_grads=False)
     gen_nav(tiny)
     gen_adamw()
+    gen_graph()
 
     rvr = BevBertConfig.tiny(image_feat_size=768, obj_feat_size=768, obj_prob_size=50,
                              pretrain_tasks=("mlm", "mrc", "sap", "og"))

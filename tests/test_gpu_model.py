@@ -407,3 +407,55 @@ def test_batches_from_resident_grid_feature_store(env):
             want = R.pretrain_forward(sd, cfg, ob, task)
         assert torch.equal(via_store, as_tensors), task
         assert max_abs(via_store.numpy(), want.numpy()) < FP32_TOL, task
+
+
+def test_finetune_bev_from_store_rows_of_visited_neighbours(env):
+    """f3: the fine-tune BEV of a step = lift + splat over the current viewpoint AND its visited 1-hop neighbours
+    (GraphMap.gather_node_pc + agent.splat, map_nav_src/models/graph_utils.py:129-144, r2r/agent.py:143-192).  The
+    product reads the neighbours' features straight from the resident store (multi-row sample_rows); the oracle
+    concatenates materialised point clouds like the reference.  Cell ids and fp32 BEV features must agree exactly."""
+    from vln_bevbert_amd import ops
+    from vln_bevbert_amd.feature_store import GridFeatureStore
+    from vln_bevbert_amd.graph_map import GraphMapBatch
+    cfg = BevBertConfig()
+    B, T, n_nodes = 3, 6, 14
+    obs_all, ended_all = synthetic.make_nav_episodes(B, T, seed=77, n_nodes=n_nodes)
+    g = torch.Generator().manual_seed(77)
+    keys = [f"scan{i}_e{i}_v{n}" for i in range(B) for n in range(n_nodes)]
+    N = len(keys)
+    rgbs = torch.randn(N, 12, 14, 14, 64, generator=g).half()              # 64 channels keep the store small
+    depths = torch.rand(N, 12, 14, 14, generator=g) * 0.5
+    depths[torch.rand(depths.shape, generator=g) < 0.05] = 0.0
+    sems = torch.randint(0, 40, (N, 12, 14, 14), generator=g).to(torch.uint8)
+    store = GridFeatureStore(keys, rgbs, depths, sems, DEV)
+    gm = GraphMapBatch([ob["viewpoint"] for ob in obs_all[0]], 8, DEV)
+    gm.update_graph(obs_all[0])
+    pix = ops.pixel_scale(cfg.grid_hw, torch.device(DEV))
+    K = cfg.bev_dim ** 2
+    multi = 0
+    for t in range(T):
+        obs, ended = obs_all[t], ended_all[t]
+        if t > 0:
+            gm.update_graph(obs, ended_all[t - 1])
+        gm.remember_views(obs, [f"{ob['scan']}_{ob['viewpoint']}" for ob in obs], store, ended)
+        bi = gm.bev_inputs(obs, store, pc_order=1, bev_dim=cfg.bev_dim, bev_res=cfg.bev_res)
+        R = bi["grid_rows"].shape[1]
+        multi += int(R > 1)
+        cell, order, start = ops.bev_lift_bin(bi["depths"], bi["T_c2w"], bi["T_w2c"], bi["S_w2c"], pix, cfg.bev_dim,
+                                              cfg.bev_res)
+        bev, _, _ = ops.bev_splat_mean(store.rgbs, order, start, K, out_dtype=torch.float32, rows=bi["grid_rows"])
+        # oracle: materialise the concatenated inputs the way the reference stores and gathers them
+        rows = bi["grid_rows"].cpu().long()
+        feat = store.rgbs.cpu().float()[rows].reshape(B, -1, 64)
+        pc, nod = R_lift(bi, cfg)
+        want_cell = R.cell_index(pc, nod, cfg.bev_dim, cfg.bev_res)
+        assert torch.equal(cell.cpu().long(), want_cell), t
+        want, _, _ = R.project_bev(pc, nod, feat, None, cfg.bev_dim, cfg.bev_res)
+        assert torch.equal(bev.cpu(), want), t
+        # candidate cells feed bev_nav_masks; the centre cell is the [stop] token
+        assert bool(bi["bev_nav_masks"][:, (K - 1) // 2].all())
+    assert multi >= 2          # the walks did revisit neighbourhoods: several steps splat more than one panorama
+
+
+def R_lift(bi, cfg):
+    return R.lift_points(bi["depths"].cpu(), bi["T_c2w"].cpu(), bi["T_w2c"].cpu(), bi["S_w2c"].cpu(), cfg.grid_hw)

@@ -193,3 +193,55 @@ def test_grid_feature_store_rows_and_attach():
     assert set(b) == {"txt_ids", "grid_store", "grid_rows"} and b["grid_rows"].tolist() == [6]
     with pytest.raises(KeyError, match="not in the grid-feature store"):
         st.rows(["scan9_vp99"])
+
+
+def test_graph_map_batch_matches_reference_graphmap():
+    """f3: the batched, device-resident rollout bookkeeping (graph_map.GraphMapBatch) against the reference's
+    GraphMap / FloydGraph driven through the agent's per-step updates (golden: tests/golden/graph_nav.npz)."""
+    import json
+    from tests.helpers import load_golden
+    from vln_bevbert_amd.graph_map import GraphMapBatch
+    g = load_golden("graph_nav")
+    B, T, H, seed = int(g["B"]), int(g["T"]), int(g["H"]), int(g["seed"])
+    steps = json.loads(str(g["steps_json"]))
+    obs_all, ended_all = synthetic.make_nav_episodes(B, T, seed)
+    gm = GraphMapBatch([ob["viewpoint"] for ob in obs_all[0]], H, "cpu", capacity=4)     # capacity 4: exercises growth
+    gm.update_graph(obs_all[0])
+
+    class _Store:                       # the bookkeeping only needs key -> row
+        row = {f"scan{i}_e{i}_v{n}": 100 * i + n for i in range(B) for n in range(14)}
+    for t in range(T):
+        obs, ended, ref = obs_all[t], ended_all[t], steps[t]
+        if t > 0:
+            gm.update_graph(obs, ended_all[t - 1])
+        gm.set_step_ids(obs, t, ended)
+        avg = torch.tensor(ref["avg"]).requires_grad_(True)
+        pano = torch.tensor(ref["pano"]).requires_grad_(True)
+        gm.update_node_embeds(obs, [[c["viewpointId"] for c in ob["candidate"]] for ob in obs], avg, pano, ended)
+        gm.remember_views(obs, [f"{ob['scan']}_{ob['viewpoint']}" for ob in obs], _Store, ended)
+        nv = gm.nav_gmap_variable(obs)
+        assert nv["gmap_vpids"] == ref["gmap_vpids"] and nv["no_vp_left"] == ref["no_vp_left"]
+        G = nv["gmap_img_embeds"].shape[1]
+        for i in range(B):
+            n = len(ref["gmap_vpids"][i])
+            assert nv["gmap_masks"][i].tolist() == [True] * n + [False] * (G - n)
+            assert nv["gmap_step_ids"][i, :n].tolist() == ref["gmap_step_ids"][i]
+            assert nv["gmap_visited_masks"][i, :n].long().tolist() == ref["gmap_visited_masks"][i]
+            assert np.array_equal(nv["gmap_pos_fts"][i, :n].numpy(), np.asarray(ref["gmap_pos_fts"][i], dtype=np.float32))
+            assert np.array_equal(nv["gmap_pair_dists"][i, :n, :n].numpy(),
+                                  np.asarray(ref["gmap_pair_dists"][i], dtype=np.float32))
+            assert float(nv["gmap_pair_dists"][i, n:].abs().sum()) == 0 and float(nv["gmap_pos_fts"][i, n:].abs().sum()) == 0
+            want = torch.tensor(ref["gmap_img_embeds"][i])
+            assert torch.allclose(nv["gmap_img_embeds"][i, :n].detach(), want, rtol=0, atol=1e-6)
+            assert float(nv["gmap_img_embeds"][i, n:].detach().abs().sum()) == 0
+            ob = obs[i]
+            assert gm.gather_nodes(i, ob["viewpoint"], 1) == ref["gather_order1"][i]
+            assert gm.cand_cells(ob, 21, 0.5).tolist() == ref["cand_cells"][i]
+            got = gm.pos_fts(i, ob["viewpoint"], [gm.eps[i].start_vp], ob["heading"], ob["elevation"])
+            assert np.array_equal(got, np.asarray(ref["start_pos_fts"][i], dtype=np.float32))
+            for vp, path in ref["paths"][i].items():
+                assert gm.eps[i].graph.path(ob["viewpoint"], vp) == path
+        # the stored embeddings stay differentiable across steps (the reference keeps graph-attached tensors)
+        if t == T - 1:
+            nv["gmap_img_embeds"].sum().backward()
+            assert avg.grad is not None and float(avg.grad.abs().sum()) > 0

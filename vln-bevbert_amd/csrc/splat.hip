@@ -13,7 +13,7 @@
 #include "common.h"
 
 #define MAX_CELLS 1024
-#define MAX_POINTS 8192
+#define MAX_POINTS 24576   // 10 panoramas of 12 x 14 x 14 points (fine-tune: current viewpoint + visited neighbours)
 
 // ---------------------------------------------------------------------------------------------
 // Kernel A: one workgroup per sample: cell id per point, then a stable counting sort by cell.
@@ -145,16 +145,24 @@ __global__ __launch_bounds__(256) void bev_splat_mean_kernel(const TI* __restric
                                                              const double* __restrict__ sem_dense,  // (B,P,S) or null
                                                              int S, uint8_t* __restrict__ out_sem,  // (B,K,S)
                                                              uint8_t* __restrict__ out_sem_mask,    // (B,K)
-                                                             const int* __restrict__ sample_rows) { // (B) or null
+                                                             const int* __restrict__ sample_rows,   // (B,R) or null
+                                                             int R) {
   const int cellg = blockIdx.x;  // b*K + cell
   const int b = cellg / K, cell = cellg - b * K;
-  // row of the feature / semantic-id arrays that holds sample b's points: b itself, or -- zero-copy batches drawn
-  // from a device-resident feature store -- the store row of the sample's viewpoint
-  const size_t src = sample_rows != nullptr ? (size_t)sample_rows[b] : (size_t)b;
+  // Where sample b's points live in the feature / semantic-id arrays: row b itself, or -- zero-copy batches drawn from
+  // a device-resident feature store -- R store rows of P0 = P / R points each (pre-training: the sample's viewpoint;
+  // fine-tuning: the current viewpoint and its visited neighbours, in the order the reference concatenates them)
+  const int P0 = P / R;
+  const int* rows = sample_rows != nullptr ? sample_rows + (size_t)b * R : nullptr;
+  auto src_point = [&](int p) -> size_t {      // global point index of sample-local point p
+    if (rows == nullptr) return (size_t)b * P + p;
+    if (R == 1) return (size_t)rows[0] * P0 + p;
+    const int r = p / P0;
+    return (size_t)rows[r] * P0 + (p - r * P0);
+  };
   const int s0 = cell_start[(size_t)b * (K + 1) + cell];
   const int n = cell_start[(size_t)b * (K + 1) + cell + 1] - s0;
   const int* ord = order + (size_t)b * P + s0;
-  const TI* fb = feat + src * P * C;
   const float inv_denominator = (float)(n > 1 ? n : 1);
 
   for (int c4 = threadIdx.x; c4 * 4 < C; c4 += blockDim.x) {
@@ -162,17 +170,17 @@ __global__ __launch_bounds__(256) void bev_splat_mean_kernel(const TI* __restric
     int i = 0;
     for (; i + 4 <= n; i += 4) {  // 4 independent row loads in flight, added in point order
       const int p0 = ord[i], p1 = ord[i + 1], p2 = ord[i + 2], p3 = ord[i + 3];
-      const float4 v0 = ld4<TI>(fb + (size_t)p0 * C + c4 * 4);
-      const float4 v1 = ld4<TI>(fb + (size_t)p1 * C + c4 * 4);
-      const float4 v2 = ld4<TI>(fb + (size_t)p2 * C + c4 * 4);
-      const float4 v3 = ld4<TI>(fb + (size_t)p3 * C + c4 * 4);
+      const float4 v0 = ld4<TI>(feat + src_point(p0) * C + c4 * 4);
+      const float4 v1 = ld4<TI>(feat + src_point(p1) * C + c4 * 4);
+      const float4 v2 = ld4<TI>(feat + src_point(p2) * C + c4 * 4);
+      const float4 v3 = ld4<TI>(feat + src_point(p3) * C + c4 * 4);
       acc.x = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc.x, v0.x), v1.x), v2.x), v3.x);
       acc.y = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc.y, v0.y), v1.y), v2.y), v3.y);
       acc.z = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc.z, v0.z), v1.z), v2.z), v3.z);
       acc.w = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc.w, v0.w), v1.w), v2.w), v3.w);
     }
     for (; i < n; ++i) {
-      const float4 v = ld4<TI>(fb + (size_t)ord[i] * C + c4 * 4);
+      const float4 v = ld4<TI>(feat + src_point(ord[i]) * C + c4 * 4);
       acc.x = __fadd_rn(acc.x, v.x); acc.y = __fadd_rn(acc.y, v.y);
       acc.z = __fadd_rn(acc.z, v.z); acc.w = __fadd_rn(acc.w, v.w);
     }
@@ -186,8 +194,7 @@ __global__ __launch_bounds__(256) void bev_splat_mean_kernel(const TI* __restric
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
       uint8_t flag = 0;
       if (sem_ids != nullptr) {
-        const uint8_t* sb = sem_ids + src * P;
-        for (int i = 0; i < n; ++i) flag |= (uint8_t)(sb[ord[i]] == (uint8_t)c);
+        for (int i = 0; i < n; ++i) flag |= (uint8_t)(sem_ids[src_point(ord[i])] == (uint8_t)c);
       } else {
         // dense (one-hot, fp64 in the reference): mean > 0 -> 1 (bev_utils.py:417-422)
         const double* sb = sem_dense + (size_t)b * P * S;
@@ -241,11 +248,11 @@ BEVBERT_API int bevbert_bev_bin_points(const float* points, const uint8_t* drop_
 template <typename TI, typename TO>
 static int launch_splat(const void* feat, const int* order, const int* cell_start, void* out, int B, int P, int K,
                         int C, const uint8_t* sem_ids, const double* sem_dense, int S, uint8_t* out_sem,
-                        uint8_t* out_sem_mask, const int* sample_rows, hipStream_t stream) {
+                        uint8_t* out_sem_mask, const int* sample_rows, int R, hipStream_t stream) {
   const int threads = (C / 4 >= 192) ? 192 : ((C / 4 + 63) / 64) * 64;
   hipLaunchKernelGGL((bev_splat_mean_kernel<TI, TO>), dim3(B * K), dim3(threads < 64 ? 64 : threads), 0, stream,
                      (const TI*)feat, order, cell_start, (TO*)out, P, K, C, sem_ids, sem_dense, S, out_sem,
-                     out_sem_mask, sample_rows);
+                     out_sem_mask, sample_rows, R);
   BB_CHECK_LAUNCH("bev_splat_mean");
   return BB_OK;
 }
@@ -253,14 +260,17 @@ static int launch_splat(const void* feat, const int* order, const int* cell_star
 BEVBERT_API int bevbert_bev_splat_mean(const void* feat, int feat_dtype, const int* order, const int* cell_start,
                                        void* out, int out_dtype, int B, int P, int K, int C, const uint8_t* sem_ids,
                                        const double* sem_dense, int S, uint8_t* out_sem, uint8_t* out_sem_mask,
-                                       const int* sample_rows, hipStream_t stream) {
+                                       const int* sample_rows, int rows_per_sample, hipStream_t stream) {
   BB_REQUIRE(C % 4 == 0, "bev_splat_mean: C=%d must be a multiple of 4", C);
+  const int R = rows_per_sample < 1 ? 1 : rows_per_sample;
+  BB_REQUIRE(R == 1 || sample_rows != nullptr, "bev_splat_mean: rows_per_sample=%d needs sample_rows", R);
+  BB_REQUIRE(P % R == 0, "bev_splat_mean: P=%d is not a multiple of rows_per_sample=%d", P, R);
   BB_REQUIRE(sample_rows == nullptr || sem_dense == nullptr,
              "bev_splat_mean: sample_rows indexes feat / sem_ids stores; dense semantics are per batch");
   BB_REQUIRE(out_sem == nullptr || (sem_ids != nullptr) != (sem_dense != nullptr),
              "bev_splat_mean: exactly one of sem_ids / sem_dense when semantics are requested");
 #define GO(TI, TO) \
-  return launch_splat<TI, TO>(feat, order, cell_start, out, B, P, K, C, sem_ids, sem_dense, S, out_sem, out_sem_mask, sample_rows, stream)
+  return launch_splat<TI, TO>(feat, order, cell_start, out, B, P, K, C, sem_ids, sem_dense, S, out_sem, out_sem_mask, sample_rows, R, stream)
   if (feat_dtype == BB_F32 && out_dtype == BB_F32) GO(float, float);
   if (feat_dtype == BB_F32 && out_dtype == BB_BF16) GO(float, bf16_raw);
   if (feat_dtype == BB_BF16 && out_dtype == BB_F32) GO(bf16_raw, float);

@@ -58,7 +58,7 @@ _P, _I, _I64, _U64, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c
 _PROTOS = {
     "bevbert_bev_lift_bin": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _F, _P, _P, _P, _P],
     "bevbert_bev_bin_points": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P],
-    "bevbert_bev_splat_mean": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P],
+    "bevbert_bev_splat_mean": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P],
     "bevbert_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _F, _U64, _U64, _P],
     "bevbert_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _F,
                          _U64, _U64, _P],

@@ -982,9 +982,12 @@ def bev_bin_points(points, drop_mask, dim, res, y_clip=0.5):
 @torch.no_grad()
 def bev_splat_mean(feat, order, cell_start, K, out_dtype=None, sems=None, n_classes=40, rows=None):
     """feat (B,P,C) f32/bf16/f16 -> (B,K,C); sems: (B,P) uint8 ids or (B,P,S) float64 one-hot or None.
-    rows (B) int32: feat / sems are (N,P,...) stores and sample b reads row rows[b] (feature_store.GridFeatureStore)."""
-    _, P, C = feat.shape
-    B = order.shape[0]
+    rows (B,) or (B,R) int32: feat / sems are (N,P0,...) stores (feature_store.GridFeatureStore) and sample b's points
+    are the R store rows rows[b] back to back (P = R * P0 = order.shape[1])."""
+    C = feat.shape[-1]
+    B, P = order.shape
+    R = 1 if rows is None or rows.dim() == 1 else rows.shape[1]
+    assert P == R * feat.shape[1] if rows is not None else feat.shape[:2] == (B, P)
     assert feat.is_contiguous() if rows is not None else True
     feat = feat.contiguous()
     out_dtype = out_dtype or (feat.dtype if feat.dtype != torch.float16 else torch.float32)
@@ -994,7 +997,7 @@ def bev_splat_mean(feat, order, cell_start, K, out_dtype=None, sems=None, n_clas
     if sems is not None:
         if sems.dim() == 2:
             sem_ids = sems.contiguous().to(torch.uint8)
-            assert sem_ids.shape[1] == P and (rows is not None or sem_ids.shape[0] == B)
+            assert sem_ids.shape[1] * R == P and (rows is not None or sem_ids.shape[0] == B)
         else:
             sem_dense = sems.contiguous().to(torch.float64)
             S = sems.shape[-1]
@@ -1002,7 +1005,7 @@ def bev_splat_mean(feat, order, cell_start, K, out_dtype=None, sems=None, n_clas
         out_mask = torch.empty(B, K, dtype=torch.uint8, device=feat.device)
     call("bevbert_bev_splat_mean", ptr(feat), dtype_code(feat), ptr(order), ptr(cell_start), ptr(out),
          dtype_code(out_dtype), B, P, K, C, ptr(sem_ids), ptr(sem_dense), S, ptr(out_sem), ptr(out_mask),
-         ptr(rows), stream())
+         ptr(rows.contiguous() if rows is not None else None), R, stream())
     return out, out_sem, out_mask
 
 

@@ -318,3 +318,42 @@ def gmap_csr(batch, device):
         lens = lens + batch["traj_vp_obj_lens"]
     return build_gmap_csr(list(batch["traj_step_lens"]), lens.tolist(), batch["traj_vpids"], batch["traj_cand_vpids"],
                           batch["gmap_vpids"], batch["traj_loc_fts"].shape[1], device)
+
+
+# ----------------------------------------------------------------------------- fine-tune rollouts (graph bookkeeping)
+def make_nav_episodes(B, T, seed, n_nodes=14, degree=3):
+    """Synthetic observation streams for the fine-tune bookkeeping (map_nav_src/r2r/env.py _get_obs fields the agent's
+    graph code reads): per episode a random connectivity graph of viewpoints with 3-D positions and a T-step walk that
+    revisits nodes now and then.  Returns obs[t][i] = {'scan', 'viewpoint', 'position', 'heading', 'elevation',
+    'candidate': [{'viewpointId', 'position', 'pointId'}]} and ended[t] (B,) flags (episodes stop at random steps)."""
+    rng = np.random.default_rng(seed)
+    graphs = []
+    for i in range(B):
+        pos = np.concatenate([rng.uniform(-8, 8, size=(n_nodes, 2)), rng.uniform(-1, 1, size=(n_nodes, 1))], 1)
+        d = np.linalg.norm(pos[:, None] - pos[None], axis=-1)
+        adj = [set() for _ in range(n_nodes)]
+        for a in range(n_nodes):
+            for b in np.argsort(d[a])[1:1 + degree]:
+                adj[a].add(int(b))
+                adj[int(b)].add(a)
+        graphs.append((pos, [sorted(s) for s in adj]))
+    cur = [int(rng.integers(0, n_nodes)) for _ in range(B)]
+    stop_at = [int(rng.integers(max(2, T - 2), T + 1)) for _ in range(B)]
+    obs, ended = [], []
+    for t in range(T):
+        step = []
+        for i in range(B):
+            pos, adj = graphs[i]
+            c = cur[i]
+            step.append({
+                "scan": f"scan{i}", "viewpoint": f"e{i}_v{c}", "position": tuple(float(x) for x in pos[c]),
+                "heading": float(rng.uniform(0, 2 * math.pi)), "elevation": 0.0,
+                "candidate": [{"viewpointId": f"e{i}_v{n}", "position": tuple(float(x) for x in pos[n]),
+                               "pointId": int(k)} for k, n in enumerate(adj[c])],
+            })
+        obs.append(step)
+        ended.append(np.asarray([t >= stop_at[i] for i in range(B)]))
+        for i in range(B):
+            if t + 1 < stop_at[i]:
+                cur[i] = int(rng.choice(graphs[i][1][cur[i]]))
+    return obs, ended
