@@ -439,8 +439,7 @@ def test_finetune_bev_from_store_rows_of_visited_neighbours(env):
             gm.update_graph(obs, ended_all[t - 1])
         gm.remember_views(obs, [f"{ob['scan']}_{ob['viewpoint']}" for ob in obs], store, ended)
         bi = gm.bev_inputs(obs, store, pc_order=1, bev_dim=cfg.bev_dim, bev_res=cfg.bev_res)
-        R = bi["grid_rows"].shape[1]
-        multi += int(R > 1)
+        multi += int(bi["grid_rows"].shape[1] > 1)
         cell, order, start = ops.bev_lift_bin(bi["depths"], bi["T_c2w"], bi["T_w2c"], bi["S_w2c"], pix, cfg.bev_dim,
                                               cfg.bev_res)
         bev, _, _ = ops.bev_splat_mean(store.rgbs, order, start, K, out_dtype=torch.float32, rows=bi["grid_rows"])

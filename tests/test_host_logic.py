@@ -237,6 +237,7 @@ def test_graph_map_batch_matches_reference_graphmap():
             ob = obs[i]
             assert gm.gather_nodes(i, ob["viewpoint"], 1) == ref["gather_order1"][i]
             assert gm.cand_cells(ob, 21, 0.5).tolist() == ref["cand_cells"][i]
+            assert gm.cand_cells_batch(obs, 21, 0.5)[i].tolist() == ref["cand_cells"][i]
             got = gm.pos_fts(i, ob["viewpoint"], [gm.eps[i].start_vp], ob["heading"], ob["elevation"])
             assert np.array_equal(got, np.asarray(ref["start_pos_fts"][i], dtype=np.float32))
             for vp, path in ref["paths"][i].items():

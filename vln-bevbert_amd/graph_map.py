@@ -31,13 +31,15 @@ _INF = 95959595     # graph_utils.py:46: the reference's "no path yet"
 
 
 def rel_pos_fts(a, b, base_heading=0.0, base_elevation=0.0):
-    """graph_utils.py:16-34 calculate_vp_rel_pos_fts for one origin ``a`` (3,) and many targets ``b`` (n, 3)."""
+    """graph_utils.py:16-34 calculate_vp_rel_pos_fts for many (origin, target) pairs at once: ``a`` (3,) or (n, 3)
+    origins, ``b`` (n, 3) targets, scalar or (n,) base angles."""
     b = np.asarray(b, dtype=np.float64).reshape(-1, 3)
-    d = b - np.asarray(a, dtype=np.float64)[None]
+    a = np.broadcast_to(np.asarray(a, dtype=np.float64).reshape(-1, 3), b.shape)
+    d = b - a
     xy = np.maximum(np.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2), 1e-8)
     xyz = np.maximum(np.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2 + d[:, 2] ** 2), 1e-8)
     heading = np.arcsin(d[:, 0] / xy)
-    heading = np.where(b[:, 1] < a[1], np.pi - heading, heading) - base_heading
+    heading = np.where(b[:, 1] < a[:, 1], np.pi - heading, heading) - base_heading
     elevation = np.arcsin(d[:, 2] / xyz) - base_elevation
     return heading, elevation, xyz
 
@@ -226,6 +228,37 @@ class GraphMapBatch:
         out[:, angle_feat_size:] = dists
         return out
 
+    def pos_fts_batch(self, obs, vpid_lists, angle_feat_size=4):
+        """pos_fts for every sample with ONE pass of numpy over all (sample, node) pairs: per-sample Python only walks
+        the graphs (distances are matrix rows, hop counts come from the next-hop table)."""
+        org, tgt, bh, be, gd, hops, where = [], [], [], [], [], [], []
+        for i, (ob, g) in enumerate(zip(obs, vpid_lists)):
+            ep = self.eps[i]
+            cur = ob["viewpoint"]
+            a = ep.node_positions[cur]
+            for k, vp in enumerate(g):
+                if vp is None:
+                    continue
+                org.append(a)
+                tgt.append(ep.node_positions[vp])
+                bh.append(ob["heading"])
+                be.append(ob["elevation"])
+                gd.append(ep.graph.distance(cur, vp))
+                hops.append(len(ep.graph.path(cur, vp)))
+                where.append((i, k))
+        stop = angle_fts(np.zeros(1, np.float32), np.zeros(1, np.float32), angle_feat_size)   # angles (0, 0) -> (0, 1, 0, 1)
+        outs = [np.zeros((len(g), angle_feat_size + 3), dtype=np.float32) for g in vpid_lists]
+        for o in outs:
+            o[:, :angle_feat_size] = stop
+        if where:
+            h, e, d = rel_pos_fts(np.asarray(org), np.asarray(tgt), np.asarray(bh), np.asarray(be))
+            ang = angle_fts(h.astype(np.float32), e.astype(np.float32), angle_feat_size)
+            dist = np.stack([d / MAX_DIST, np.asarray(gd) / MAX_DIST, np.asarray(hops) / MAX_STEP], 1).astype(np.float32)
+            for r, (i, k) in enumerate(where):
+                outs[i][k, :angle_feat_size] = ang[r]
+                outs[i][k, angle_feat_size:] = dist[r]
+        return outs
+
     def nav_gmap_variable(self, obs, enc_full_graph=True, act_visited_nodes=False, angle_feat_size=4):
         """agent.py:194-276 (_nav_gmap_variable): [stop] + map nodes per sample, padded to the batch maximum."""
         B = self.B
@@ -246,12 +279,12 @@ class GraphMapBatch:
             vpids.append(g)
             visited.append(m)
             step_ids.append([ep.node_step_ids.get(vp, 0) for vp in g])
-            pos.append(self.pos_fts(i, ob["viewpoint"], g, ob["heading"], ob["elevation"], angle_feat_size))
             pd = np.zeros((len(g), len(g)), dtype=np.float32)
             if len(g) > 1:
                 pd[1:, 1:] = (ep.graph.submatrix(g[1:]) / MAX_DIST).astype(np.float32)
             pair.append(pd)
             slots.append([-1] + [ep.node_slot[vp] for vp in g[1:]])
+        pos = self.pos_fts_batch(obs, vpids, angle_feat_size)
         lens = np.asarray([len(g) for g in vpids])
         G = int(lens.max())
         pad = lambda rows, fill, dt: np.stack([np.concatenate([np.asarray(r, dtype=dt),
@@ -284,15 +317,18 @@ class GraphMapBatch:
         """The reference stores every visited node's world-frame point cloud and 2352 x 768 features
         (GraphMap.update_node_pc, agent.py:488).  Here a node keeps its feature-store row and its 12 camera poses
         (agent.py:114-126: position (x, z, -y), heading -(k * 30 deg + ob heading), elevation pi)."""
-        for i, ob in enumerate(obs):
-            if ended is not None and ended[i]:
-                continue
-            x, y, z = ob["position"]
-            xyzhe = np.zeros((views, 5))                    # float64 like the agent's; the matrix is cast to fp32
-            xyzhe[:, 0], xyzhe[:, 1], xyzhe[:, 2] = x, z, -y
-            xyzhe[:, 3] = -(np.arange(views) * np.radians(30) + ob["heading"])
-            xyzhe[:, 4] = np.pi
-            self.eps[i].pc_nodes[ob["viewpoint"]] = (store.row[store_keys[i]], pose_matrix(xyzhe))
+        live = [i for i in range(len(obs)) if ended is None or not ended[i]]
+        if not live:
+            return
+        xyzhe = np.zeros((len(live), views, 5))             # float64 like the agent's; the matrices are cast to fp32
+        for r, i in enumerate(live):
+            x, y, z = obs[i]["position"]
+            xyzhe[r, :, 0], xyzhe[r, :, 1], xyzhe[r, :, 2] = x, z, -y
+            xyzhe[r, :, 3] = -(np.arange(views) * np.radians(30) + obs[i]["heading"])
+        xyzhe[:, :, 4] = np.pi
+        T = pose_matrix(xyzhe.reshape(-1, 5)).reshape(len(live), views, 4, 4)
+        for r, i in enumerate(live):
+            self.eps[i].pc_nodes[obs[i]["viewpoint"]] = (store.row[store_keys[i]], T[r])
 
     def gather_nodes(self, i, vp, order):
         """GraphMap.gather_node_pc's node selection (graph_utils.py:129-144): visited nodes within `order` hops of vp,
@@ -326,21 +362,42 @@ class GraphMapBatch:
         xyzhe = np.zeros((B, 5))
         xyzhe[:, 3] = [ob["heading"] for ob in obs]
         K = bev_dim * bev_dim
-        cand_vpids, cand_idxs, nav_masks, gpos = [], [], np.zeros((B, K), dtype=bool), []
-        for i, ob in enumerate(obs):
-            cand_vpids.append([None] + [c["viewpointId"] for c in ob["candidate"]])
-            idx = np.insert(self.cand_cells(ob, bev_dim, bev_res), 0, (K - 1) // 2)
-            nav_masks[i, idx] = True
-            cand_idxs.append(idx)
-            gpos.append(self.pos_fts(i, ob["viewpoint"], [self.eps[i].start_vp], ob["heading"], ob["elevation"])[0])
-        C = max(len(c) for c in cand_idxs)
-        cand_np = np.stack([np.concatenate([c, np.zeros(C - len(c), dtype=np.int64)]) for c in cand_idxs])
+        cand_vpids = [[None] + [c["viewpointId"] for c in ob["candidate"]] for ob in obs]
+        cells = self.cand_cells_batch(obs, bev_dim, bev_res)
+        C = 1 + max(len(c) for c in cells)
+        cand_np = np.zeros((B, C), dtype=np.int64)
+        nav_masks = np.zeros((B, K), dtype=bool)
+        for i, c in enumerate(cells):
+            cand_np[i, 0] = (K - 1) // 2                      # [stop]: the centre cell (agent.py:318)
+            cand_np[i, 1:1 + len(c)] = c
+            nav_masks[i, cand_np[i, :1 + len(c)]] = True
+        gpos = [g[0] for g in self.pos_fts_batch(obs, [[ep.start_vp] for ep in self.eps])]
         return {
             "grid_rows": rows_t, "depths": depths, "T_c2w": torch.from_numpy(T_c2w).to(dev),
             "T_w2c": torch.from_numpy(pose_matrix(xyzhe)).to(dev)[:, None], "S_w2c": torch.from_numpy(S).to(dev)[:, None],
             "bev_nav_masks": torch.from_numpy(nav_masks).to(dev), "bev_cand_idxs": torch.from_numpy(cand_np).to(dev),
             "bev_cand_vpids": cand_vpids, "bev_gpos_fts": torch.from_numpy(np.stack(gpos)).to(dev)[:, None],
         }
+
+    @staticmethod
+    def cand_cells_batch(obs, bev_dim, bev_res):
+        """cand_cells for every sample: the poses of the whole batch come from one pose_matrix call; the 4-term
+        products stay per-sample numpy matmuls (same BLAS path, hence the same roundings, as the reference's np.dot)."""
+        flip = np.array([1, 1, -1], dtype=np.float32)
+        xyzhe = np.zeros((len(obs), 5))
+        xyzhe[:, 3] = [-ob["heading"] for ob in obs]
+        T = pose_matrix(xyzhe)
+        out = []
+        for i, ob in enumerate(obs):
+            if not ob["candidate"]:
+                out.append(np.zeros(0, dtype=np.int64))
+                continue
+            S = np.asarray(ob["position"], dtype=np.float32)[[0, 2, 1]] * flip
+            p = np.asarray([c["position"] for c in ob["candidate"]], dtype=np.float32)[:, [0, 2, 1]] * flip - S
+            p1 = np.concatenate([p, np.ones((p.shape[0], 1), dtype=np.float32)], -1) @ T[i]    # see cand_cells
+            c = np.clip(np.round(p1[:, [0, 2]] / bev_res) + (bev_dim - 1) // 2, 0, bev_dim - 1).astype(np.int64)
+            out.append(c[:, 1] * bev_dim + c[:, 0])
+        return out
 
     @staticmethod
     def cand_cells(ob, bev_dim, bev_res):
