@@ -235,6 +235,11 @@ def _gemm(kind, fn, m, n, k):
 _LT_ENABLED = _os.environ.get("BEVBERT_LT_GEMM", "1") == "1"
 _LT_AUTOTUNE = int(_os.environ.get("BEVBERT_LT_AUTOTUNE", "32"))
 _LT_UNSUPPORTED = set()
+# Every new problem costs one timing pass (32 candidates x 10 launches + a sync) the first time it is seen.  The R2R step
+# has ~100 problems; real batches add data-dependent row counts (masked tokens, selected cells, trajectory lengths).
+# Past this many plans new problems stay on torch's own GEMM path (the library's single heuristic pick, no timing pass)
+# so that an unbounded variety of shapes cannot turn into an unbounded number of stalls.
+_LT_PLAN_BUDGET = int(_os.environ.get("BEVBERT_LT_PLAN_BUDGET", "2048"))
 
 
 _LT_PLANS = {}
@@ -274,6 +279,8 @@ def _lt_gemm(a, b, out, bias, M, N, K, opA, opB, lda, ldb, ldc, batch=1, sa=0, s
            accumulate)
     plan = _LT_PLANS.get(key)
     if plan is None:
+        if len(_LT_PLANS) >= _LT_PLAN_BUDGET:
+            return False
         if not _tuning_loaded:
             load_gemm_tuning_table()
         plan = lib.load().bevbert_gemm_plan(M, N, K, opA, opB, lda, ldb, ldc, batch, sa, sb, sc, dtype_code(a),
