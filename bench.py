@@ -109,6 +109,10 @@ def algorithmic_work(key, args, esize):
 
 def main():
     a = parse()
+    # watchdog: a stalled run (a collective that never completes, a wedged queue) dumps every thread's Python stack to
+    # stderr and exits instead of sitting on the GPU until somebody kills it; a normal run takes 1-3 minutes
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("BEVBERT_BENCH_WATCHDOG_S", "1500")), exit=True)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -128,7 +132,7 @@ def main():
     from vln_bevbert_amd import ops, synthetic
     from vln_bevbert_amd.config import BevBertConfig
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
-    from vln_bevbert_amd.train import PretrainTrainer, TaskSampler, load_gemm_tuning
+    from vln_bevbert_amd.train import PretrainTrainer, load_gemm_tuning
     n_tuned = load_gemm_tuning()
     n_rows = ops.load_gemm_tuning_table()
     log(f"hipBLASLt choice table: {n_rows} rows ({ops.GEMM_TUNING_FILE}); torch TunableOp table: {n_tuned} shapes")
@@ -290,6 +294,7 @@ def main():
         log(f"gemm tuning table: {ops.save_gemm_tuning_table(a.save_gemm_tuning)} rows -> {a.save_gemm_tuning}")
     if world > 1 or force:
         dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         print(json.dumps(out), flush=True)     # after the teardown: the JSON is the last line on stdout
 

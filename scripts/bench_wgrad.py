@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """A/B of weight-gradient GEMM formulations dW(N x Kin) = dy^T(N x M) @ x(M x Kin) for the step's shapes:
 plain mm vs split-K as a batched GEMM over S chunks of M (+ partial sum)."""
-import sys
 import torch
 
 def t(fn, n=30):

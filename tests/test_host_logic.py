@@ -3,7 +3,6 @@ import ctypes
 import os
 import re
 import subprocess
-import sys
 
 import numpy as np
 import pytest

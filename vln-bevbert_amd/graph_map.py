@@ -18,8 +18,6 @@ Here:
     the per-view poses -- exactly what ``ops.bev_lift_bin`` + ``ops.bev_splat_mean(rows=...)`` consume.
 Host logic is plain numpy / torch indexing (device agnostic); the kernels it feeds are the C-ABI ones.
 """
-import math
-
 import numpy as np
 import torch
 

@@ -1,7 +1,6 @@
 """Host-side mirror of the fine-tuning model: map_nav_src/models/vilmodel.py (GlocalTextPathNavCMT) and
 map_nav_src/models/model.py (VLNBert).  Three per-step modes over the same fused blocks as pre-training."""
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops

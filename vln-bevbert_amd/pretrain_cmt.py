@@ -7,7 +7,6 @@ the batch, exactly like the reference's defaultdict copy), same un-reduced loss 
 lift_splat is two kernel launches for the whole batch (ops.bev_lift_bin + ops.bev_splat_mean) instead of a
 B-iteration Python loop with three D2H syncs per sample (bev_utils.py:390-423).
 """
-from collections import defaultdict
 
 import numpy as np
 import torch

@@ -12,7 +12,6 @@ forward is a short chain of fused HIP kernels (ops.py) and library GEMMs:
 Host/device syncs of the reference forward (4608 item() + 192 nonzero at B=64) are gone: sequence
 masks come from host-known shapes, the gmap aggregation is one CSR gather, the SAP fusion is one index gather.
 """
-import math
 
 import numpy as np
 import torch
