@@ -245,3 +245,33 @@ def test_graph_map_batch_matches_reference_graphmap():
         if t == T - 1:
             nv["gmap_img_embeds"].sum().backward()
             assert avg.grad is not None and float(avg.grad.abs().sum()) > 0
+
+
+def test_feature_cache_round_trip(tmp_path):
+    """f2: sharded safetensors cache of the grid features -> GridFeatureStore, whole or per split; no h5py involved."""
+    from vln_bevbert_amd import feature_cache
+    from vln_bevbert_amd.feature_store import GridFeatureStore
+    rng = np.random.default_rng(4)
+    keys = [f"s{i % 3}_vp{i}" for i in range(11)]
+    rgbs = rng.standard_normal((11, 12, 196, 16)).astype(np.float16)
+    depths = rng.random((11, 12, 14, 14)).astype(np.float32)
+    sems = rng.integers(0, 40, (11, 12, 14, 14)).astype(np.uint8)
+    n = feature_cache.write_shards(((k, rgbs[i], depths[i], sems[i]) for i, k in enumerate(keys)), str(tmp_path), shard_size=4)
+    assert n == 11 and sorted(os.listdir(tmp_path)) == ["index.json"] + [f"shard_{i:05d}.safetensors" for i in range(3)]
+    idx = feature_cache.read_index(str(tmp_path))
+    assert idx["keys"] == keys and idx["shape"] == {"V": 12, "hw": 14, "C": 16} and idx["shard_of"][4] == 1
+    direct = GridFeatureStore(keys, rgbs, depths, sems, "cpu")
+    st = feature_cache.load_store(str(tmp_path), "cpu")
+    assert st.row == direct.row and torch.equal(st.rgbs, direct.rgbs) and torch.equal(st.depths, direct.depths)
+    assert torch.equal(st.sems, direct.sems)
+    part = feature_cache.load_store(str(tmp_path), "cpu", keys=[keys[9], keys[2], keys[5]])      # e.g. one data split
+    assert sorted(part.row) == sorted([keys[9], keys[2], keys[5]]) and len(part) == 3
+    for k in part.row:
+        assert torch.equal(part.rgbs[part.row[k]], direct.rgbs[direct.row[k]])
+        assert torch.equal(part.sems[part.row[k]], direct.sems[direct.row[k]])
+    with pytest.raises(KeyError, match="not in the cache"):
+        feature_cache.load_store(str(tmp_path), "cpu", keys=["nope_1"])
+    with pytest.raises(ValueError, match="duplicate key"):
+        feature_cache.write_shards([(keys[0], rgbs[0], depths[0], sems[0])] * 2, str(tmp_path / "dup"))
+    with pytest.raises(ImportError, match="needs h5py"):
+        feature_cache.convert_hdf5("a.hdf5", "b.hdf5", "c.hdf5", str(tmp_path / "x"))
