@@ -14,55 +14,48 @@ MAX_DIST = 30
 
 
 def nav_gmap_variable(obs, gmaps, enc_full_graph=True, act_visited_nodes=False):
-    out = {"gmap_vpids": [], "gmap_lens": [], "gmap_img_embeds": [], "gmap_step_ids": [], "gmap_pos_fts": [],
-           "gmap_pair_dists": [], "gmap_visited_masks": [], "no_vp_left": []}
-    for i, gmap in enumerate(gmaps):
-        visited_vpids, unvisited_vpids = [], []
-        for k in gmap.node_positions.keys():                      # agent.py:205-216
-            if act_visited_nodes:
-                (visited_vpids if k == obs[i]["viewpoint"] else unvisited_vpids).append(k)
-            else:
-                (visited_vpids if gmap.graph.visited(k) else unvisited_vpids).append(k)
-        out["no_vp_left"].append(len(unvisited_vpids) == 0)
-        if enc_full_graph:                                        # agent.py:218-223
-            gmap_vpids = [None] + visited_vpids + unvisited_vpids
-            gmap_visited_masks = [0] + [1] * len(visited_vpids) + [0] * len(unvisited_vpids)
+    """Per-sample map inputs of one navigation step, unpadded (the collation that follows in the reference only pads).
+    Node order: [stop], then the visited nodes, then the unvisited ones, each group in the map's insertion order."""
+    keys = ("gmap_vpids", "gmap_lens", "gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists",
+            "gmap_visited_masks", "no_vp_left")
+    out = {k: [] for k in keys}
+    for ob, gmap in zip(obs, gmaps):
+        here = ob["viewpoint"]
+        is_visited = (lambda vp: vp == here) if act_visited_nodes else gmap.graph.visited      # agent.py:205-216
+        seen = [vp for vp in gmap.node_positions if is_visited(vp)]
+        frontier = [vp for vp in gmap.node_positions if not is_visited(vp)]
+        if enc_full_graph:                                                                      # agent.py:218-223
+            nodes, flags = [None] + seen + frontier, [0] + [1] * len(seen) + [0] * len(frontier)
         else:
-            gmap_vpids = [None] + unvisited_vpids
-            gmap_visited_masks = [0] * len(gmap_vpids)
-        gmap_step_ids = [gmap.node_step_ids.get(vp, 0) for vp in gmap_vpids]
-        embeds = [gmap.get_node_embed(vp) for vp in gmap_vpids[1:]]
-        embeds = torch.stack([torch.zeros_like(embeds[0])] + embeds, 0)
-        pos_fts = gmap.get_pos_fts(obs[i]["viewpoint"], gmap_vpids, obs[i]["heading"], obs[i]["elevation"])
-        pair = np.zeros((len(gmap_vpids), len(gmap_vpids)), dtype=np.float32)
-        for a in range(1, len(gmap_vpids)):                       # agent.py:236-240
-            for b in range(a + 1, len(gmap_vpids)):
-                pair[a, b] = pair[b, a] = gmap.graph.distance(gmap_vpids[a], gmap_vpids[b]) / MAX_DIST
-        out["gmap_vpids"].append(gmap_vpids)
-        out["gmap_lens"].append(len(gmap_vpids))
-        out["gmap_img_embeds"].append(embeds)
-        out["gmap_step_ids"].append(gmap_step_ids)
-        out["gmap_pos_fts"].append(pos_fts)
+            nodes, flags = [None] + frontier, [0] * (1 + len(frontier))
+        n = len(nodes)
+        feats = [gmap.get_node_embed(vp) for vp in nodes[1:]]
+        pair = np.zeros((n, n), dtype=np.float32)                                               # agent.py:236-240
+        for a in range(1, n):
+            for b in range(a + 1, n):
+                pair[a, b] = pair[b, a] = gmap.graph.distance(nodes[a], nodes[b]) / MAX_DIST
+        out["gmap_vpids"].append(nodes)
+        out["gmap_lens"].append(n)
+        out["gmap_img_embeds"].append(torch.stack([torch.zeros_like(feats[0])] + feats, 0))     # [stop] = zeros
+        out["gmap_step_ids"].append([gmap.node_step_ids.get(vp, 0) for vp in nodes])
+        out["gmap_pos_fts"].append(gmap.get_pos_fts(here, nodes, ob["heading"], ob["elevation"]))
         out["gmap_pair_dists"].append(pair)
-        out["gmap_visited_masks"].append(gmap_visited_masks)
+        out["gmap_visited_masks"].append(flags)
+        out["no_vp_left"].append(len(frontier) == 0)
     return out
 
 
 def map_cand_to_bev(ob, bev_dim, bev_res, transfrom3D):
-    """agent.py:278-300 with the reference's transfrom3D passed in."""
-    S = np.array(ob["position"])[None, :].astype(np.float32)
-    S = S[:, [0, 2, 1]] * np.array([1, 1, -1], dtype=np.float32)
-    xyzhe = np.zeros([1, 5])
-    xyzhe[:, 3] = -ob["heading"]
-    T = transfrom3D(xyzhe)[0, :, :]
-    cand_pos = np.array([c["position"] for c in ob["candidate"]]).astype(np.float32)
-    cand_pos = cand_pos[:, [0, 2, 1]] * np.array([1, 1, -1], dtype=np.float32)
-    cand_pos = cand_pos - S
-    ones = np.ones([cand_pos.shape[0], 1]).astype(np.float32)
-    cand_pos1 = np.concatenate([cand_pos, ones], axis=-1)
-    cand_pos1 = np.dot(cand_pos1, T.transpose(0, 1))
-    cand_pos = cand_pos1[:, :3]
-    cand_pos = (cand_pos[:, [0, 2]] / bev_res).round() + (bev_dim - 1) // 2
-    cand_pos[cand_pos < 0] = 0
-    cand_pos[cand_pos >= bev_dim] = bev_dim - 1
-    return cand_pos.astype(np.int64)
+    """agent.py:278-300: BEV (x, z) cell of every candidate viewpoint of `ob`, clamped to the grid.  Simulator positions
+    (x, y, z) become (x, z, -y); they are taken relative to the agent and multiplied by the pose matrix of heading
+    -ob.heading -- by the matrix ITSELF: the reference calls ``T.transpose(0, 1)`` on a 2-D numpy array, which numpy
+    defines as the identity permutation."""
+    to_cam = lambda p: np.asarray(p, dtype=np.float32).reshape(-1, 3)[:, [0, 2, 1]] * np.float32([1, 1, -1])
+    pose = np.zeros([1, 5])
+    pose[0, 3] = -ob["heading"]
+    T = transfrom3D(pose)[0]
+    rel = to_cam([c["position"] for c in ob["candidate"]]) - to_cam(ob["position"])
+    hom = np.concatenate([rel, np.ones([rel.shape[0], 1], dtype=np.float32)], axis=-1)
+    ego = np.dot(hom, T)
+    cell = (ego[:, [0, 2]] / bev_res).round() + (bev_dim - 1) // 2
+    return np.clip(cell, 0, bev_dim - 1).astype(np.int64)
