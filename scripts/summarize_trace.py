@@ -18,7 +18,9 @@ ev = []
 for f in files:
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
+            wg = max(1, int(r.get("Workgroup_Size_X", 1) or 1))
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"),
+                       int(r.get("Grid_Size_X", 0) or 0) // wg))
 ev.sort()
 ends = [e for e in ev if e[2].startswith("adamw_kernel")]
 if len(ends) < K + 1:
@@ -28,7 +30,7 @@ t0, t1 = ends[-K - 1][1], ends[-1][1]
 win = [e for e in ev if e[0] >= t0 and e[1] <= t1]
 wall = (t1 - t0) / 1e6
 busy, cur_s, cur_e = 0, None, None
-for s, e, _, _ in win:
+for s, e, *_ in win:
     if cur_e is None or s > cur_e:
         if cur_e is not None:
             busy += cur_e - cur_s
@@ -37,7 +39,7 @@ for s, e, _, _ in win:
         cur_e = max(cur_e, e)
 if cur_e is not None:
     busy += cur_e - cur_s
-tot = sum(e - s for s, e, _, _ in win)
+tot = sum(e - s for s, e, *_ in win)
 
 
 def cls(name):
@@ -57,11 +59,11 @@ print(f"last {K} steps: wall {wall:.2f} ms ({wall / K:.2f} ms/step), GPU busy {b
       f"({100 * busy / 1e6 / wall:.1f} % of wall), sum of kernel durations {tot / 1e6 / K:.2f} ms/step, "
       f"{len(win) / K:.0f} launches/step")
 by_q = {}
-for s, e, _, q in win:
+for s, e, _, q, _ in win:
     by_q[q] = by_q.get(q, 0) + (e - s)
 print("per HW queue (ms/step):", {q: round(t / 1e6 / K, 2) for q, t in sorted(by_q.items())})
 by_c, by_k = {}, {}
-for s, e, n, _ in win:
+for s, e, n, _, _ in win:
     by_c[cls(n)] = by_c.get(cls(n), 0) + (e - s)
     c = by_k.setdefault(n, [0, 0])
     c[0] += 1
@@ -72,3 +74,18 @@ print()
 print(f"{'class':7s} {'calls/step':>10s} {'ms/step':>9s} {'avg_us':>9s} {'%':>6s}  name")
 for n, (c, t) in sorted(by_k.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"{cls(n):7s} {c / K:10.1f} {t / 1e6 / K:9.3f} {t / 1e3 / c:9.2f} {100 * t / tot:6.2f}  {n[:110]}")
+
+# the attention kernels per problem size: one launch grid = one (B, heads, Lq | Lk).  With B = 64 samples and 12 heads
+# the forward / dQ kernels launch ceil(Lq / 128) * 12 * B workgroups and the dK/dV kernel ceil(Lk / 64) * 12 * B, e.g. the
+# 441 x 441 BEV self-attention = 3072 / 3072 / 5376 workgroups -- the rows to compare with bench.py's
+# roofline.avg_launch_us (bevbert_attn_bwd[Lq=441,Lk=441] = its dQ launch + its dK/dV launch)
+print()
+print("attention kernels by launch grid (workgroups):")
+by_g = {}
+for s, e, n, _, g in win:
+    if "attn_mfma" in n:
+        c = by_g.setdefault((n.split("(")[0], g), [0, 0])
+        c[0] += 1
+        c[1] += e - s
+for (n, g), (c, t) in sorted(by_g.items(), key=lambda kv: -kv[1][1]):
+    print(f"  {c / K:6.1f} calls/step {t / 1e3 / c:9.2f} us avg  grid {g:6d}  {n[:80]}")
