@@ -458,3 +458,56 @@ def test_finetune_bev_from_store_rows_of_visited_neighbours(env):
 
 def R_lift(bi, cfg):
     return R.lift_points(bi["depths"].cpu(), bi["T_c2w"].cpu(), bi["T_w2c"].cpu(), bi["S_w2c"].cpu(), cfg.grid_hw)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_phase_a_gradients_are_final_when_the_text_hook_fires(env, dtype):
+    """The overlapped all-reduce (train.GradReducer.phase_a) reduces the arena region [split, end) -- map encoders and
+    heads -- as soon as d loss / d text-embeddings is complete.  That is only correct if every kernel that writes that
+    region has been issued by then (a one-rank RCCL group cannot show a violation: its all-reduce is the identity).
+    Snapshot the region at the moment the hook fires and compare with the region after the whole backward."""
+    from vln_bevbert_amd import ops, weights
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=2, num_x_layers=2, vocab_size=400)
+    model = GlocalTextPathCMTPreTraining(cfg)
+    model.load_state_dict(weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
+    model.tie_weights()
+    arena = model.finalize(DEV, dtype)
+    model.train()
+    model.set_dropout(0.1)
+    split = PretrainTrainer(model, arena, overlap=False).reducer.split
+    assert 0 < split < arena.numel
+    snap = {}
+
+    def at_hook(g):
+        ops.WgradStream.flush_all()                  # what GradReducer._launch does before it issues the collective
+        torch.cuda.synchronize()
+        snap["region"] = arena.grads[split:].clone()
+        return g
+
+    def fwd_hook(mod, inputs, output):
+        if output.requires_grad and torch.is_grad_enabled():
+            output.register_hook(at_hook)
+
+    handle = model.bert.lang_encoder.register_forward_hook(fwd_hook)
+    try:
+        for step, task in enumerate(("sap", "mlm", "masksem")):
+            snap.clear()
+            ops.RT.new_step(500 + step)
+            arena.zero_grad()
+            b = synthetic.batch_to(synthetic.make_batch(cfg, task, 3, seed=90 + step, ragged=True), DEV)
+            model(b, task).mean().backward()
+            arena.sync()
+            torch.cuda.synchronize()
+            assert "region" in snap, task                # the hook fired: every task here reads the text encoder
+            final = arena.grads[split:]
+            late = (snap["region"] != final).nonzero()
+            if late.numel():
+                off = int(late[0]) + split
+                name = [n for n, (o, k) in arena.slices.items() if o <= off < o + k]
+                raise AssertionError(f"{task}: {late.shape[0]} gradient elements of [split, end) changed after the "
+                                     f"text hook, first in {name}")
+            assert float(final.abs().sum()) > 0
+    finally:
+        handle.remove()
