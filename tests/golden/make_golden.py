@@ -17,6 +17,7 @@ Shims -- installed before the reference is imported:
 
 Usage:  python tests/golden/make_golden.py           (writes tests/golden/*.npz)
         python tests/golden/make_golden.py --graph   (fine-tune GraphMap bookkeeping only)
+        python tests/golden/make_golden.py --rxr     (xlm-roberta vocabulary only)
         python tests/golden/make_golden.py --ce      (continuous-environment fork only: its modules are also called
                                                       ``model.*``, so it needs a process of its own)
 """
@@ -427,6 +428,29 @@ CE_GRAD_KEYS = {
 }
 
 
+def gen_rxr():
+    """BASELINE.json configs[3]: RxR pre-training -- the xlm-roberta vocabulary (250 002 tokens, 514 positions,
+    configs/rxr_model.json) and 160-token instructions; one layer of each kind keeps the fixture generation short."""
+    print("RxR vocabulary [tiny_rxr]")
+    cfg = BevBertConfig.rxr(num_l_layers=1, num_x_layers=1, num_pano_layers=1, pretrain_tasks=("mlm", "sap"))
+    ref = build_ref_pretrain(cfg)
+    gen_keys(ref, "tiny_rxr")
+    B, seed = 2, 61
+    arrs = {"seed": np.int64(seed), "B": np.int64(B), "txt_len": np.int64(160)}
+    for task in ("mlm", "sap"):
+        b = synthetic.make_batch(cfg, task, B, seed=seed, txt_len=160, ragged=True)
+        with torch.no_grad():
+            arrs[f"{task}_loss"] = npy(ref(dict(b), task, True))
+            outs = ref(dict(b), task, False)
+        if task == "mlm":
+            arrs["mlm_scores_sub"] = sub(outs, 4099)
+            arrs["mlm_scores_rowmax"] = npy(outs.max(1).values)
+            arrs["mlm_scores_argmax"] = npy(outs.argmax(1))
+        else:
+            arrs.update(sap_global=npy(outs[0]), sap_local=npy(outs[1]), sap_fused=npy(outs[2]))
+    save("tasks_tiny_rxr", **arrs)
+
+
 def gen_graph():
     """Fine-tune bookkeeping: the reference's GraphMap / FloydGraph (map_nav_src/models/graph_utils.py) driven through
     agent.rollout's per-step updates (map_nav_src/r2r/agent.py:447-449,471-494,556-559) on synthetic observation
@@ -502,6 +526,9 @@ def main():
     if "--graph" in sys.argv:
         gen_graph()
         return
+    if "--rxr" in sys.argv:
+        gen_rxr()
+        return
 
     tiny = BevBertConfig.tiny()
     ref = build_ref_pretrain(tiny)
@@ -513,6 +540,7 @@ def main():
     gen_nav(tiny)
     gen_adamw()
     gen_graph()
+    gen_rxr()
 
     rvr = BevBertConfig.tiny(image_feat_size=768, obj_feat_size=768, obj_prob_size=50,
                              pretrain_tasks=("mlm", "mrc", "sap", "og"))

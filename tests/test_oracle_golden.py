@@ -225,3 +225,24 @@ def test_adamw_and_schedule():
         assert R.warmup_linear_lr(int(s), 5e-5, 10000, 100000) == pytest.approx(float(lr), rel=1e-12)
     assert R.no_decay_key("bert.embeddings.LayerNorm.weight") and R.no_decay_key("a.dense.bias")
     assert not R.no_decay_key("bert.img_embeddings.img_layer_norm.weight")   # decayed: substring rule
+
+
+def test_rxr_vocabulary_tasks():
+    """BASELINE.json configs[3]: xlm-roberta vocabulary (250 002 tokens, 514 positions), 160-token instructions."""
+    cfg = BevBertConfig.rxr(num_l_layers=1, num_x_layers=1, num_pano_layers=1, pretrain_tasks=("mlm", "sap"))
+    g = load_golden("tasks_tiny_rxr")
+    sd = rule_state_dict("pretrain_state_dict_keys_tiny_rxr.txt")
+    assert sd["bert.embeddings.word_embeddings.weight"].shape == (250002, 768)
+    assert sd["bert.embeddings.position_embeddings.weight"].shape == (514, 768)
+    B, seed, L = int(g["B"]), int(g["seed"]), int(g["txt_len"])
+    with torch.no_grad():
+        b = synthetic.make_batch(cfg, "mlm", B, seed=seed, txt_len=L, ragged=True)
+        assert 80 < b["txt_ids"].shape[1] <= L and int(b["txt_ids"].max()) > 30522      # ragged: padded to the batch max
+        assert max_abs(R.pretrain_forward(sd, cfg, b, "mlm").numpy(), g["mlm_loss"]) < FP32_TOL
+        scores = R.pretrain_forward(sd, cfg, b, "mlm", compute_loss=False)
+        assert scores.shape[1] == 250002 and max_abs(sub(scores, 4099), g["mlm_scores_sub"]) < FP32_TOL
+        assert np.array_equal(scores.argmax(1).numpy(), g["mlm_scores_argmax"])
+        b = synthetic.make_batch(cfg, "sap", B, seed=seed, txt_len=L, ragged=True)
+        assert max_abs(R.pretrain_forward(sd, cfg, b, "sap").numpy(), g["sap_loss"]) < FP32_TOL
+        outs = R.pretrain_forward(sd, cfg, b, "sap", compute_loss=False)
+        assert max_abs(outs[2].numpy(), g["sap_fused"]) < FP32_TOL

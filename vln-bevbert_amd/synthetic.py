@@ -34,6 +34,12 @@ def pose_matrix(xyzhe: np.ndarray) -> np.ndarray:
     return T.astype(np.float32)
 
 
+def _vocab_hi(cfg):
+    """upper end of the synthetic token ids: BERT-sized vocabularies keep the historical 29 000 (the committed golden
+    vectors depend on it); larger ones (xlm-roberta, 250 002) use their whole range so that high ids are exercised"""
+    return min(cfg.vocab_size - 1, 29000) if cfg.vocab_size <= 30522 else cfg.vocab_size - 1
+
+
 def _mask_tokens(rng, ids, vocab_lo, vocab_hi, mask_id):
     """BERT 15 % masking, at least one label (pretrain_src/data/tasks.py:14-55)."""
     out, lab = list(ids), [-1] * len(ids)
@@ -202,7 +208,7 @@ def collate(samples, cfg, task, rng, sems_as="onehot64"):
     for s in samples:
         ids = s["txt_ids"]
         if task.startswith("mlm"):
-            hi = min(cfg.vocab_size - 1, 29000)
+            hi = _vocab_hi(cfg)
             ids, lab = _mask_tokens(rng, ids, min(1000, hi - 1), hi, 103 % cfg.vocab_size)
             labs.append(np.asarray(lab, dtype=np.int64))
         txt.append(np.asarray(ids, dtype=np.int64))
