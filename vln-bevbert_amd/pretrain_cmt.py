@@ -102,6 +102,11 @@ def _host_rows(batch, key):
     return t.tolist() if torch.is_tensor(t) else t
 
 
+import os as _os
+
+_MLM_ROW_PAD = int(_os.environ.get("BEVBERT_MLM_ROW_PAD", "0"))      # 0 = off (the reference's exact row count)
+
+
 class GlocalTextPathCMTPreTraining(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -273,8 +278,17 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             pos = torch.nonzero(host.reshape(-1) != -1).squeeze(1).to(labels.device, non_blocking=True)
         else:
             pos = torch.nonzero(labels.reshape(-1) != -1).squeeze(1)
-        masked = txt_embeds.reshape(-1, txt_embeds.shape[-1]).index_select(0, pos)
-        scores = self.mlm_head(masked).float()
+        n = pos.numel()
+        pad_to = _MLM_ROW_PAD
+        if pad_to > 1 and n % pad_to:
+            # opt-in (BEVBERT_MLM_ROW_PAD=128): round the data-dependent number of masked rows up so that the head's GEMM
+            # problems repeat across batches (every new problem costs a hipBLASLt timing pass); the extra rows re-read
+            # row 0 and are cut off again below, the rows that count are untouched
+            pos_in = torch.cat([pos, pos.new_zeros(pad_to - n % pad_to)])
+        else:
+            pos_in = pos
+        masked = txt_embeds.reshape(-1, txt_embeds.shape[-1]).index_select(0, pos_in)
+        scores = self.mlm_head(masked).float()[:n]
         if compute_loss:
             return F.cross_entropy(scores, labels.reshape(-1).index_select(0, pos), reduction="none")
         return scores
