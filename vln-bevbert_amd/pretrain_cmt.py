@@ -288,7 +288,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         else:
             pos_in = pos
         masked = txt_embeds.reshape(-1, txt_embeds.shape[-1]).index_select(0, pos_in)
-        scores = self.mlm_head(masked).float()[:n]
+        scores = self.mlm_head(masked).float()
+        if pos_in is not pos:
+            scores = scores[:n]
         if compute_loss:
             return F.cross_entropy(scores, labels.reshape(-1).index_select(0, pos), reduction="none")
         return scores
