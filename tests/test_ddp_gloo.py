@@ -51,7 +51,10 @@ def _worker(rank, world, port, q):
             p.main_grad.copy_(leaf[n].grad)
     local = arena.grads.clone()
     reducer.phase_a()                       # map encoders + heads first (overlaps with the text encoder's backward)
-    reducer.finish()
+    reducer.launch_region(split // 3, split // 2)       # an out-of-order middle region (opt-in per-layer text phases)
+    assert reducer._remaining() == [(0, split // 3), (split // 2, split)]
+    reducer.finish()                        # ... and whatever is left, exactly once
+    assert reducer._done == [] and reducer._works == []
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
     assert torch.allclose(arena.grads, sum(gathered), rtol=0, atol=1e-6)

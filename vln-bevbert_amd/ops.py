@@ -243,7 +243,7 @@ _LT_PLAN_BUDGET = int(_os.environ.get("BEVBERT_LT_PLAN_BUDGET", "2048"))
 
 
 _LT_PLANS = {}
-GEMM_TUNING_FILE = _os.environ.get("BEVBERT_GEMM_TUNING",
+GEMM_TUNING_FILE = _os.environ.get("BEVBERT_GEMM_TABLE",
                                    _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "gemm_tuning.txt"))
 _tuning_loaded = False
 

@@ -77,6 +77,25 @@ class GradReducer:
         self.stream = torch.cuda.Stream() if (self.cuda and self.active) else None
         self._works = []
         self._phase_a_done = False
+        self._done = []          # [lo, hi) regions already issued in this step
+
+    def launch_region(self, lo, hi):
+        """Reduce [lo, hi) now: every gradient in it has been enqueued (caller's guarantee).  Regions may be issued in
+        any order; finish() covers whatever is left."""
+        lo, hi = max(0, int(lo)), min(int(hi), self.flat.numel())
+        if self.active and hi > lo:
+            self._launch(lo, hi)
+            self._done.append((lo, hi))
+
+    def _remaining(self):
+        gaps, at = [], 0
+        for lo, hi in sorted(self._done):
+            if lo > at:
+                gaps.append((at, lo))
+            at = max(at, hi)
+        if at < self.flat.numel():
+            gaps.append((at, self.flat.numel()))
+        return gaps
 
     def _launch(self, lo, hi):
         if hi <= lo:
@@ -97,21 +116,20 @@ class GradReducer:
         """Call when every gradient in [split, end) has been enqueued (tensor hook on the text embeddings)."""
         if self.active and not self._phase_a_done:
             self._phase_a_done = True
-            self._launch(self.split, self.flat.numel())
+            self.launch_region(self.split, self.flat.numel())
 
     def finish(self):
         """Call after backward: reduces what phase A did not cover and joins the side stream."""
         if self.active:
-            if not self._phase_a_done:
-                self._launch(0, self.flat.numel())
-            else:
-                self._launch(0, self.split)
+            for lo, hi in self._remaining():
+                self._launch(lo, hi)
             for w in self._works:
                 w.wait()
             if self.stream is not None:
                 torch.cuda.current_stream().wait_stream(self.stream)
         self._works = []
         self._phase_a_done = False
+        self._done = []
 
 
 class PretrainTrainer:
@@ -131,6 +149,24 @@ class PretrainTrainer:
         self.overlap = overlap and self.reducer.active
         if self.overlap:
             model.bert.lang_encoder.register_forward_hook(self._hook_text)
+            # opt-in finer pipeline (BEVBERT_REDUCE_TEXT_LAYERS="2,4,6"; not validated on a multi-GPU node yet): when the
+            # gradient w.r.t. the INPUT of text layer k is complete, every kernel of the text layers >= k has been
+            # enqueued, so their arena region can go out while the earlier layers are still in backward
+            import os
+            layers = [int(x) for x in os.environ.get("BEVBERT_REDUCE_TEXT_LAYERS", "").split(",") if x.strip()]
+            n_layers = len(model.bert.lang_encoder.layer)
+            hi = max(o + k for n, (o, k) in arena.slices.items() if n.startswith("bert.lang_encoder."))
+            for k in sorted({x for x in layers if 0 < x < n_layers}, reverse=True):
+                lo = min(o for n, (o, _) in arena.slices.items() if n.startswith(f"bert.lang_encoder.layer.{k}."))
+                model.bert.lang_encoder.layer[k].register_forward_pre_hook(self._make_layer_hook(lo, hi))
+                hi = lo
+
+    def _make_layer_hook(self, lo, hi):
+        def pre_hook(module, inputs):
+            x = inputs[0]
+            if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled():
+                x.register_hook(lambda g: (self.reducer.launch_region(lo, hi), g)[1])
+        return pre_hook
 
     def _hook_text(self, module, inputs, output):
         if output.requires_grad and torch.is_grad_enabled():
