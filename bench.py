@@ -311,9 +311,11 @@ def cpu_baseline(cfg, a):
     params = list({id(v): v for v in sd.values()}.values())
     m = [torch.zeros_like(p) for p in params]
     v = [torch.zeros_like(p) for p in params]
-    B = 4
+    B = 8
     t_total, n_samples, budget_s = 0.0, 0, 30.0
-    for it, task in enumerate(("sap", "mlm", "sap", "mlm", "masksem")):
+    order = ("sap", "mlm", "sap", "mlm", "masksem", "mlm", "sap", "mlm", "sap")      # first one is the untimed warm-up
+    order = tuple(t if t in cfg.pretrain_tasks else "mlm" for t in order)
+    for it, task in enumerate(order):
         if t_total > budget_s:
             break
         b = synthetic.make_batch(cfg, task, B, seed=4000 + it, txt_len=a.txt_len)
@@ -330,8 +332,9 @@ def cpu_baseline(cfg, a):
             t_total += dt
             n_samples += B
     return {"value": round(n_samples / t_total, 3), "unit": "samples/s", "cores": n, "kind": "port",
-            "sample": f"{n_samples // B} steps (mlm, sap, mlm, masksem order) of batch {B}, same shapes, fp32, "
-                      f"dropout off, fwd+bwd+AdamW, torch CPU with {n} threads; 1 untimed warm-up step"}
+            "sample": f"{n_samples // B} steps ({', '.join(order[1:1 + n_samples // B])}) of batch {B}, same shapes, "
+                      f"fp32, dropout off, fwd+bwd+AdamW, {t_total:.1f} s of torch CPU work with {n} threads after "
+                      "1 untimed warm-up step"}
 
 
 if __name__ == "__main__":
