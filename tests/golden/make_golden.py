@@ -18,6 +18,8 @@ Shims -- installed before the reference is imported:
 Usage:  python tests/golden/make_golden.py           (writes tests/golden/*.npz)
         python tests/golden/make_golden.py --graph   (fine-tune GraphMap bookkeeping only)
         python tests/golden/make_golden.py --rxr     (xlm-roberta vocabulary only)
+        python tests/golden/make_golden.py --modules --autocast --configs   (per-module vectors / the reference's own
+                                                      autocast-bf16 noise / the model configuration key-values)
         python tests/golden/make_golden.py --ce      (continuous-environment fork only: its modules are also called
                                                       ``model.*``, so it needs a process of its own)
 """
@@ -261,6 +263,153 @@ GRAD_KEYS = {
     "sap_fuse_linear.net.3.weight",
     "local_sem_head.net.3.bias",
 }
+
+
+def gen_configs():
+    """Key/value content of the reference's model configuration files: what PretrainedConfig.from_json_file hands the
+    model constructors (pretrain_src/train_r2r.py:102-113).  Data, not source: the product's boundary test rebuilds
+    the attribute bag from it and checks that nothing the JSON lacks (BEV resolution, grid shape, semantic classes ...)
+    is needed from the caller."""
+    import json
+    out = {"_comment": "key/value content of the reference's configs/{r2r,rxr,rvr}_model.json, written by "
+                       "tests/golden/make_golden.py --configs"}
+    for tag in ("r2r", "rxr", "rvr"):
+        with open(os.path.join(REF, "configs", f"{tag}_model.json")) as f:
+            out[tag] = json.load(f)
+    with open(os.path.join(OUT, "model_configs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("  wrote tests/golden/model_configs.json")
+
+
+def gen_modules(ref, cfg):
+    """Per-module vectors: one BertLayer, one GraphLXRTXLayer in each of its three forwards
+    (with / without graph_sprels), the panorama encoder alone with ragged view counts, and ImageEmbeddings' embedding
+    sum.  Inputs are re-derivable: torch.randn from the stated generator seeds, in the order written here."""
+    print("per-module vectors")
+    sys.path.insert(0, os.path.join(REF, "pretrain_src"))
+    from model.ops import extend_neg_masks
+    g = torch.Generator().manual_seed(4242)
+    arrs = {"seed": np.int64(4242)}
+    with torch.no_grad():
+        # BertLayer (vilmodel.py:195-208): text layer 0, lens (11, 6)
+        x = torch.randn(2, 11, 768, generator=g)
+        m = torch.arange(11)[None] < torch.tensor([11, 6])[:, None]
+        arrs["bert_layer"] = npy(ref.bert.lang_encoder.layer[0](x, extend_neg_masks(m))[0])
+        # GraphLXRTXLayer (vilmodel.py:365-421): global-map encoder layer 0
+        layer = ref.bert.global_encoder.encoder.x_layers[0]
+        lang = torch.randn(2, 9, 768, generator=g)
+        visn = torch.randn(2, 7, 768, generator=g)
+        spr = torch.randn(2, 7, 7, generator=g)
+        lm = torch.arange(9)[None] < torch.tensor([9, 4])[:, None]
+        vm = torch.arange(7)[None] < torch.tensor([5, 7])[:, None]
+        el, ev = extend_neg_masks(lm), extend_neg_masks(vm)
+        arrs["x_visn_sprels"] = npy(layer(lang, el, visn, ev, graph_sprels=spr[:, None]))
+        arrs["x_visn"] = npy(layer(lang, el, visn, ev, graph_sprels=None))
+        arrs["x_lang2visn"] = npy(layer.forward_lang2visn(lang, el, visn, ev))
+        arrs["x_visn2visn"] = npy(layer.forward_visn2visn(visn, ev))
+        # panorama encoder alone (transformer.py:133-182, pre-norm; vilmodel.py:527-532), view counts (36, 20, 5)
+        pano = torch.randn(3, 36, 768, generator=g)
+        pm = torch.arange(36)[None] < torch.tensor([36, 20, 5])[:, None]
+        out = ref.bert.img_embeddings.pano_encoder(pano, src_key_padding_mask=pm.logical_not())
+        arrs["pano_encoder"] = npy(out)
+        arrs["pano_valid"] = npy(pm)
+        # ImageEmbeddings without the pano encoder: the embedding sum + LayerNorm (vilmodel.py:494-524)
+        ie = ref.bert.img_embeddings
+        vf = torch.randn(3, 36, cfg.image_feat_size, generator=g)
+        lf = torch.randn(3, 36, 7, generator=g)
+        nt = torch.randint(0, 3, (3, 36), generator=g)
+        te = ref.bert.embeddings.token_type_embeddings
+        e = ie.img_layer_norm(ie.img_linear(vf)) + ie.loc_layer_norm(ie.loc_linear(lf)) + ie.nav_type_embedding(nt) \
+            + te(torch.ones(1, 1).long())
+        arrs["img_embed_sum_ln"] = npy(ie.layer_norm(e))
+        # LocalBEVEncoder's input embedding (vilmodel.py:585-593)
+        le = ref.bert.local_encoder
+        bf = torch.randn(2, 441, 768, generator=g)
+        bp = torch.randn(2, 441, 10, generator=g)
+        bn = torch.rand(2, 441, generator=g) < 0.1
+        be = le.bev_fts_embeddings(bf) + le.bev_pos_embeddings(bp) + le.nav_type_embedding(bn.long())
+        arrs["bev_input_embedding_sub"] = sub(be, 5)
+    save("modules_tiny", **arrs)
+
+
+def gen_autocast(ref, cfg):
+    """How far the REFERENCE's own autocast forward sits from its fp32 forward (the yardstick for 'within 1e-2 bf16'):
+    torch.autocast('cpu', bfloat16) around the reference model, same batches as tasks_tiny_b3_ragged."""
+    print("reference autocast-bf16 vs fp32 (tiny, B=3 ragged)")
+    arrs = {}
+    for task in ("mlm", "sap", "masksem"):
+        b = synthetic.make_batch(cfg, task, 3, seed=7, ragged=True)
+        with torch.no_grad():
+            want = ref(dict(b), task, False)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                got = ref(dict(b), task, False)
+        want = want if torch.is_tensor(want) else want[2] if task == "sap" else want[0]
+        got = got if torch.is_tensor(got) else got[2] if task == "sap" else got[0]
+        w, gt = npy(want.float()).astype(np.float64), npy(got.float()).astype(np.float64)
+        if w.shape != gt.shape:
+            # the lift runs under autocast too (train_r2r.py:256-258 wraps the whole forward): bf16 point coordinates
+            # move points across cell borders, so even the SET of supervised cells differs from the fp32 run
+            arrs[f"{task}_rows_fp32"], arrs[f"{task}_rows_bf16"] = np.int64(w.shape[0]), np.int64(gt.shape[0])
+            print(f"   {task}: row count differs under autocast ({w.shape[0]} fp32 vs {gt.shape[0]} bf16) -- not comparable")
+            continue
+        fin = np.isfinite(w) & np.isfinite(gt)
+        scale = np.abs(w[fin]).max()
+        err = np.abs(w[fin] - gt[fin])
+        arrs[f"{task}_max_rel"] = np.float64(err.max() / scale)
+        arrs[f"{task}_mean_rel"] = np.float64(err.mean() / scale)
+        print(f"   {task}: max-abs / absmax = {err.max() / scale:.3e}   mean-abs / absmax = {err.mean() / scale:.3e}")
+    save("ref_autocast_noise", **arrs)
+
+
+
+CURVE = dict(n_steps=100, batch=2, lr=1e-4, warmup=10, total=200, wd=0.01, betas=(0.9, 0.98), clip=5.0,
+             ratio="mlm.5.sap.5.masksem.1", sampler_seed=1, batch_seed0=50)
+
+
+def gen_curve():
+    """north_star: "loss curves overlapping for 100 steps".  The REFERENCE trains here: its model
+    (pretrain_src/model), its AdamW (optim/adamw.py) behind build_optimizer's two parameter groups
+    (optim/misc.py:12-37), its schedule (optim/sched.py:24-30) and its loop body (train_r2r.py:256-313: loss.mean(),
+    clip_grad_norm_ 5.0, optimizer.step, optimizer.zero_grad) on 100 synthetic batches, dropout disabled (eval mode:
+    the model has no other train/eval difference).  zero_grad is called with set_to_none=False, the default of the
+    reference's pinned torch 1.9.1 (environment.yaml:245): a parameter that has had a gradient once keeps being
+    stepped with a zero gradient on steps whose task does not use it."""
+    print("100-step training curve from the reference loop [tiny, 1+1 layers]")
+    from vln_bevbert_amd.train import TaskSampler
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=600)
+    ref = build_ref_pretrain(cfg)
+    sys.path.insert(0, os.path.join(REF, "pretrain_src"))
+    from optim.misc import build_optimizer
+    from optim.sched import get_lr_sched
+    opts = types.SimpleNamespace(weight_decay=CURVE["wd"], optim="adamw", learning_rate=CURVE["lr"],
+                                 betas=CURVE["betas"], warmup_steps=CURVE["warmup"], num_train_steps=CURVE["total"])
+    for p in ref.parameters():
+        p.requires_grad_(True)
+    optimizer = build_optimizer(ref, opts)
+    optimizer.zero_grad()
+    optimizer.step()                                        # train_r2r.py:244-246 (no-op: no gradients yet)
+    sampler = TaskSampler(CURVE["ratio"], seed=CURVE["sampler_seed"])
+    names = ["mlm", "sap", "masksem"]
+    losses, norms, tasks = [], [], []
+    for i in range(CURVE["n_steps"]):
+        t = sampler.next()
+        b = synthetic.make_batch(cfg, t, CURVE["batch"], seed=CURVE["batch_seed0"] + i, ragged=True)
+        loss = ref(dict(b), t, True).mean()
+        loss.backward()
+        lr = get_lr_sched(i + 1, opts)
+        for g in optimizer.param_groups:
+            g["lr"] = lr
+        gn = torch.nn.utils.clip_grad_norm_(ref.parameters(), CURVE["clip"])
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=False)
+        losses.append(float(loss.detach()))
+        norms.append(float(gn))
+        tasks.append(names.index(t))
+        if i % 10 == 0:
+            print(f"   step {i:3d} {t:8s} loss {losses[-1]:.5f} |g| {norms[-1]:.4f}")
+    save("train_curve_tiny", losses=np.asarray(losses, dtype=np.float64), grad_norms=np.asarray(norms, dtype=np.float64),
+         tasks=np.asarray(tasks, dtype=np.int64), **{k: np.asarray(v) for k, v in CURVE.items() if k != "ratio"})
+
 
 
 def gen_objects(cfg, tag, tasks, seed):
@@ -529,6 +678,20 @@ def main():
     if "--rxr" in sys.argv:
         gen_rxr()
         return
+    if "--configs" in sys.argv:
+        gen_configs()
+        return
+    if "--curve" in sys.argv:
+        gen_curve()
+        return
+    if "--modules" in sys.argv or "--autocast" in sys.argv:
+        tiny = BevBertConfig.tiny()
+        ref = build_ref_pretrain(tiny)
+        if "--modules" in sys.argv:
+            gen_modules(ref, tiny)
+        if "--autocast" in sys.argv:
+            gen_autocast(ref, tiny)
+        return
 
     tiny = BevBertConfig.tiny()
     ref = build_ref_pretrain(tiny)
@@ -537,10 +700,14 @@ def main():
     gen_splat(ref, tiny)
     gen_tasks(ref, tiny, "tiny_b3_ragged", B=3, seed=7, ragged=True, with_grads=True)
     gen_tasks(ref, tiny, "tiny_b2_fixed", B=2, seed=8, ragged=False, with_grads=False)
+    gen_modules(ref, tiny)
+    gen_autocast(ref, tiny)
+    gen_configs()
     gen_nav(tiny)
     gen_adamw()
     gen_graph()
     gen_rxr()
+    gen_curve()
 
     rvr = BevBertConfig.tiny(image_feat_size=768, obj_feat_size=768, obj_prob_size=50,
                              pretrain_tasks=("mlm", "mrc", "sap", "og"))

@@ -45,3 +45,31 @@ def max_abs(a, b):
     assert (np.isfinite(a) == np.isfinite(b)).all(), "inf/nan pattern differs"
     assert (a[~fin] == b[~fin]).all() if (~fin).any() else True
     return float(np.abs(a[fin] - b[fin]).max()) if fin.any() else 0.0
+
+
+def oracle_train(cfg, sd0, tasks, batches, lr_fn, wd=0.01, max_norm=5.0):
+    """CPU oracle of the reference's hot loop with dropout disabled (train_r2r.py:247-313)."""
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    sd["mlm_head.predictions.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+    names = [k for k in sd if k != "mlm_head.predictions.decoder.weight"]
+    state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k]), [0]) for k in names}
+    from oracle import bevbert_ref as R
+    losses = []
+    for step, (task, b) in enumerate(zip(tasks, batches), 1):
+        loss = R.pretrain_forward(sd, cfg, b, task).mean()
+        grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
+        gd = {k: g for k, g in zip(names, grads)}
+        for k in names:                               # zero_grad() keeps zeros for params that ever had a grad
+            if gd[k] is None and state[k][2][0] > 0:
+                gd[k] = torch.zeros_like(sd[k])
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in gd.values() if g is not None)).float()
+        coef = min(1.0, max_norm / (float(total) + 1e-6))
+        with torch.no_grad():
+            for k in names:
+                if gd[k] is None:
+                    continue
+                m, v, n = state[k]
+                n[0] += 1
+                R.adamw_step(sd[k], gd[k] * coef, m, v, n[0], lr_fn(step), 0.0 if R.no_decay_key(k) else wd)
+        losses.append(float(loss.detach()))
+    return losses

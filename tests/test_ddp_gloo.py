@@ -91,3 +91,48 @@ def test_two_rank_gradient_exchange():
     assert max(r[1] for r in res) < 1e-5                 # averaged arena gradient == global-batch gradient
     assert len({r[2] for r in res}) == 1                 # same task on every rank, no broadcast needed
     assert max(r[3] for r in res) > 0                    # ranks really drew different batches
+
+
+def _worker_broadcast(rank, world, port, q):
+    """Ranks start from DIFFERENT weights (the reference seeds each rank with seed + rank, train_r2r.py:85-88); the
+    trainer's construction must leave every replica with rank 0's parameters (DDP's wrap-time broadcast)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=300)
+    torch.manual_seed(100 + rank)
+    model = GlocalTextPathCMTPreTraining(cfg)           # init_weights draws from the rank-specific generator
+    arena = model.finalize("cpu", torch.float32)
+    mine = arena.params.clone()
+    everyone = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    differed = float((everyone[0] - everyone[1]).abs().max())
+    arena.exp_avg = torch.full_like(arena.params, float(rank))        # a resumed run carries optimiser state as well
+    arena.exp_avg_sq = torch.full_like(arena.params, float(rank))
+    PretrainTrainer(model, arena, rank=rank, world_size=world)
+    same = torch.equal(arena.params, everyone[0]) and float(arena.exp_avg.abs().max()) == 0.0
+    # the nn.Parameter objects are views of the arena: the model itself now holds rank 0's weights
+    w = model.global_sap_head.net[0].weight
+    o, k = arena.slices["global_sap_head.net.0.weight"]
+    same = same and torch.equal(w.detach().reshape(-1), everyone[0][o:o + k])
+    q.put(("ok", differed, same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_trainer_broadcasts_rank0_state_to_all_replicas():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_broadcast, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[0] == "ok" and r[2] for r in res)
+    assert min(r[1] for r in res) > 1e-3                 # the replicas really started apart

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import bevbert_ref as R
-from tests.helpers import load_golden, max_abs, rule_state_dict, sub
+from tests.helpers import load_golden, max_abs, oracle_train as _oracle_train, rule_state_dict, sub
 from vln_bevbert_amd import synthetic
 from vln_bevbert_amd.config import BevBertConfig
 
@@ -14,15 +14,38 @@ DEV = "cuda"
 FP32_TOL = 1e-3          # north_star: "within 1e-3 fp32"
 
 
+BF16_MEAN_TOL = 1e-2     # north_star "1e-2 bf16": mean-abs error relative to the output's abs-max
+BF16_MAX_TOL = 6e-2      # and the worst element (the reference's own CPU-autocast forward: 3.4e-2 on MLM scores,
+#                          tests/golden/ref_autocast_noise.npz; achieved values are logged to gpurun_out/bf16_errors.jsonl)
+
+
+def _record(kind, what, **vals):
+    """Append the achieved error of a bf16 comparison to gpurun_out/bf16_errors.jsonl (the margin is evidence)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "bf16_errors.jsonl"), "a") as f:
+            f.write(json.dumps({"kind": kind, "what": str(what), **{k: float(v) for k, v in vals.items()}}) + "\n")
+    except OSError:
+        pass
+
+
 def bf16_close(got, want, what):
     """north_star "1e-2 bf16", read as SURVEY section 7 fixes it: mean-abs error relative to the output's abs-max
-    <= 1e-2 (the reference's own autocast-bf16 forward sits at ~1e-3 by this measure), and max-abs <= 6e-2 * absmax."""
+    <= 1e-2, and max-abs <= BF16_MAX_TOL * absmax; the achieved numbers go into the assertion message and the log."""
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
     fin = np.isfinite(want)
     assert (np.isfinite(got) == fin).all(), what
     scale = max(1e-6, float(np.abs(want[fin]).max()))
     err = np.abs(got[fin] - want[fin])
-    assert err.mean() / scale < 1e-2 and err.max() / scale < 6e-2, (what, err.mean() / scale, err.max() / scale)
+    _record("fwd", what, mean_rel=err.mean() / scale, max_rel=err.max() / scale)
+    assert err.mean() / scale < BF16_MEAN_TOL and err.max() / scale < BF16_MAX_TOL, \
+        (what, f"mean {err.mean() / scale:.3e} (tol {BF16_MEAN_TOL}) max {err.max() / scale:.3e} (tol {BF16_MAX_TOL})")
+
+
+BF16_GRAD_TOL = 0.3
 
 
 def bf16_grad_close(got, ref, what):
@@ -35,7 +58,8 @@ def bf16_grad_close(got, ref, what):
         assert float(np.abs(got).max()) < 5e-2, (what, got)
         return
     l2 = float(np.linalg.norm(got - ref) / max(1e-12, np.linalg.norm(ref)))
-    assert l2 < 0.3, (what, l2)
+    _record("grad", what, rel_l2=l2)
+    assert l2 < BF16_GRAD_TOL, (what, f"relative L2 {l2:.3e} (tol {BF16_GRAD_TOL})")
 
 
 @pytest.fixture(scope="module")
@@ -263,31 +287,193 @@ def test_bev_geometry_variants_against_oracle(env, dim, res):
         assert got.shape == want.shape and max_abs(got.numpy(), want.numpy()) < FP32_TOL, (task, dim)
 
 
-def _oracle_train(cfg, sd0, tasks, batches, lr_fn, wd=0.01, max_norm=5.0):
-    """CPU oracle of the reference's hot loop with dropout disabled (train_r2r.py:247-313)."""
-    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
-    sd["mlm_head.predictions.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
-    names = [k for k in sd if k != "mlm_head.predictions.decoder.weight"]
-    state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k]), [0]) for k in names}
-    losses = []
-    for step, (task, b) in enumerate(zip(tasks, batches), 1):
-        loss = R.pretrain_forward(sd, cfg, b, task).mean()
-        grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
-        gd = {k: g for k, g in zip(names, grads)}
-        for k in names:                               # zero_grad() keeps zeros for params that ever had a grad
-            if gd[k] is None and state[k][2][0] > 0:
-                gd[k] = torch.zeros_like(sd[k])
-        total = torch.sqrt(sum((g.double() ** 2).sum() for g in gd.values() if g is not None)).float()
-        coef = min(1.0, max_norm / (float(total) + 1e-6))
+# ----------------------------------------------------------------------------- per-module parity
+def _module_inputs():
+    """The inputs of tests/golden/modules_tiny.npz, re-derived from its generator seed (make_golden.gen_modules)."""
+    g = torch.Generator().manual_seed(4242)
+    d = {"x": torch.randn(2, 11, 768, generator=g)}
+    d["m"] = torch.arange(11)[None] < torch.tensor([11, 6])[:, None]
+    d["lang"] = torch.randn(2, 9, 768, generator=g)
+    d["visn"] = torch.randn(2, 7, 768, generator=g)
+    d["spr"] = torch.randn(2, 7, 7, generator=g)
+    d["lm"] = torch.arange(9)[None] < torch.tensor([9, 4])[:, None]
+    d["vm"] = torch.arange(7)[None] < torch.tensor([5, 7])[:, None]
+    d["pano"] = torch.randn(3, 36, 768, generator=g)
+    d["pm"] = torch.arange(36)[None] < torch.tensor([36, 20, 5])[:, None]
+    d["vf"] = torch.randn(3, 36, 512, generator=g)
+    d["lf"] = torch.randn(3, 36, 7, generator=g)
+    d["nt"] = torch.randint(0, 3, (3, 36), generator=g)
+    d["bf"] = torch.randn(2, 441, 768, generator=g)
+    d["bp"] = torch.randn(2, 441, 10, generator=g)
+    d["bn"] = torch.rand(2, 441, generator=g) < 0.1
+    return d
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_per_module_vectors(env, dtype):
+    """One BertLayer, one GraphLXRTXLayer in each of its three forwards (with / without graph_sprels), the panorama
+    encoder alone and the two input-embedding sums against vectors from the reference's own modules: a regression in
+    the end-to-end goldens is localised by this test."""
+    from vln_bevbert_amd.vilmodel import neg_key_mask
+    g = load_golden("modules_tiny")
+    model, _ = build(BevBertConfig.tiny(), "pretrain_state_dict_keys_tiny.txt", dtype)
+    d = {k: v.to(DEV) for k, v in _module_inputs().items()}
+    fp32 = dtype == torch.float32
+
+    def cmp(got, ref, what):
+        got = got.detach().float().cpu().numpy()
+        if fp32:
+            assert max_abs(got, ref) < FP32_TOL, (what, max_abs(got, ref))
+        else:
+            bf16_close(got, ref, what)
+
+    c = lambda t: t.to(dtype).contiguous()
+    with torch.no_grad():
+        cmp(model.bert.lang_encoder.layer[0](c(d["x"]), neg_key_mask(d["m"])), g["bert_layer"], "bert_layer")
+        layer = model.bert.global_encoder.encoder.x_layers[0]
+        lm, vm = neg_key_mask(d["lm"]), neg_key_mask(d["vm"])
+        cmp(layer(c(d["lang"]), lm, c(d["visn"]), vm, graph_sprels=d["spr"].contiguous()), g["x_visn_sprels"], "x_visn_sprels")
+        cmp(layer(c(d["lang"]), lm, c(d["visn"]), vm), g["x_visn"], "x_visn")
+        cmp(layer.forward_lang2visn(c(d["lang"]), lm, c(d["visn"]), vm), g["x_lang2visn"], "x_lang2visn")
+        cmp(layer.forward_visn2visn(c(d["visn"]), vm), g["x_visn2visn"], "x_visn2visn")
+        pano = model.bert.img_embeddings.pano_encoder(c(d["pano"]), d["pm"].logical_not())
+        valid = g["pano_valid"]
+        cmp(pano[d["pm"]], g["pano_encoder"][valid], "pano_encoder")
+        ie = model.bert.img_embeddings
+        enc, ie.pano_encoder = ie.pano_encoder, None            # the embedding sum alone
+        try:
+            e, _ = ie.embed(d["vf"], d["lf"], d["nt"], torch.full((3,), 36, device=DEV),
+                            model.bert.embeddings.token_type_embeddings)
+        finally:
+            ie.pano_encoder = enc
+        cmp(e, g["img_embed_sum_ln"], "img_embed_sum_ln")
+        be = model.bert.local_encoder.bev_input_embedding(d["bf"], d["bp"], d["bn"])
+        cmp(torch.from_numpy(sub(be.float().cpu(), 5).copy()), g["bev_input_embedding_sub"], "bev_input_embedding")
+
+
+# ----------------------------------------------------------------------------- the reference's own config object
+def test_forward_with_the_reference_config_object(env):
+    """the model built from an attribute bag holding ONLY the keys of configs/r2r_model.json (+ the two
+    attributes train_r2r.py:108-112 adds) runs every task and agrees with the model built from BevBertConfig()."""
+    import json
+    import os
+    import types
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "model_configs.json")) as f:
+        keys = json.load(f)["r2r"]
+    bag = types.SimpleNamespace(**keys, pretrain_tasks={"mlm", "sap", "masksem"}, sem_pred_token="cattn")
+    m = GlocalTextPathCMTPreTraining(bag)
+    m.load_state_dict(rule_state_dict("pretrain_state_dict_keys_r2r.txt"))
+    m.tie_weights()
+    m.finalize(DEV, torch.float32)
+    m.eval()
+    g = load_golden("tasks_r2r_b2")
+    cfg = BevBertConfig()
+    for task in ("mlm", "sap", "masksem"):
+        b = synthetic.batch_to(synthetic.make_batch(cfg, task, int(g["B"]), seed=int(g["seed"])), DEV)
         with torch.no_grad():
-            for k in names:
-                if gd[k] is None:
-                    continue
-                m, v, n = state[k]
-                n[0] += 1
-                R.adamw_step(sd[k], gd[k] * coef, m, v, n[0], lr_fn(step), 0.0 if R.no_decay_key(k) else wd)
-        losses.append(float(loss.detach()))
-    return losses
+            loss = m(b, task).float().cpu().numpy()
+        assert max_abs(loss, g[f"{task}_loss"]) < FP32_TOL, task
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[3]: RxR
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rxr_vocabulary_tasks_gpu(env, dtype):
+    """xlm-roberta vocabulary (250 002-row tied MLM decoder, 514 positions), 160-token instructions, ragged lengths:
+    the HIP model against the reference's vectors (configs/rxr_model.json, scripts/pt_rxr.bash)."""
+    cfg = BevBertConfig.rxr(num_l_layers=1, num_x_layers=1, num_pano_layers=1, pretrain_tasks=("mlm", "sap"))
+    g = load_golden("tasks_tiny_rxr")
+    model, arena = build(cfg, "pretrain_state_dict_keys_tiny_rxr.txt", dtype)
+    fp32 = dtype == torch.float32
+    B, seed, L = int(g["B"]), int(g["seed"]), int(g["txt_len"])
+
+    def cmp(got, ref, what):
+        got = np.asarray(got.detach().float().cpu()) if torch.is_tensor(got) else got
+        if fp32:
+            assert max_abs(got, ref) < FP32_TOL, (what, max_abs(got, ref))
+        else:
+            bf16_close(got, ref, what)
+
+    with torch.no_grad():
+        b = synthetic.batch_to(synthetic.make_batch(cfg, "mlm", B, seed=seed, txt_len=L, ragged=True), DEV)
+        assert 80 < b["txt_ids"].shape[1] <= L and int(b["txt_ids"].max()) > 30522
+        cmp(model(b, "mlm"), g["mlm_loss"], "rxr mlm_loss")
+        scores = model(b, "mlm", compute_loss=False)
+        assert scores.shape[1] == 250002
+        cmp(torch.from_numpy(sub(scores.float().cpu(), 4099).copy()), g["mlm_scores_sub"], "rxr mlm_scores")
+        cmp(scores.max(1).values, g["mlm_scores_rowmax"], "rxr mlm_rowmax")
+        if fp32:
+            assert np.array_equal(scores.argmax(1).cpu().numpy(), g["mlm_scores_argmax"])
+        b = synthetic.batch_to(synthetic.make_batch(cfg, "sap", B, seed=seed, txt_len=L, ragged=True), DEV)
+        cmp(model(b, "sap"), g["sap_loss"], "rxr sap_loss")
+        outs = model(b, "sap", compute_loss=False)
+        cmp(outs[0], g["sap_global"], "rxr sap_global"); cmp(outs[1], g["sap_local"], "rxr sap_local")
+        cmp(outs[2], g["sap_fused"], "rxr sap_fused")
+    # one training step through the 250 002-row tied decoder: finite, and the embedding table receives both gradients
+    model.train()
+    arena.zero_grad()
+    b = synthetic.batch_to(synthetic.make_batch(cfg, "mlm", B, seed=seed, txt_len=L, ragged=True), DEV)
+    model(b, "mlm").mean().backward()
+    arena.sync()
+    gw = model.bert.embeddings.word_embeddings.weight.main_grad
+    assert bool(torch.isfinite(gw).all()) and float(gw.abs().sum()) > 0
+    assert int((gw.abs().sum(1) > 0).sum()) > 1000          # the decoder side touches every vocabulary row
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[1] at full batch
+def test_full_r2r_batch64_properties(env):
+    """configs[1] at its real size (batch 64, full depth, bf16, dropout 0.1) through the whole model.  The oracle cannot
+    finish this size in seconds, so the checks are size-independent: finite losses of the right shape; parameters a task
+    does not use keep an exactly-zero gradient (find_unused_parameters semantics); a rerun with the same (seed, step)
+    reproduces losses bit for bit and gradients up to the fp32 atomics of the embedding / graph-bias gradients."""
+    from vln_bevbert_amd import ops
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    cfg = BevBertConfig()
+    torch.manual_seed(0)
+    model = GlocalTextPathCMTPreTraining(cfg)
+    arena = model.finalize(DEV, torch.bfloat16)
+    model.train()
+    model.set_dropout(0.1)
+    B = 64
+    atomic = ("bert.embeddings.word_embeddings.weight", "bert.global_encoder.sprel_linear.weight",
+              "bert.global_encoder.sprel_linear.bias")
+    for task in ("sap", "mlm", "masksem"):
+        b = synthetic.batch_to(synthetic.make_batch(cfg, task, B, seed=2000, sems_as="ids"), DEV)
+        runs = []
+        for rep in range(3):                    # rep 0 settles the hipBLASLt plans of this task's shapes
+            ops.RT.new_step(77)
+            arena.zero_grad()
+            loss = model(b, task)
+            loss.mean().backward()
+            arena.sync()
+            torch.cuda.synchronize()
+            runs.append((loss.detach().float().clone(), arena.grads.clone()))
+        l1, g1 = runs[1]
+        l2, g2 = runs[2]
+        assert bool(torch.isfinite(l1).all()) and bool(torch.isfinite(g1).all()), task
+        assert l1.shape[0] == (B if task == "sap" else l1.shape[0]) and l1.numel() > 0
+        assert torch.equal(l1, l2), task                                     # forward: bit-reproducible
+        exact = torch.ones(arena.numel, dtype=torch.bool, device=DEV)
+        for n in atomic:
+            o, k = arena.slices[n]
+            exact[o:o + k] = False
+        assert torch.equal(g1[exact], g2[exact]), task
+        rel = float((g1 - g2).norm() / g1.norm())
+        assert rel < 1e-6, (task, rel)
+        unused = {"sap": ("mlm_head.", "local_sem_head."), "mlm": ("global_sap_head.", "local_sap_head.", "local_sem_head.",
+                                                                    "sap_fuse_linear."),
+                  "masksem": ("mlm_head.predictions.transform", "global_sap_head.", "bert.global_encoder.")}[task]
+        n_checked = 0
+        for n, (o, k) in arena.slices.items():
+            if n.startswith(unused):
+                assert float(g1[o:o + k].abs().max()) == 0.0, (task, n)
+                n_checked += 1
+        assert n_checked >= 4
+        used = {"sap": "global_sap_head.net.0.weight", "mlm": "mlm_head.predictions.transform.dense.weight",
+                "masksem": "local_sem_head.net.0.weight"}[task]
+        o, k = arena.slices[used]
+        assert float(g1[o:o + k].abs().sum()) > 0
 
 
 def test_training_curve_matches_oracle_fp32(env):
@@ -316,6 +502,51 @@ def test_training_curve_matches_oracle_fp32(env):
     assert abs(got[0] - want[0]) < 1e-3 * max(1.0, abs(want[0]))
 
 
+def _ema(xs, beta=0.9):
+    out, m = [], None
+    for x in xs:
+        m = x if m is None else beta * m + (1 - beta) * x
+        out.append(m)
+    return np.asarray(out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_100_step_loss_curve_overlaps_the_reference(env, dtype):
+    """north_star: "loss curves overlapping for 100 steps".  The golden curve was produced by the REFERENCE's model,
+    AdamW, schedule and loop body (tests/golden/make_golden.py --curve, dropout disabled); the product trains the same
+    100 batches from the same weights.  fp32: every one of the first 10 losses within 1e-3, the EMA(0.9)-smoothed curve
+    within 1e-2 relative over all 100 steps; bf16: 2e-2 / 3e-2."""
+    from vln_bevbert_amd import weights
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from vln_bevbert_amd.train import PretrainTrainer, TaskSampler
+    g = load_golden("train_curve_tiny")
+    n, B = int(g["n_steps"]), int(g["batch"])
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=600)
+    model = GlocalTextPathCMTPreTraining(cfg)
+    model.load_state_dict(weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
+    model.tie_weights()
+    arena = model.finalize(DEV, dtype)
+    model.train()
+    model.set_dropout(0.0)
+    sampler = TaskSampler("mlm.5.sap.5.masksem.1", seed=int(g["sampler_seed"]))
+    tasks = [sampler.next() for _ in range(n)]
+    assert [("mlm", "sap", "masksem").index(t) for t in tasks] == g["tasks"].tolist()
+    trainer = PretrainTrainer(model, arena, learning_rate=float(g["lr"]), warmup_steps=int(g["warmup"]),
+                              num_train_steps=int(g["total"]), betas=tuple(float(x) for x in g["betas"]),
+                              weight_decay=float(g["wd"]), grad_norm=float(g["clip"]))
+    got = []
+    for i, t in enumerate(tasks):
+        b = synthetic.batch_to(synthetic.make_batch(cfg, t, B, seed=int(g["batch_seed0"]) + i, ragged=True), DEV)
+        got.append(trainer.step(t, b))
+    got = np.asarray([float(x) for x in got])
+    want = g["losses"]
+    first = float(np.max(np.abs(got[:10] - want[:10]) / np.maximum(1.0, np.abs(want[:10]))))
+    smooth = float(np.max(np.abs(_ema(got) - _ema(want)) / np.maximum(1.0, np.abs(_ema(want)))))
+    _record("curve", f"100-step {dtype}", first10=first, ema=smooth)
+    tol_first, tol_ema = (1e-3, 1e-2) if dtype == torch.float32 else (2e-2, 3e-2)
+    assert first < tol_first and smooth < tol_ema, (first, smooth, got[:10], want[:10])
+
+
 def test_training_step_bf16_full_size_runs_and_learns(env):
     """BASELINE configs[1] shapes at a reduced batch: bf16, dropout on; loss is finite and falls on a fixed batch."""
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
@@ -334,44 +565,6 @@ def test_training_step_bf16_full_size_runs_and_learns(env):
     for t in ("mlm", "masksem"):
         bb = synthetic.batch_to(synthetic.make_batch(cfg, t, 8, seed=10, sems_as="ids"), DEV)
         assert np.isfinite(float(trainer.step(t, bb)))
-
-
-def test_rccl_reducer_path_single_rank(env):
-    """The data-parallel exchange (side stream, text-embedding hook, in-place all-reduce of arena slices) on real RCCL
-    with a one-rank group: the collectives are identities, so the run must match one without them.  Every dropout
-    mask comes from the library's counter-based stream (seed, step), so two runs differ only by the summation order
-    of the fp32 atomics in the embedding / graph-bias gradients (measured: <= 1e-8 on 1-3 of 52 M parameters)."""
-    import os
-    import socket
-    import torch.distributed as dist
-    from vln_bevbert_amd import weights
-    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
-    from vln_bevbert_amd.train import PretrainTrainer
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
-        results = []
-        # the first pass only settles the hipBLASLt plans (the first launch of a problem times its candidates and leaves
-        # the product of whichever ran last): the two compared passes must use the final algorithms throughout
-        for force in (None, False, True):
-            model = GlocalTextPathCMTPreTraining(cfg)
-            model.load_state_dict(weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
-            model.tie_weights()
-            arena = model.finalize(DEV, torch.bfloat16)
-            model.train()
-            model.set_dropout(0.1)
-            tr = PretrainTrainer(model, arena, warmup_steps=2, num_train_steps=20, force_collectives=bool(force))
-            assert tr.reducer.active == bool(force) and tr.overlap == bool(force)
-            for i, task in enumerate(("sap", "mlm", "masksem", "sap")):
-                tr.step(task, synthetic.batch_to(synthetic.make_batch(cfg, task, 2, seed=80 + i, ragged=True), DEV))
-            torch.cuda.synchronize()
-            if force is not None:
-                results.append(arena.params.clone())
-        assert float((results[0] - results[1]).abs().max()) < 1e-6
-    finally:
-        dist.destroy_process_group()
 
 
 def test_batches_from_resident_grid_feature_store(env):
@@ -458,56 +651,3 @@ def test_finetune_bev_from_store_rows_of_visited_neighbours(env):
 
 def R_lift(bi, cfg):
     return R.lift_points(bi["depths"].cpu(), bi["T_c2w"].cpu(), bi["T_w2c"].cpu(), bi["S_w2c"].cpu(), cfg.grid_hw)
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_phase_a_gradients_are_final_when_the_text_hook_fires(env, dtype):
-    """The overlapped all-reduce (train.GradReducer.phase_a) reduces the arena region [split, end) -- map encoders and
-    heads -- as soon as d loss / d text-embeddings is complete.  That is only correct if every kernel that writes that
-    region has been issued by then (a one-rank RCCL group cannot show a violation: its all-reduce is the identity).
-    Snapshot the region at the moment the hook fires and compare with the region after the whole backward."""
-    from vln_bevbert_amd import ops, weights
-    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
-    from vln_bevbert_amd.train import PretrainTrainer
-    cfg = BevBertConfig.tiny(num_l_layers=2, num_x_layers=2, vocab_size=400)
-    model = GlocalTextPathCMTPreTraining(cfg)
-    model.load_state_dict(weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
-    model.tie_weights()
-    arena = model.finalize(DEV, dtype)
-    model.train()
-    model.set_dropout(0.1)
-    split = PretrainTrainer(model, arena, overlap=False).reducer.split
-    assert 0 < split < arena.numel
-    snap = {}
-
-    def at_hook(g):
-        ops.WgradStream.flush_all()                  # what GradReducer._launch does before it issues the collective
-        torch.cuda.synchronize()
-        snap["region"] = arena.grads[split:].clone()
-        return g
-
-    def fwd_hook(mod, inputs, output):
-        if output.requires_grad and torch.is_grad_enabled():
-            output.register_hook(at_hook)
-
-    handle = model.bert.lang_encoder.register_forward_hook(fwd_hook)
-    try:
-        for step, task in enumerate(("sap", "mlm", "masksem")):
-            snap.clear()
-            ops.RT.new_step(500 + step)
-            arena.zero_grad()
-            b = synthetic.batch_to(synthetic.make_batch(cfg, task, 3, seed=90 + step, ragged=True), DEV)
-            model(b, task).mean().backward()
-            arena.sync()
-            torch.cuda.synchronize()
-            assert "region" in snap, task                # the hook fired: every task here reads the text encoder
-            final = arena.grads[split:]
-            late = (snap["region"] != final).nonzero()
-            if late.numel():
-                off = int(late[0]) + split
-                name = [n for n, (o, k) in arena.slices.items() if o <= off < o + k]
-                raise AssertionError(f"{task}: {late.shape[0]} gradient elements of [split, end) changed after the "
-                                     f"text hook, first in {name}")
-            assert float(final.abs().sum()) > 0
-    finally:
-        handle.remove()

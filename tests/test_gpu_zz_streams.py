@@ -1,0 +1,159 @@
+"""Stream / collective plumbing of the training step on the MI355X (sorts after the parity tests on purpose: these
+compare the product with ITSELF under different launch orders; every oracle / golden comparison runs before them).
+
+  * the RCCL exchange (side stream, text-embedding hook, in-place all-reduce of arena slices) on a one-rank group must
+    leave exactly the gradients of a run without collectives -- compared BEFORE clip + AdamW, where a difference means
+    an ordering bug and not chaotic amplification of fp32 summation order;
+  * the precondition of the overlapped phase A: the arena region it reduces is final when the hook fires.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from vln_bevbert_amd import synthetic
+from vln_bevbert_amd.config import BevBertConfig
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# parameters whose gradients are accumulated with fp32 atomics (order-dependent in the last bits): the word-embedding
+# table (scatter of token gradients) and the Linear(1,1) behind the graph bias (atomic (B,G,G) bias gradient)
+ATOMIC = ("bert.embeddings.word_embeddings.weight", "bert.global_encoder.sprel_linear.weight",
+          "bert.global_encoder.sprel_linear.bias")
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vln_bevbert_amd import lib
+    lib.load()
+    return True
+
+
+def _fresh(cfg, dtype):
+    from vln_bevbert_amd import weights
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    model = GlocalTextPathCMTPreTraining(cfg)
+    model.load_state_dict(weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
+    model.tie_weights()
+    arena = model.finalize(DEV, dtype)
+    model.train()
+    model.set_dropout(0.1)
+    return model, arena
+
+
+@pytest.fixture(scope="module")
+def one_rank_group(env):
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rccl_reducer_leaves_the_gradients_of_a_run_without_collectives(one_rank_group, dtype):
+    """One backward per task with the collectives forced / not forced, same (seed, step): ``arena.grads`` before
+    clip + AdamW.  A one-rank all-reduce is the identity, so the two must agree: exactly wherever no fp32 atomics
+    contribute, and to 1e-6 relative L2 overall (pretrain_src/utils/misc.py:64-77 semantics: the wrapper changes
+    where gradients are summed, never their value)."""
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=2, num_x_layers=2, vocab_size=400)
+    grads = {}
+    for force in (None, False, True):            # the first pass only settles the hipBLASLt plans
+        model, arena = _fresh(cfg, dtype)
+        tr = PretrainTrainer(model, arena, warmup_steps=2, num_train_steps=20, force_collectives=bool(force))
+        assert tr.reducer.active == bool(force) and tr.overlap == bool(force)
+        for i, task in enumerate(("sap", "mlm", "masksem")):
+            b = synthetic.batch_to(synthetic.make_batch(cfg, task, 3, seed=80 + i, ragged=True), DEV)
+            loss = tr.forward_backward(task, b)
+            torch.cuda.synchronize()
+            grads[(force, task)] = (float(loss), arena.grads.clone())
+    exact = torch.ones(arena.numel, dtype=torch.bool, device=DEV)
+    for n in ATOMIC:
+        o, k = arena.slices[n]
+        exact[o:o + k] = False
+    for task in ("sap", "mlm", "masksem"):
+        (l0, g0), (l1, g1) = grads[(False, task)], grads[(True, task)]
+        assert l0 == l1, task
+        assert float(g0.norm()) > 0
+        rel = float((g0 - g1).norm() / g0.norm())
+        assert rel < 1e-6, (task, rel)
+        bad = (g0[exact] != g1[exact]).nonzero()
+        if bad.numel():
+            off = int(exact.nonzero()[int(bad[0])])
+            name = [n for n, (o, k) in arena.slices.items() if o <= off < o + k]
+            raise AssertionError(f"{task}: {bad.shape[0]} gradient elements outside the atomic regions differ "
+                                 f"with the collectives on, first in {name}")
+
+
+def test_four_steps_with_forced_collectives_track_a_run_without(one_rank_group):
+    """Smoke of the whole step (hook, side stream, clip, AdamW) with the exchange on: finite, and the losses of four
+    steps agree with a run without collectives to 1e-3 (parameters after AdamW are NOT compared: bias-corrected Adam
+    turns last-bit differences of near-zero gradients into +-lr updates)."""
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    curves = {}
+    for force in (None, False, True):
+        model, arena = _fresh(cfg, torch.bfloat16)
+        tr = PretrainTrainer(model, arena, warmup_steps=2, num_train_steps=20, force_collectives=bool(force))
+        out = []
+        for i, task in enumerate(("sap", "mlm", "masksem", "sap")):
+            out.append(float(tr.step(task, synthetic.batch_to(synthetic.make_batch(cfg, task, 2, seed=80 + i, ragged=True), DEV))))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(arena.params).all())
+        curves[force] = np.asarray(out)
+    assert np.isfinite(curves[True]).all()
+    assert np.max(np.abs(curves[True] - curves[False]) / np.maximum(1.0, np.abs(curves[False]))) < 1e-3, curves
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_phase_a_gradients_are_final_when_the_text_hook_fires(env, dtype):
+    """The overlapped all-reduce (train.GradReducer.phase_a) reduces the arena region [split, end) -- map encoders and
+    heads -- as soon as d loss / d text-embeddings is complete.  That is only correct if every kernel that writes that
+    region has been issued by then (a one-rank RCCL group cannot show a violation: its all-reduce is the identity).
+    Snapshot the region at the moment the hook fires and compare with the region after the whole backward."""
+    from vln_bevbert_amd import ops
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=2, num_x_layers=2, vocab_size=400)
+    model, arena = _fresh(cfg, dtype)
+    split = PretrainTrainer(model, arena, overlap=False).reducer.split
+    assert 0 < split < arena.numel
+    snap = {}
+
+    def at_hook(g):
+        ops.WgradStream.flush_all()                  # what GradReducer._launch does before it issues the collective
+        torch.cuda.synchronize()
+        snap["region"] = arena.grads[split:].clone()
+        return g
+
+    def fwd_hook(mod, inputs, output):
+        if output.requires_grad and torch.is_grad_enabled():
+            output.register_hook(at_hook)
+
+    handle = model.bert.lang_encoder.register_forward_hook(fwd_hook)
+    try:
+        for step, task in enumerate(("sap", "mlm", "masksem")):
+            snap.clear()
+            ops.RT.new_step(500 + step)
+            arena.zero_grad()
+            b = synthetic.batch_to(synthetic.make_batch(cfg, task, 3, seed=90 + step, ragged=True), DEV)
+            model(b, task).mean().backward()
+            arena.sync()
+            torch.cuda.synchronize()
+            assert "region" in snap, task                # the hook fired: every task here reads the text encoder
+            final = arena.grads[split:]
+            late = (snap["region"] != final).nonzero()
+            if late.numel():
+                off = int(late[0]) + split
+                name = [n for n, (o, k) in arena.slices.items() if o <= off < o + k]
+                raise AssertionError(f"{task}: {late.shape[0]} gradient elements of [split, end) changed after the "
+                                     f"text hook, first in {name}")
+            assert float(final.abs().sum()) > 0
+    finally:
+        handle.remove()

@@ -32,8 +32,14 @@ def test_library_builds_loads_and_exports_header_symbols():
 
 
 def test_code_object_targets_gfx950_only():
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", lib.LIB_PATH],
-                         capture_output=True, text=True).stdout
+    # --offloading drops the extracted code objects next to its INPUT file: work on a copy in a scratch directory so
+    # that nothing lands in the package directory
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        so = shutil.copy(lib.LIB_PATH, tmp)
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", so], capture_output=True,
+                             text=True, cwd=tmp).stdout
     archs = set(re.findall(r"gfx[0-9a-f]+", out))
     assert archs == {"gfx950"}, archs
 
@@ -275,3 +281,63 @@ def test_feature_cache_round_trip(tmp_path):
         feature_cache.write_shards([(keys[0], rgbs[0], depths[0], sems[0])] * 2, str(tmp_path / "dup"))
     with pytest.raises(ImportError, match="needs h5py"):
         feature_cache.convert_hdf5("a.hdf5", "b.hdf5", "c.hdf5", str(tmp_path / "x"))
+
+
+def _reference_config_bag(tag, **extra):
+    """What train_r2r.py:102-113 hands the model: an attribute bag with ONLY the keys of configs/<tag>_model.json plus
+    pretrain_tasks (a set) and sem_pred_token."""
+    import json
+    import types
+    with open(os.path.join(ROOT, "tests", "golden", "model_configs.json")) as f:
+        keys = json.load(f)[tag]
+    bag = types.SimpleNamespace(**keys)
+    for k, v in extra.items():
+        setattr(bag, k, v)
+    return bag, keys
+
+
+def test_models_build_from_the_reference_config_object():
+    """The drop-in boundary: the reference's own configuration object constructs the models; the
+    constants its JSON does not carry come from the defaults the reference hard-codes in its model code."""
+    from vln_bevbert_amd.nav_model import GlocalTextPathNavCMT
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    bag, keys = _reference_config_bag("r2r", pretrain_tasks={"mlm", "sap", "masksem"}, sem_pred_token="cattn")
+    for absent in ("bev_res", "grid_hw", "sem_classes", "grid_views", "grid_feat_size"):
+        assert absent not in keys                       # the point of the test: the JSON really lacks them
+    m = GlocalTextPathCMTPreTraining(bag)
+    assert not hasattr(bag, "grid_hw")                  # the caller's object is left alone
+    c = m.config
+    assert (c.grid_hw, c.bev_res, c.sem_classes, c.grid_views, c.bev_dim, c.feat_dropout) == (14, 0.5, 40, 12, 21, 0.4)
+    assert c.pretrain_tasks == {"mlm", "sap", "masksem"} and m.sem_pred_token == "cattn"
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == read_shapes("pretrain_state_dict_keys_r2r.txt")
+    # list-valued tasks and the xlm-roberta file
+    bag, _ = _reference_config_bag("rxr", pretrain_tasks=["mlm", "sap"], sem_pred_token="cattn")
+    bag.num_l_layers, bag.num_x_layers, bag.num_pano_layers = 1, 1, 1          # keep the CPU test light
+    m = GlocalTextPathCMTPreTraining(bag)
+    assert m.config.vocab_size == 250002 and not hasattr(m, "local_sem_head")
+    # transformers' own class, when importable, behaves like the bag
+    try:
+        from transformers import PretrainedConfig
+    except Exception:
+        PretrainedConfig = None
+    if PretrainedConfig is not None:
+        pc = PretrainedConfig(**{k: v for k, v in keys.items() if k not in ("num_labels",)})
+        pc.num_l_layers, pc.num_x_layers, pc.num_pano_layers, pc.vocab_size = 1, 1, 1, 500
+        pc.pretrain_tasks, pc.sem_pred_token = {"mlm", "sap", "masksem"}, "cattn"
+        assert GlocalTextPathCMTPreTraining(pc).config.bev_res == 0.5
+        # fine-tune side: vlnbert_init.py:57-76 sets these by hand on the PretrainedConfig
+        pc.fix_lang_embedding = pc.fix_pano_embedding = pc.fix_local_branch = False
+        assert GlocalTextPathNavCMT(pc).config.grid_hw == 14
+
+
+def test_remapped_pretrain_checkpoint_loads_strictly():
+    from vln_bevbert_amd.nav_model import GlocalTextPathNavCMT, remap_pretrain_checkpoint
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=300)
+    pre = GlocalTextPathCMTPreTraining(cfg)
+    nav = GlocalTextPathNavCMT(cfg)
+    mapped, missing, unexpected = remap_pretrain_checkpoint({"module." + k: v for k, v in pre.state_dict().items()}, nav)
+    assert missing == []
+    assert unexpected and all(k.startswith(("mlm_head.", "local_sem_head.")) for k in unexpected)
+    nav.load_state_dict(mapped, strict=True)
+    assert torch.equal(nav.global_sap_head.net[0].weight, pre.global_sap_head.net[0].weight)

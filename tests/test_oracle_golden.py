@@ -246,3 +246,55 @@ def test_rxr_vocabulary_tasks():
         assert max_abs(R.pretrain_forward(sd, cfg, b, "sap").numpy(), g["sap_loss"]) < FP32_TOL
         outs = R.pretrain_forward(sd, cfg, b, "sap", compute_loss=False)
         assert max_abs(outs[2].numpy(), g["sap_fused"]) < FP32_TOL
+
+
+def _module_inputs():
+    """The inputs of tests/golden/modules_tiny.npz, re-derived from its generator seed (make_golden.gen_modules)."""
+    g = torch.Generator().manual_seed(4242)
+    d = {"x": torch.randn(2, 11, 768, generator=g)}
+    d["m"] = torch.arange(11)[None] < torch.tensor([11, 6])[:, None]
+    d["lang"] = torch.randn(2, 9, 768, generator=g)
+    d["visn"] = torch.randn(2, 7, 768, generator=g)
+    d["spr"] = torch.randn(2, 7, 7, generator=g)
+    d["lm"] = torch.arange(9)[None] < torch.tensor([9, 4])[:, None]
+    d["vm"] = torch.arange(7)[None] < torch.tensor([5, 7])[:, None]
+    d["pano"] = torch.randn(3, 36, 768, generator=g)
+    d["pm"] = torch.arange(36)[None] < torch.tensor([36, 20, 5])[:, None]
+    d["vf"] = torch.randn(3, 36, 512, generator=g)
+    d["lf"] = torch.randn(3, 36, 7, generator=g)
+    d["nt"] = torch.randint(0, 3, (3, 36), generator=g)
+    d["bf"] = torch.randn(2, 441, 768, generator=g)
+    d["bp"] = torch.randn(2, 441, 10, generator=g)
+    d["bn"] = torch.rand(2, 441, generator=g) < 0.1
+    return d
+
+
+def test_per_module_vectors():
+    """One BertLayer, one GraphLXRTXLayer per forward (with / without graph_sprels), the panorama encoder alone, the
+    two input-embedding sums: the oracle's building blocks against the reference's own modules."""
+    from tests.helpers import rule_state_dict
+    g = load_golden("modules_tiny")
+    sd = rule_state_dict("pretrain_state_dict_keys_tiny.txt")
+    cfg = BevBertConfig.tiny()
+    d = _module_inputs()
+    nh = cfg.num_attention_heads
+    tol = 2e-5
+    assert max_abs(R.bert_layer(sd, "bert.lang_encoder.layer.0", d["x"], R.neg_mask(d["m"]), nh), g["bert_layer"]) < tol
+    p = "bert.global_encoder.encoder.x_layers.0"
+    el, ev = R.neg_mask(d["lm"]), R.neg_mask(d["vm"])
+    assert max_abs(R.x_layer_visn(sd, p, nh, d["lang"], el, d["visn"], ev, d["spr"][:, None]), g["x_visn_sprels"]) < tol
+    assert max_abs(R.x_layer_visn(sd, p, nh, d["lang"], el, d["visn"], ev), g["x_visn"]) < tol
+    assert max_abs(R.x_layer_lang2visn(sd, p, nh, d["lang"], el, d["visn"], ev), g["x_lang2visn"]) < tol
+    assert max_abs(R.x_layer_visn2visn(sd, p, nh, d["visn"], ev), g["x_visn2visn"]) < tol
+    e = d["pano"]
+    for i in range(cfg.num_pano_layers):
+        e = R.pano_layer(sd, f"bert.img_embeddings.pano_encoder.layers.{i}", e, ~d["pm"], nh)
+    e = R.layer_norm(sd, "bert.img_embeddings.pano_encoder.norm", e)
+    assert max_abs(e[d["pm"]], g["pano_encoder"][g["pano_valid"]]) < tol          # padded query rows carry garbage
+    ip = "bert.img_embeddings"
+    emb = R.layer_norm(sd, ip + ".img_layer_norm", R.linear(sd, ip + ".img_linear", d["vf"])) \
+        + R.layer_norm(sd, ip + ".loc_layer_norm", R.linear(sd, ip + ".loc_linear", d["lf"])) \
+        + sd[ip + ".nav_type_embedding.weight"][d["nt"]] + sd["bert.embeddings.token_type_embeddings.weight"][1]
+    assert max_abs(R.layer_norm(sd, ip + ".layer_norm", emb), g["img_embed_sum_ln"]) < tol
+    be = R.bev_input_embedding(sd, "bert.local_encoder", d["bf"], d["bp"], d["bn"])
+    assert max_abs(be.reshape(-1)[::5], g["bev_input_embedding_sub"]) < tol

@@ -64,6 +64,25 @@ class BevBertConfig:
             self.loc_feat_size = self.angle_feat_size + 3
 
     @classmethod
+    def adopt(cls, config):
+        """Complete a foreign configuration object.  The reference hands its models a transformers ``PretrainedConfig``
+        built from configs/*_model.json plus ``pretrain_tasks`` (set or list) and ``sem_pred_token``
+        (pretrain_src/train_r2r.py:102-113); those files do not carry the constants the reference hard-codes in its
+        model code (BEV resolution 0.5 m, the 14x14x12 ViT grid, 768-d grid features, 40 semantic classes:
+        pretrain_src/model/pretrain_cmt.py:16-32,68; vilmodel.py:577).  Any attribute bag / dict is accepted: known
+        keys are taken from it, everything else falls back to ``_DEFAULTS``; the caller's object is not modified."""
+        if isinstance(config, cls):
+            return config
+        if isinstance(config, dict):
+            get, has = config.__getitem__, config.__contains__
+        else:
+            get, has = (lambda k: getattr(config, k)), (lambda k: hasattr(config, k))
+        kw = {k: get(k) for k in cls._DEFAULTS if has(k) and get(k) is not None}
+        if isinstance(kw.get("pretrain_tasks"), str):
+            kw["pretrain_tasks"] = kw["pretrain_tasks"].split(".")[::2]      # "mlm.5.sap.5.masksem.1" (opts.task_ratio)
+        return cls(**kw)
+
+    @classmethod
     def from_json_file(cls, path, **kw):
         with open(path) as f:
             d = json.load(f)

@@ -4,6 +4,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .config import BevBertConfig
 from .pretrain_cmt import ClsPrediction, fuse_sap_logits, sap_fusion_indices
 from .vilmodel import (BertEmbeddings, GlobalMapEncoder, ImageEmbeddings, LanguageEncoder, LocalBEVEncoder,
                        _all_ones_to_none, finalize)
@@ -12,6 +13,7 @@ from .vilmodel import (BertEmbeddings, GlobalMapEncoder, ImageEmbeddings, Langua
 class GlocalTextPathNavCMT(nn.Module):
     def __init__(self, config):
         super().__init__()
+        config = BevBertConfig.adopt(config)     # map_nav_src/models/vlnbert_init.py:50-76 builds a PretrainedConfig
         self.config = config
         self.bev_dim = config.bev_dim
         self.embeddings = BertEmbeddings(config)
@@ -134,9 +136,14 @@ class VLNBert(nn.Module):
         raise NotImplementedError("wrong mode: %s" % mode)
 
 
-def remap_pretrain_checkpoint(state_dict):
+def remap_pretrain_checkpoint(state_dict, model=None):
     """map_nav_src/models/vlnbert_init.py:39-46: pre-training keys -> fine-tuning module keys
-    ('module.' stripped; '*_head' / 'sap_fuse' keys gain the 'bert.' prefix; then 'bert.' is the model root)."""
+    ('module.' stripped; '*_head' / 'sap_fuse' keys gain the 'bert.' prefix; then 'bert.' is the model root).
+
+    With ``model`` (a GlocalTextPathNavCMT) the mapped dict is filtered to the model's own keys so that it loads with
+    ``strict=True``, and the function returns ``(mapped, missing, unexpected)`` -- what the reference's
+    ``from_pretrained`` reports: keys the model has but the checkpoint lacks, and checkpoint keys the fine-tuning
+    model has no use for (the pre-training-only heads: mlm_head.*, local_sem_head.*, obj_classifier.*, ...)."""
     out = {}
     for k, v in state_dict.items():
         if k.startswith("module."):
@@ -145,4 +152,9 @@ def remap_pretrain_checkpoint(state_dict):
             k = "bert." + k
         if k.startswith("bert."):
             out[k[5:]] = v
-    return out
+    if model is None:
+        return out
+    own = model.state_dict()
+    unexpected = sorted(k for k in out if k not in own)
+    missing = sorted(k for k in own if k not in out)
+    return {k: v for k, v in out.items() if k in own}, missing, unexpected

@@ -3,7 +3,10 @@
 PyTorch here is plumbing: device memory, streams and the autograd tape.  The Linear layers stay on the vendor BLAS
 (north star) but are issued to hipBLASLt directly through the C ABI (bevbert_gemm, cached per-shape plans).  Everything else on the hot path --
 attention, bias/dropout/residual/LayerNorm, bias+GELU, the BEV splat, gmap aggregation, the optimiser -- is a
-hand-written HIP kernel reached through ``lib.call``.  Nothing in this file has a CPU or eager fallback.
+hand-written HIP kernel reached through ``lib.call``; none of them has a CPU or eager fallback.  The library GEMMs are
+the one exception: a problem hipBLASLt's direct path cannot take (no algorithm for the layout, the plan budget is
+spent, BEVBERT_LT_GEMM=0) is handed to torch's GEMM -- the same library underneath, 4x the host cost per call -- and
+every such problem is reported once through ``warnings`` (``ops.GEMM_FALLBACKS`` counts them), never silently.
 
 Gradient sinks: a parameter that lives in a ParamArena (arena.py) carries ``main_grad`` (fp32 view of the flat
 gradient arena).  Backward kernels accumulate straight into that view and the Function returns ``None`` for the
@@ -243,6 +246,17 @@ _LT_PLAN_BUDGET = int(_os.environ.get("BEVBERT_LT_PLAN_BUDGET", "2048"))
 
 
 _LT_PLANS = {}
+GEMM_FALLBACKS = {}      # (kind, M, N, K) -> calls that went through torch's GEMM instead of the direct hipBLASLt path
+
+
+def _warn_fallback(kind, M, N, K, why="no direct hipBLASLt plan"):
+    key = (kind, int(M), int(N), int(K))
+    n = GEMM_FALLBACKS.get(key, 0)
+    GEMM_FALLBACKS[key] = n + 1
+    if n == 0:
+        import warnings
+        warnings.warn(f"vln_bevbert_amd: {kind} GEMM M={M} N={N} K={K} runs through torch ({why}); same library, "
+                      f"~4x the host cost per call", RuntimeWarning, stacklevel=3)
 GEMM_TUNING_FILE = _os.environ.get("BEVBERT_GEMM_TABLE",
                                    _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "gemm_tuning.txt"))
 _tuning_loaded = False
@@ -329,6 +343,8 @@ def _linear_fwd(x, w_c, b_c):
         y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
         if _lt_gemm(x2, w_c, y, b_c, M, N, K, 0, 1, lda, w_c.stride(0), N):
             return y
+    if x.is_cuda:
+        _warn_fallback("fwd", x.numel() // max(1, K), N, K)
     return F.linear(x, w_c, b_c)
 
 
@@ -341,6 +357,8 @@ def _linear_dgrad(dy2, w_c):
         dx = torch.empty(M, K, dtype=dy2.dtype, device=dy2.device)
         if _lt_gemm(d2, w_c, dx, None, M, K, N, 0, 0, lda, w_c.stride(0), K):
             return dx
+    if dy2.is_cuda:
+        _warn_fallback("dgrad", dy2.shape[0], K, N)
     return dy2.mm(w_c)
 
 
@@ -356,6 +374,8 @@ def _linear_wgrad(dy2, x2, S=1):
             Ms = M // S
             if _lt_gemm(d2, xx, part, None, N, K, Ms, 1, 0, lda, ldb, K, S, Ms * lda, Ms * ldb, N * K):
                 return part
+    if dy2.is_cuda:
+        _warn_fallback("wgrad", N, K, M)
     if S > 1:
         return _on_launch_stream(lambda: torch.bmm(dy2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)))
     return _on_launch_stream(lambda: dy2.t().mm(x2))
@@ -392,6 +412,8 @@ def _wgrad_into(sink, dy2, x2):
     M, N = dy2.shape
     K = x2.shape[1]
     if dy2.dtype == torch.float32 and not (_LT_ENABLED and dy2.is_cuda):
+        if dy2.is_cuda:
+            _warn_fallback("wgrad", N, K, M, "BEVBERT_LT_GEMM=0")
         _gemm("wgrad", lambda: _on_launch_stream(lambda: sink.addmm_(dy2.t(), x2)), N, K, M)
         return None
     S = _split_k(M, N, K) if dy2.dtype != torch.float32 else 1
@@ -875,20 +897,26 @@ class _EmbedLN(torch.autograd.Function):
         def word_grad(t):
             call("bevbert_embedding_grad", ptr(ids), ptr(dz2), ptr(t), rows, H, dtype_code(dz2), stream())
 
-        outs = []
-        for p, make in ((word, word_grad),
-                        (pos, lambda t: t[:L].add_(dzf.view(B, L, H).sum(0))),
-                        (typ, lambda t: t[type_index].add_(dzf.sum(0)))):
+        makers = ((word, word_grad),
+                  (pos, lambda t: _on_launch_stream(lambda: t[:L].add_(dzf.view(B, L, H).sum(0)))),
+                  (typ, lambda t: _on_launch_stream(lambda: t[type_index].add_(dzf.sum(0)))))
+        outs, deferred = [], []
+        for p, make in makers:
             if not p.requires_grad:
                 outs.append(None)
             elif _sink(p) is not None:
                 _mark_touched(p)
-                make(_sink(p))
+                deferred.append((make, _sink(p)))
                 outs.append(None)
             else:
                 t = torch.zeros(p.shape, dtype=torch.float32, device=dy.device)
                 make(t)
                 outs.append(t.to(p.dtype))
+        if deferred:
+            # every write into a parameter's gradient sink goes through the weight-gradient stream: the word table also
+            # receives the tied MLM decoder's dW there (a deferred, non-atomic read-modify-write), the type table the
+            # panorama branch's row-1 gradient -- one stream keeps the writers of a sink in program order
+            WgradStream.submit(dy.device, lambda: [m(t) for m, t in deferred], dz2, dzf, ids, dy)
         return (None, outs[0], outs[1], outs[2], rg, rb, None, None, None, None, None)
 
 

@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
+from .config import BevBertConfig
 from .vilmodel import BertOnlyMLMHead, GlocalTextPathCMT, finalize, gen_seq_masks
 
 BEV_DIM = 21      # pretrain_cmt.py:16-17 (the config's bev_dim / bev_res override these defaults)
@@ -110,6 +111,7 @@ _MLM_ROW_PAD = int(_os.environ.get("BEVBERT_MLM_ROW_PAD", "0"))      # 0 = off (
 class GlocalTextPathCMTPreTraining(nn.Module):
     def __init__(self, config):
         super().__init__()
+        config = BevBertConfig.adopt(config)     # a PretrainedConfig built from configs/*_model.json drops in (train_r2r.py:102-113)
         self.config = config
         self.bert = GlocalTextPathCMT(config)
         self.feat_dropout = config.feat_dropout

@@ -147,6 +147,8 @@ class PretrainTrainer:
         # the arena keeps registration order: embeddings, lang_encoder, img_embeddings come before the map encoders
         self.reducer = GradReducer(arena.grads, first_map, force=force_collectives)
         self.overlap = overlap and self.reducer.active
+        if self.reducer.active:
+            self.broadcast_state()             # replicas start from rank 0's weights, as under DistributedDataParallel
         if self.overlap:
             model.bert.lang_encoder.register_forward_hook(self._hook_text)
             # opt-in finer pipeline (BEVBERT_REDUCE_TEXT_LAYERS="2,4,6"; not validated on a multi-GPU node yet): when the
@@ -173,8 +175,27 @@ class PretrainTrainer:
             output.register_hook(lambda g: (self.reducer.phase_a(), g)[1])
         return output
 
-    def step(self, task, batch):
-        """One optimisation step on one batch (gradient_accumulation_steps == 1, as every shipped config)."""
+    def broadcast_state(self, src=0):
+        """DistributedDataParallel's wrap-time synchronisation (pretrain_src/utils/misc.py:64-72: DDP broadcasts
+        rank 0's parameters and buffers when it wraps the model).  The reference seeds every rank differently
+        (train_r2r.py:85-88) and loads its LXMERT / XLM-R checkpoints with strict=False, so every parameter the
+        checkpoint lacks (image / BEV / map embeddings, all heads) starts rank-specific; only the broadcast makes the
+        replicas identical.  Here: ONE collective over the flat parameter arena (plus the optimiser state when a run
+        is resumed), then the bf16 compute copy is rebuilt from the received masters."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        a = self.arena
+        dist.broadcast(a.params, src=src, group=self.reducer.group)
+        if a.exp_avg is not None:
+            dist.broadcast(a.exp_avg, src=src, group=self.reducer.group)
+            dist.broadcast(a.exp_avg_sq, src=src, group=self.reducer.group)
+            dist.broadcast(a.chunk_steps, src=src, group=self.reducer.group)
+        for b in self.model.buffers():
+            dist.broadcast(b, src=src, group=self.reducer.group)
+        a.sync_shadow()
+
+    def forward_backward(self, task, batch):
+        """Forward + backward + gradient exchange of one batch; leaves the (summed) gradients in ``arena.grads``."""
         self.global_step += 1
         ops.RT.new_step((self.seed + self.rank) * 1000003 + self.global_step)    # per-rank dropout stream
         self.arena.zero_grad()
@@ -183,6 +204,15 @@ class PretrainTrainer:
         loss.backward()
         self.arena.sync()                      # side-stream branches have written their gradients
         self.reducer.finish()
+        return loss.detach()
+
+    def optimizer_step(self):
+        """clip_grad_norm_ + AdamW + schedule (train_r2r.py:278-313) on the flat arena."""
         lr = warmup_linear_lr(self.global_step, self.lr, self.warmup, self.total)
         self.arena.clip_and_step(lr, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
-        return loss.detach()
+
+    def step(self, task, batch):
+        """One optimisation step on one batch (gradient_accumulation_steps == 1, as every shipped config)."""
+        loss = self.forward_backward(task, batch)
+        self.optimizer_step()
+        return loss

@@ -20,6 +20,7 @@ from torch import nn
 
 from . import ops
 from .arena import ParamArena
+from .config import BevBertConfig
 
 LN_EPS = 1e-12
 
@@ -439,7 +440,8 @@ class _GatherRows(torch.autograd.Function):
         g = onehot.t().mm(d)
         if sink is not None:
             ops._mark_touched(table)
-            sink.add_(g)
+            # sink writes live on the weight-gradient stream (the token-type table is also written by _EmbedLN there)
+            ops.WgradStream.submit(dy.device, lambda: ops._on_launch_stream(lambda: sink.add_(g)), g, dy)
             return None, None, None
         return None, g.to(table.dtype), None
 
@@ -559,6 +561,7 @@ class GlocalTextPathCMT(nn.Module):
 
     def __init__(self, config):
         super().__init__()
+        config = BevBertConfig.adopt(config)
         self.config = config
         self.bev_dim = config.bev_dim
         self.embeddings = BertEmbeddings(config)
