@@ -130,6 +130,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from vln_bevbert_amd import ops, synthetic
+    from vln_bevbert_amd.static_step import StaticBatch
     from vln_bevbert_amd.config import BevBertConfig
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
     from vln_bevbert_amd.train import PretrainTrainer, load_gemm_tuning
@@ -155,9 +156,10 @@ def main():
     counter = [0]
 
     log(f"model in arena: {arena.n_params / 1e6:.1f} M params; generating resident batches")
-    # resident synthetic batches: two per task and rank, drawn with seed 1000 + rank
-    batches = {t: [synthetic.batch_to(synthetic.make_batch(cfg, t, a.batch, seed=1000 + rank + 97 * j,
-                                                           txt_len=a.txt_len, sems_as="ids"), dev)
+    # resident synthetic batches: two per task and rank, drawn with seed 1000 + rank, each in
+    # its own set of static device buffers (static_step.StaticBatch: loader-built index tensors, padded row counts)
+    batches = {t: [StaticBatch(cfg, t, synthetic.make_batch(cfg, t, a.batch, seed=1000 + rank + 97 * j,
+                                                            txt_len=a.txt_len, sems_as="ids"), dev)
                    for j in range(2)] for t in tasks}
     torch.cuda.synchronize()
 
@@ -175,13 +177,16 @@ def main():
             losses.append(trainer.step(t, batches[t][(i // len(cycle)) % 2]))
         return losses
 
-    # plan pass (untimed, before the warm-up): every distinct resident batch goes through the step once, so that each
-    # GEMM problem of the run has its hipBLASLt plan -- from the shipped choice table, or timed now (problems whose row
-    # count depends on the data, e.g. the number of masked tokens of this rank's batches) -- before anything is measured
-    log("batches resident; plan pass")
-    for t in tasks:
-        for bt in batches[t]:
-            trainer.step(t, bt)
+    # preparation (untimed, before the warm-up): every distinct resident batch goes through the step eagerly (each GEMM
+    # problem of the run gets its hipBLASLt plan -- from the shipped choice table, or timed now: problems whose row
+    # count depends on the data) and is then captured into a hipGraph, so that the timed region only replays
+    n_prep = trainer.GRAPH_WARMUP + 1 if trainer.use_graphs else 1
+    log(f"batches resident; preparation pass ({n_prep} steps per batch; graphs {'on' if trainer.use_graphs else 'off'})")
+    for _ in range(n_prep):
+        for t in tasks:
+            for bt in batches[t]:
+                trainer.step(t, bt)
+    n_graphs = sum(bt.graph is not None for t in tasks for bt in batches[t])
     log("warm-up")
     run(a.warmup)
     barrier()
@@ -209,8 +214,68 @@ def main():
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "params_M": round(arena.n_params / 1e6, 1), "gemm": f"hipBLASLt via the C ABI, {n_rows} shapes from the shipped choice table, others timed on first use"},
         "host_enqueue_ms_per_step": round(1000.0 * t_host / a.steps, 3),
+        "step_launch": f"hipGraph replay ({n_graphs} captured steps, one per resident batch)" if n_graphs else "eager",
         "final_loss": round(float(losses[-1].item()), 4),
     }
+
+    # ---- forward ms/batch (the second half of BASELINE.json's metric; reference: train_r2r.py:256-260): the training
+    # forward (dropout on, tape recorded) issued eagerly, and the same batch's inference forward replayed from a graph
+    if rank == 0:
+        log("forward timing")
+        fwd = {}
+        for t in tasks:
+            sb = batches[t][0]
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+            def timed(fn, n=10):
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                ev[0].record()
+                for _ in range(n):
+                    fn()
+                ev[1].record()
+                torch.cuda.synchronize()
+                return ev[0].elapsed_time(ev[1]) / n
+
+            def train_fwd():
+                ops.RT.new_step(12345)
+                model.loss_mean(sb.tensors, t)
+
+            fwd[t] = {"train_eager_ms": round(timed(train_fwd), 3)}
+            arena.sync()
+            model.eval()
+            try:
+                with torch.no_grad():
+                    for _ in range(2):
+                        model.loss_mean(sb.tensors, t)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        model.loss_mean(sb.tensors, t)
+                    fwd[t]["eval_graph_ms"] = round(timed(g.replay), 3)
+            except Exception as e:          # a forward that cannot be captured is reported, not hidden
+                fwd[t]["eval_graph_ms"] = None
+                fwd[t]["eval_graph_error"] = repr(e)[:200]
+                torch.cuda.synchronize()
+            model.train()
+        out["fwd_ms_per_batch"] = fwd
+    if world > 1 or force:
+        # what the exchange moves, and how long it takes alone (all ranks take part; rank 0 reports)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(arena.grads)
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t0) / 5 * 1e3
+        out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                       "allreduce_bytes_per_step": int(arena.numel) * 4,
+                       "phase_a_bytes": int(arena.numel - trainer.reducer.split) * 4,
+                       "allreduce_alone_ms": round(ar_ms, 3),
+                       "allreduce_alone_GBps": round(arena.numel * 4 / ar_ms / 1e6, 1),
+                       "overlap": "phase A from the text-embedding gradient hook, phase B after backward; both on a "
+                                  "side stream" + (", captured inside the step graph" if n_graphs else "")}
+        arena.grads.zero_()
 
     if not a.no_kernel_pass:
         # ---- per-kernel timing pass (not part of the timed region above): HIP events around every C-ABI launch.
@@ -260,12 +325,16 @@ def main():
             by_entry[k.split("[")[0]] = by_entry.get(k.split("[")[0], 0.0) + r["ms"]
         dom_entry = max(by_entry, key=by_entry.get)
         dom_key, dom = max(((k, r) for k, r in rows.items() if k.split("[")[0] == dom_entry), key=lambda kv: kv[1]["ms"])
-        traffic = None       # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if measured
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f).get(dom_key)
-        except Exception:
-            pass
+        traffic = traffic_source = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic = json.load(f).get(dom_key)
+            except Exception:
+                traffic = None
+            if traffic is not None:
+                traffic_source = f"profiles/{name} (separate rocprofv3 --pmc passes over scripts/bench_attn.py, not this process)"
+                break
 
         def roof(r):
             secs = r["ms"] / 1e3
@@ -277,7 +346,8 @@ def main():
             return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4)}
 
-        out["roofline"] = {"kernel": dom_key, **roof(dom), "traffic": traffic, "avg_launch_us": dom["avg_us"],
+        out["roofline"] = {"kernel": dom_key, **roof(dom), "traffic": traffic, "traffic_source": traffic_source,
+                           "avg_launch_us": dom["avg_us"],
                            "launches": dom["launches"],
                            "entry_share_of_custom_ms": round(by_entry[dom_entry] / max(custom_ms, 1e-9), 3)}
         # the same figure for every traced hand-written entry (heaviest first) -- context for the line above

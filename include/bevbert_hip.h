@@ -147,12 +147,15 @@ int bevbert_segment_wsum(const void* src, const int* rowptr, const int* idx, con
  * bevbert_adamw_step: AdamW.step (pretrain_src/optim/adamw.py:53-112): bias-corrected Adam, decoupled decay applied
  *   after the update; optionally refreshes the bf16 shadow copy of the parameters in the same pass.  chunk_steps
  *   (int32 per 1024-element chunk, zero-initialised by the caller) is the reference's per-parameter state["step"]:
- *   it advances only for chunks whose flag bit1 is set, so a parameter first used at step 6 starts at t = 1. */
+ *   it advances only for chunks whose flag bit1 is set, so a parameter first used at step 6 starts at t = 1.
+ *   lr_dev (may be NULL): learning rate read from device memory instead of the `lr` argument, so that a step captured
+ *   in a hipGraph follows the schedule (optim/sched.py:24-30) without being re-captured. */
 int bevbert_grad_norm_clip(const float* grads, int64_t n, float pre_scale, float max_norm, float* partials,
                            float* scalars, hipStream_t stream);
 int bevbert_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* params_bf16,
-                       const uint8_t* chunk_flags, int* chunk_steps, int64_t n, const float* grad_scale_dev, float lr,
-                       float beta1, float beta2, float eps, float weight_decay, hipStream_t stream);
+                       const uint8_t* chunk_flags, int* chunk_steps, int64_t n, const float* grad_scale_dev,
+                       const float* lr_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       hipStream_t stream);
 int bevbert_cast_f32(const float* src, void* dst, int64_t n, int dst_dtype, hipStream_t stream);
 /* sink[i] += sum_{s<S} partials[s*n + i]: reduction of the host-side split-K weight-gradient GEMMs (library batched
  * GEMM over S chunks of the token axis), fused with the accumulation into the fp32 gradient arena. */
@@ -200,6 +203,13 @@ int bevbert_gemm_tuning_import(const char* text);
  * (transformer.py:170-182).  The backward of x is the same call on dy with residual = NULL. */
 int bevbert_dropout_add(const void* x, const void* residual, void* y, int64_t n, int in_dtype, int out_dtype,
                         float drop_p, uint64_t seed, uint64_t offset, hipStream_t stream);
+
+/* Per-step dropout salt.  Every dropout site derives its mask from hash(seed, offset) -- launch arguments, frozen in a
+ * captured hipGraph.  After bevbert_set_step_salt(word) (word: 4 bytes of device memory owned by the caller, NULL to
+ * clear) every dropout kernel of the library uses hash(site_key ^ *word): the host rewrites the word once per training
+ * step and a replayed graph draws fresh masks; forward and backward of one step read the same word, so they agree.
+ * Process-wide setting (the one piece of state besides the hipBLASLt plan cache); set it once, before any launch. */
+int bevbert_set_step_salt(const void* device_word);
 
 /* test hook: keep-mask (uint8) the kernels derive for n consecutive elements starting at `offset` */
 int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p, uint64_t seed, uint64_t offset,

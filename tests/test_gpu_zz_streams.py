@@ -157,3 +157,92 @@ def test_phase_a_gradients_are_final_when_the_text_hook_fires(env, dtype):
             assert float(final.abs().sum()) > 0
     finally:
         handle.remove()
+
+
+# ----------------------------------------------------------------------------- static batches and captured steps
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_static_batch_step_equals_the_reference_api_step(env, dtype):
+    """A static_step.StaticBatch (loader-built fusion table / masked positions / CSR, padded row counts, padded
+    global-map width) gives the loss and the gradients of the same batch fed through the reference API
+    (GlocalTextPathCMTPreTraining.forward(batch, task).mean()): padding rows carry exactly zero weight."""
+    from vln_bevbert_amd import ops
+    from vln_bevbert_amd.static_step import StaticBatch
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    model, arena = _fresh(cfg, dtype)
+    model.set_dropout(0.0)
+    for task in ("sap", "mlm", "masksem"):
+        cpu = synthetic.make_batch(cfg, task, 3, seed=70, ragged=True, sems_as="ids")
+        sb = StaticBatch(cfg, task, cpu, DEV)
+        res = []
+        for which in ("api", "static", "api", "static"):            # the first two settle the library plans
+            ops.RT.new_step(5)
+            arena.zero_grad()
+            if which == "api":
+                loss = model(synthetic.batch_to(cpu, DEV), task).mean()
+            else:
+                loss = model.loss_mean(sb.tensors, task)
+            loss.backward()
+            arena.sync()
+            torch.cuda.synchronize()
+            res.append((float(loss), arena.grads.clone()))
+        (la, ga), (ls, gs_) = res[2], res[3]
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert abs(la - ls) <= tol * max(1.0, abs(la)), (task, la, ls)
+        rel = float((ga - gs_).norm() / ga.norm())
+        assert rel < (1e-4 if dtype == torch.float32 else 5e-2), (task, rel)
+
+
+def test_captured_step_replays_the_eager_step(env):
+    """The hipGraph path against the eager path, same weights, same (seed, step) sequence, dropout ON: four passes over
+    three static batches (two eager uses, the capture, one replay each).  The first step is compared bit for bit
+    (identical parameters on both sides); later steps to 1e-5 -- the only run-to-run freedom of either path is the
+    order of the fp32 atomics in the word-embedding / graph-bias gradients, which AdamW then carries into the weights.
+    Replays must also follow the learning-rate schedule and draw fresh dropout masks (device-resident lr / salt)."""
+    from vln_bevbert_amd.static_step import StaticBatch
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    seq = ("sap", "mlm", "masksem") * 4
+    curves, finals = {}, {}
+    for graphs in (False, True):
+        model, arena = _fresh(cfg, torch.bfloat16)
+        tr = PretrainTrainer(model, arena, learning_rate=1e-4, warmup_steps=4, num_train_steps=40)
+        tr.use_graphs = graphs
+        sbs = {t: StaticBatch(cfg, t, synthetic.make_batch(cfg, t, 3, seed=60, ragged=True, sems_as="ids"), DEV)
+               for t in ("sap", "mlm", "masksem")}
+        out = [float(tr.step(t, sbs[t])) for t in seq]
+        torch.cuda.synchronize()
+        assert all((sb.graph is not None) == graphs for sb in sbs.values())
+        curves[graphs], finals[graphs] = np.asarray(out), arena.params.clone()
+    e, g = curves[False], curves[True]
+    assert np.isfinite(g).all()
+    assert e[0] == g[0], (e[0], g[0])
+    assert np.max(np.abs(e - g) / np.maximum(1.0, np.abs(e))) < 1e-5, (e, g)
+    # the same batch at different steps: different dropout masks and a moving learning rate -> different losses
+    assert len({round(x, 6) for x in g[0::3]}) == 4, g[0::3]
+    rel = float((finals[False] - finals[True]).norm() / finals[False].norm())
+    assert rel < 1e-5, rel
+
+
+def test_static_batch_refill_keeps_the_captured_graph(env):
+    """load() writes the next batch of the same shape bucket into the buffers a graph was captured on; the replay then
+    trains on the new batch (loss equals a fresh eager step on that batch from the same weights)."""
+    from vln_bevbert_amd.static_step import StaticBatch
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    b1 = synthetic.make_batch(cfg, "sap", 3, seed=61, sems_as="ids")
+    b2 = synthetic.make_batch(cfg, "sap", 3, seed=62, sems_as="ids")
+    losses = {}
+    for graphs in (False, True):
+        model, arena = _fresh(cfg, torch.float32)
+        model.set_dropout(0.0)
+        tr = PretrainTrainer(model, arena, learning_rate=0.0, warmup_steps=1, num_train_steps=10)   # lr 1e-8: weights ~fixed
+        tr.use_graphs = graphs
+        sb = StaticBatch(cfg, "sap", b1, DEV)
+        if sb.signature != StaticBatch(cfg, "sap", b2, "cpu").signature:
+            pytest.skip("the two synthetic batches fell into different shape buckets")
+        for _ in range(3):
+            tr.step("sap", sb)
+        assert (sb.graph is not None) == graphs
+        sb.load(b2)
+        losses[graphs] = float(tr.step("sap", sb))
+    assert abs(losses[True] - losses[False]) <= 1e-5 * max(1.0, abs(losses[False])), losses

@@ -341,3 +341,56 @@ def test_remapped_pretrain_checkpoint_loads_strictly():
     assert unexpected and all(k.startswith(("mlm_head.", "local_sem_head.")) for k in unexpected)
     nav.load_state_dict(mapped, strict=True)
     assert torch.equal(nav.global_sap_head.net[0].weight, pre.global_sap_head.net[0].weight)
+
+
+def test_static_batch_host_side_and_in_place_refill():
+    """static_step.StaticBatch on the CPU: the loader-built index tensors equal what the model would build inside its
+    forward, padded row counts carry zero weight, and load() rewrites the same buffers."""
+    from vln_bevbert_amd.pretrain_cmt import sap_fusion_indices
+    from vln_bevbert_amd.static_step import GMAP_PAD, MLM_ROW_PAD, SEM_ROW_PAD, StaticBatch
+    from vln_bevbert_amd.vilmodel import build_gmap_csr
+    cfg = BevBertConfig.tiny()
+    b1 = synthetic.make_batch(cfg, "sap", 4, seed=5, sems_as="ids")
+    b2 = synthetic.make_batch(cfg, "sap", 4, seed=6, sems_as="ids")
+    sb = StaticBatch(cfg, "sap", b1, "cpu")
+    G0 = int(b1["gmap_lens"].max())
+    G = sb.tensors["gmap_step_ids"].shape[1]
+    assert G % GMAP_PAD == 0 and G0 <= G < G0 + GMAP_PAD and sb.tensors["gmap_pair_dists"].shape == (4, G, G)
+    assert torch.equal(sb.tensors["gmap_pair_dists"][:, :G0, :G0], b1["gmap_pair_dists"])
+    src, vis_c = sap_fusion_indices(b1["gmap_vpids"], b1["gmap_visited_masks"].tolist(),
+                                    [[None] + c[-1] for c in b1["traj_cand_vpids"]], G0, b1["bev_cand_idxs"].shape[1])
+    st = sb.tensors["_static"]
+    assert np.array_equal(st["sap_src"].numpy()[:, :G0], src) and np.array_equal(st["sap_vis_c"].numpy(), vis_c)
+    assert (st["sap_src"].numpy()[:, G0:] == b1["bev_cand_idxs"].shape[1] + 1).all()      # padding reads the zero slot
+    ref_csr, _ = build_gmap_csr(list(b1["traj_step_lens"]), b1["traj_vp_view_lens"].tolist(), b1["traj_vpids"],
+                                b1["traj_cand_vpids"], b1["gmap_vpids"], 36, "cpu", G=G)
+    csr = sb.tensors["gmap_csr"][0]
+    n = ref_csr.idx.numel()
+    assert torch.equal(csr.rowptr, ref_csr.rowptr) and torch.equal(csr.idx[:n], ref_csr.idx) and csr.capacity >= n
+    assert torch.equal(csr.t_rowptr, ref_csr.t_rowptr) and torch.equal(csr.t_idx[:n], ref_csr.t_idx)
+    # refill in place: same buffers, the other batch's content
+    ptrs = {k: v.data_ptr() for k, v in sb.tensors.items() if torch.is_tensor(v) and not k.endswith("_cpu")}
+    assert StaticBatch(cfg, "sap", b2, "cpu").signature == sb.signature
+    sb.load(b2)
+    assert all(sb.tensors[k].data_ptr() == p for k, p in ptrs.items())
+    fresh = StaticBatch(cfg, "sap", b2, "cpu")
+    for k, v in fresh.tensors.items():
+        if torch.is_tensor(v):
+            assert torch.equal(sb.tensors[k], v), k
+    assert torch.equal(sb.tensors["_static"]["sap_src"], fresh.tensors["_static"]["sap_src"])
+    assert torch.equal(sb.tensors["gmap_csr"][0].rowptr, fresh.tensors["gmap_csr"][0].rowptr)
+    # a different bucket is refused
+    with pytest.raises(ValueError):
+        sb.load(synthetic.make_batch(cfg, "sap", 3, seed=6, sems_as="ids"))
+    # MLM: masked positions padded to a multiple of MLM_ROW_PAD with zero-weight rows
+    bm = synthetic.make_batch(cfg, "mlm", 4, seed=7, sems_as="ids")
+    sm = StaticBatch(cfg, "mlm", bm, "cpu").tensors["_static"]
+    lab = bm["txt_labels"].reshape(-1)
+    pos = torch.nonzero(lab != -1).squeeze(1)
+    assert sm["mlm_n"] == pos.numel() and sm["mlm_pos"].numel() % MLM_ROW_PAD == 0
+    assert torch.equal(sm["mlm_pos"][:sm["mlm_n"]], pos) and torch.equal(sm["mlm_targets"][:sm["mlm_n"]], lab[pos])
+    assert float(sm["mlm_valid"].sum()) == sm["mlm_n"] and float(sm["mlm_n_dev"]) == sm["mlm_n"]
+    # MaskSEM: the row capacity bounds the number of supervised cells from above
+    bs = synthetic.make_batch(cfg, "masksem", 4, seed=8, sems_as="ids")
+    cap = StaticBatch(cfg, "masksem", bs, "cpu").tensors["_static"]["sem_cap"]
+    assert cap % SEM_ROW_PAD == 0 and cap >= int(bs["bev_mrc_masks"].sum())

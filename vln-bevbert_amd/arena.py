@@ -89,7 +89,7 @@ class ParamArena:
         self._touched = set()
         self._flags_dirty = False
         self.step_count = 0
-        self._scalars = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._scalars = torch.zeros(4, dtype=torch.float32, device=dev)       # [grad norm, clip multiplier, lr, -]
         self._partials = torch.zeros(1024, dtype=torch.float32, device=dev)
         # re-point every parameter at its arena view
         self.named = named
@@ -132,17 +132,19 @@ class ParamArena:
                  stream())
 
     def sync(self):
-        """Make the current stream wait for the model's side-stream branches (ops.Branches).  Backward kernels write
-        parameter gradients straight into ``grads`` as a side effect autograd does not see, so whoever reads or
-        overwrites the arena next (optimiser, all-reduce, zero_grad, a test) must order itself after them."""
+        """Make the current stream wait for the side streams that carry work of this step (weight-gradient stream,
+        model branches).  Backward kernels write parameter gradients straight into ``grads`` as a side effect autograd
+        does not see, so whoever reads or overwrites the arena next (optimiser, all-reduce, zero_grad, a test) must
+        order itself after them.  Streams without pending work are left alone: inside a graph capture a wait on a
+        stream that is not part of the capture would be an error."""
         if self.device.type == "cuda":
             from . import ops
             ops.WgradStream.flush_all()
-            sides = ops.Branches.side_streams()
-            if sides:
-                cur = torch.cuda.current_stream(self.device)
-                for side in sides:
+            cur = torch.cuda.current_stream(self.device)
+            for side in ops.Branches.side_streams():
+                if ops.Branches.enabled or side is not ops.WgradStream.stream or ops.WgradStream.dirty:
                     cur.wait_stream(side)
+            ops.WgradStream.dirty = False
             ops.WgradStream.release()
 
     def zero_grad(self):
@@ -155,21 +157,36 @@ class ParamArena:
         return out
 
     # ---- optimiser ---------------------------------------------------------------------------
-    def clip_and_step(self, lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_norm=5.0, grad_pre_scale=1.0):
-        """clip_grad_norm_(max_norm) + AdamW.step (train_r2r.py:295-313) in three launches, no host sync."""
+    def set_lr(self, lr):
+        """Learning rate of the next optimiser step, kept in device memory (one 4-byte fill on the stream): the AdamW
+        kernel reads it there, so a step captured in a hipGraph follows the schedule without being re-captured."""
+        self._scalars[2:3].fill_(float(lr))
+
+    def upload_flags(self):
+        """Host -> device copy of the per-chunk flags when a parameter was touched for the first time (never inside a
+        graph capture: the copy reads pageable host memory)."""
+        if self._flags_dirty:
+            self.flags.copy_(self._flags_host, non_blocking=True)
+            self._flags_dirty = False
+
+    def clip_and_step(self, lr=None, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_norm=5.0, grad_pre_scale=1.0):
+        """clip_grad_norm_(max_norm) + AdamW.step (train_r2r.py:295-313) in three launches, no host sync.
+        ``lr=None``: use the device-resident learning rate as set by ``set_lr`` (graph-captured steps)."""
         self.sync()
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.params)
             self.exp_avg_sq = torch.zeros_like(self.params)
-        if self._flags_dirty:
-            self.flags.copy_(self._flags_host, non_blocking=True)
-            self._flags_dirty = False
+        if lr is not None:
+            self.set_lr(lr)
+        if not torch.cuda.is_current_stream_capturing():
+            self.upload_flags()
         self.step_count += 1
         call("bevbert_grad_norm_clip", ptr(self.grads), self.numel, float(grad_pre_scale),
              float(max_norm if max_norm is not None else -1.0), ptr(self._partials), ptr(self._scalars), stream())
         call("bevbert_adamw_step", ptr(self.params), ptr(self.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
              ptr(self.shadow), ptr(self.flags), ptr(self.chunk_steps), self.numel, self._scalars[1:].data_ptr(),
-             float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), stream())
+             self._scalars[2:].data_ptr(), 0.0, float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+             stream())
 
     def grad_norm(self):
         """L2 norm computed by the last clip_and_step (device scalar; reading it syncs)."""

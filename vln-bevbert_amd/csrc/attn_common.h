@@ -26,7 +26,8 @@ struct AttnArgs {
   float scale;
   float drop_p;
   uint32_t drop_thr;   // 16-bit threshold
-  uint32_t drop_key;   // bb_site_key(seed, offset)
+  uint32_t drop_key;   // bb_site_key(seed, offset); kernels use bb_salted(drop_key, salt)
+  const uint32_t* salt; // per-step salt word in device memory (bevbert_set_step_salt) or null
   int nblk;            // workgroups per (batch, head) along the tiled sequence axis (set by the launcher)
   int Lk2;             // Lk rounded up to even: dropout element index = ((b*nh + h)*Lq + q)*Lk2 + k
   // backward only

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
   int blk, h, b;
   attn_decode_block(a, blk, h, b);
+  if (DROP) a.drop_key = bb_salted(a.drop_key, a.salt);
   const int qbase = blk * (64 * QT) + w * (16 * QT);
   const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
   const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
   int blk, h, b;
   attn_decode_block(a, blk, h, b);
+  if (DROP) a.drop_key = bb_salted(a.drop_key, a.salt);
   const int qbase = blk * (64 * QT) + w * (16 * QT);
   const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
   const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(256, KT == 1 ? 2 : 1) void attn_mfma_dkv_kernel(Att
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
   int blk, h, b;
   attn_decode_block(a, blk, h, b);
+  if (DROP) a.drop_key = bb_salted(a.drop_key, a.salt);
   const int kbase = blk * (64 * KT) + w * (16 * KT);
   const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
   const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;

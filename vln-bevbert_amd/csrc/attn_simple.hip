@@ -29,6 +29,7 @@ __device__ __forceinline__ float score(const AttnArgs& a, const T* kbase, const 
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_simple_fwd_kernel(AttnArgs a) {
+  if (a.drop_p > 0.f) a.drop_key = bb_salted(a.drop_key, a.salt);
   __shared__ float s_p[4][LK_MAX];
   __shared__ float s_q[4][ATTN_D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, float* __re
 // dQ (and dbias): one wave per query row
 template <typename T>
 __global__ __launch_bounds__(256) void attn_simple_dq_kernel(AttnArgs a) {
+  if (a.drop_p > 0.f) a.drop_key = bb_salted(a.drop_key, a.salt);
   __shared__ float s_ds[4][LK_MAX];
   __shared__ float s_q[4][ATTN_D];
   __shared__ float s_do[4][ATTN_D];
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256) void attn_simple_dq_kernel(AttnArgs a) {
 // dK, dV: one wave per key row, lanes over the head dim
 template <typename T>
 __global__ __launch_bounds__(256) void attn_simple_dkv_kernel(AttnArgs a) {
+  if (a.drop_p > 0.f) a.drop_key = bb_salted(a.drop_key, a.salt);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int key = blockIdx.x * 4 + w, h = blockIdx.y, b = blockIdx.z;
   if (key >= a.Lk) return;

@@ -14,7 +14,14 @@ void bb_set_error(const char* fmt, ...) {
 }
 
 BEVBERT_API const char* bevbert_last_error(void) { return g_err; }
-BEVBERT_API int bevbert_version(void) { return 100; }  // 0.1.0
+BEVBERT_API int bevbert_version(void) { return 110; }  // 0.1.1: step salt, device-resident learning rate
+
+static const uint32_t* g_step_salt = nullptr;
+const uint32_t* bb_step_salt() { return g_step_salt; }
+BEVBERT_API int bevbert_set_step_salt(const void* device_word) {
+  g_step_salt = static_cast<const uint32_t*>(device_word);
+  return BB_OK;
+}
 BEVBERT_API const char* bevbert_arch(void) { return "gfx950"; }
 
 int attn_simple_fwd(const AttnArgs& a, int dtype, hipStream_t st);
@@ -40,7 +47,7 @@ static int fill_common(AttnArgs& a, const void* q, const void* k, const void* v,
   a.ldq = strides[0]; a.ldk = strides[1]; a.ldv = strides[2]; a.ldo = strides[3];
   a.bsq = strides[4]; a.bsk = strides[5]; a.bsv = strides[6]; a.bso = strides[7];
   a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
-  a.drop_p = drop_p; a.drop_thr = bb_drop_threshold(drop_p); a.drop_key = bb_site_key(seed, offset);
+  a.drop_p = drop_p; a.drop_thr = bb_drop_threshold(drop_p); a.drop_key = bb_site_key(seed, offset); a.salt = bb_step_salt();
   a.Lk2 = (Lk + 1) & ~1;
   BB_REQUIRE((double)B * nh * Lq * a.Lk2 < 4294967296.0, "attention: more than 2^32 score elements per launch");
   return BB_OK;
@@ -86,7 +93,8 @@ BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, co
 }
 
 // Test hook: materialise the dropout keep-mask the kernels derive from (seed, offset + element index).
-__global__ void keep_mask_kernel(uint8_t* out, size_t n, uint32_t key, uint32_t thr) {
+__global__ void keep_mask_kernel(uint8_t* out, size_t n, uint32_t key, uint32_t thr, const uint32_t* salt) {
+  key = bb_salted(key, salt);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
     out[i] = (uint8_t)bb_keep(key, (uint32_t)i, thr);
 }
@@ -96,7 +104,7 @@ BEVBERT_API int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p,
   size_t nb = ((size_t)n + 255) / 256;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(keep_mask_kernel, dim3(nb), dim3(256), 0, stream, out, (size_t)n, bb_site_key(seed, offset),
-                     bb_drop_threshold(drop_p));
+                     bb_drop_threshold(drop_p), bb_step_salt());
   BB_CHECK_LAUNCH("dropout_keep_mask");
   return BB_OK;
 }

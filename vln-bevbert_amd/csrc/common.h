@@ -124,6 +124,14 @@ __host__ __device__ __forceinline__ uint32_t bb_drop_threshold(float p) {
   if (t <= 0.f) return 0u;
   return t >= 65535.f ? 65535u : (uint32_t)t;
 }
+// Per-step salt.  A dropout site's key is folded on the HOST from (seed, offset); both are launch arguments and would
+// be frozen into a captured hipGraph.  bevbert_set_step_salt() registers ONE device word that the host rewrites before
+// every training step (a 4-byte fill on the stream); every dropout kernel then uses hash(key ^ *salt) instead of key,
+// so a replayed graph draws fresh masks and forward / backward of one step still agree.  No salt registered: key as is.
+const uint32_t* bb_step_salt();
+__device__ __forceinline__ uint32_t bb_salted(uint32_t key, const uint32_t* __restrict__ salt) {
+  return salt ? bb_hash32(key ^ *salt) : key;
+}
 __device__ __forceinline__ uint32_t bb_pair_bits(uint32_t key, uint32_t pair_idx) { return bb_hash32(pair_idx ^ key); }
 __device__ __forceinline__ bool bb_keep_lo(uint32_t bits, uint32_t thr) { return (bits & 0xffffu) >= thr; }
 __device__ __forceinline__ bool bb_keep_hi(uint32_t bits, uint32_t thr) { return (bits >> 16) >= thr; }

@@ -27,8 +27,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      float* __restrict__ rstd_out, int rows, float eps, float drop_p,
                                                      uint32_t drop_thr, uint32_t drop_key,
                                                      const int64_t* __restrict__ ids, const T* __restrict__ word,
-                                                     const T* __restrict__ pos, const T* __restrict__ type_row, int L) {
+                                                     const T* __restrict__ pos, const T* __restrict__ type_row, int L,
+                                                     const uint32_t* __restrict__ salt) {
   constexpr int H = NV * 256;
+  if (drop_p > 0.f) drop_key = bb_salted(drop_key, salt);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -107,8 +109,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, T* __restrict__ dz_out,
                                                      T* __restrict__ dx_out, float* __restrict__ partials, int rows,
-                                                     float drop_p, uint32_t drop_thr, uint32_t drop_key) {
+                                                     float drop_p, uint32_t drop_thr, uint32_t drop_key,
+                                                     const uint32_t* __restrict__ salt) {
   constexpr int H = NV * 256;
+  if (drop_p > 0.f) drop_key = bb_salted(drop_key, salt);
   __shared__ float4 s_red[3][4][NV * 64];  // [which][wave][lane-major float4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -365,9 +369,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16_raw* __restrict__ p_bf16, const uint8_t* __restrict__ flags,
                                                     int* __restrict__ chunk_steps, size_t nchunks,
-                                                    const float* __restrict__ gscale_ptr, float lr, float beta1,
+                                                    const float* __restrict__ gscale_ptr,
+                                                    const float* __restrict__ lr_ptr, float lr, float beta1,
                                                     float beta2, float eps, float wd, float log2_beta1,
                                                     float log2_beta2) {
+  if (lr_ptr) lr = *lr_ptr;            // device-resident learning rate: a captured hipGraph replays with the current one
   const size_t chunk = blockIdx.x;
   if (chunk >= nchunks) return;
   const uint8_t f = flags[chunk];
@@ -413,7 +419,8 @@ __global__ __launch_bounds__(256) void cast_f32_kernel(const float* __restrict__
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void dropout_add_kernel(const TI* __restrict__ x, const TO* __restrict__ residual,
                                                           TO* __restrict__ y, size_t n4, float keep_scale,
-                                                          uint32_t thr, uint32_t key) {
+                                                          uint32_t thr, uint32_t key, const uint32_t* __restrict__ salt) {
+  key = bb_salted(key, salt);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 a = ld4<TI>(x + i * 4);
     const uint32_t pr = (uint32_t)(i * 2);
@@ -443,7 +450,7 @@ static int ln_fwd_dispatch(int NV, dim3 grid, hipStream_t st, const void* x, con
   case N:                                                                                                            \
     hipLaunchKernelGGL((ln_fwd_kernel<T, N, GATHER>), grid, dim3(256), 0, st, (const T*)x, bias, (const T*)residual, \
                        gamma, beta, (T*)y, (T*)z_out, mean, rstd, rows, eps, p, thr, bb_site_key(seed, offset), ids, \
-                       (const T*)word, (const T*)pos, (const T*)type_row, L);                                        \
+                       (const T*)word, (const T*)pos, (const T*)type_row, L, bb_step_salt());                        \
     break;
   switch (NV) {
     GO(1) GO(2) GO(3) GO(4) GO(6) GO(8)
@@ -543,7 +550,7 @@ BEVBERT_API int bevbert_layernorm_bwd(const void* dy, const void* z, const float
   const uint32_t thr = bb_drop_threshold(drop_p);
 #define GO(T, N)                                                                                              \
   hipLaunchKernelGGL((ln_bwd_kernel<T, N>), dim3(nb), dim3(256), 0, stream, (const T*)dy, (const T*)z, mean, \
-                     rstd, gamma, (T*)dz, (T*)dx, workspace, rows, drop_p, thr, bb_site_key(seed, offset))
+                     rstd, gamma, (T*)dz, (T*)dx, workspace, rows, drop_p, thr, bb_site_key(seed, offset), bb_step_salt())
 #define SW(T)                                                                     \
   switch (H / 256) {                                                              \
     case 1: GO(T, 1); break;                                                      \
@@ -688,13 +695,13 @@ BEVBERT_API int bevbert_grad_norm_clip(const float* grads, int64_t n, float pre_
 
 BEVBERT_API int bevbert_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                    void* params_bf16, const uint8_t* chunk_flags, int* chunk_steps, int64_t n,
-                                   const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
-                                   float weight_decay, hipStream_t stream) {
+                                   const float* grad_scale_dev, const float* lr_dev, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, hipStream_t stream) {
   BB_REQUIRE(n % 1024 == 0, "adamw_step: arena length must be a multiple of 1024 elements");
   BB_REQUIRE(chunk_steps != nullptr, "adamw_step: per-chunk step counters are required");
   const size_t nchunks = (size_t)n / 1024;
   hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq,
-                     (bf16_raw*)params_bf16, chunk_flags, chunk_steps, nchunks, grad_scale_dev, lr, beta1, beta2, eps,
+                     (bf16_raw*)params_bf16, chunk_flags, chunk_steps, nchunks, grad_scale_dev, lr_dev, lr, beta1, beta2, eps,
                      weight_decay, (float)log2((double)beta1), (float)log2((double)beta2));
   BB_CHECK_LAUNCH("adamw_step");
   return BB_OK;
@@ -728,7 +735,7 @@ BEVBERT_API int bevbert_dropout_add(const void* x, const void* residual, void* y
   const uint32_t thr = bb_drop_threshold(drop_p), key = bb_site_key(seed, offset);
 #define GO(TI, TO)                                                                                                   \
   hipLaunchKernelGGL((dropout_add_kernel<TI, TO>), dim3(nb), dim3(256), 0, stream, (const TI*)x, (const TO*)residual, \
-                     (TO*)y, (size_t)n / 4, ks, thr, key)
+                     (TO*)y, (size_t)n / 4, ks, thr, key, bb_step_salt())
   if (in_dtype == BB_F32 && out_dtype == BB_F32) GO(float, float);
   else if (in_dtype == BB_F32 && out_dtype == BB_BF16) GO(float, bf16_raw);
   else if (in_dtype == BB_BF16 && out_dtype == BB_BF16) GO(bf16_raw, bf16_raw);

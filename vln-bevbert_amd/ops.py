@@ -27,25 +27,55 @@ HEAD_DIM = 64
 
 
 # ----------------------------------------------------------------------------- runtime state
+def _hash32(x):
+    """common.h bb_hash32 ("lowbias32") on the host."""
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
 class _Runtime:
-    """Dropout stream + scratch buffers.  ``seed`` is set once per training step; ``offset`` advances by the
-    element count of every dropout site so that each site draws from a disjoint counter range."""
+    """Dropout stream + scratch buffers.
+
+    A dropout site's mask is a pure function of (seed, offset, step salt, element index).  ``seed`` is fixed for the
+    life of the process and ``offset`` advances by the element count of every dropout site, so each site draws from a
+    disjoint counter range -- both are launch ARGUMENTS and freeze into a captured hipGraph.  What changes from step to
+    step is the salt: one 32-bit word in device memory (registered with the library through bevbert_set_step_salt)
+    that ``new_step`` rewrites with a 4-byte fill on the stream; a replayed graph therefore draws fresh masks."""
+
+    SEED = 0x5EED
 
     def __init__(self):
-        self.seed = 0x5EED
+        self.seed = self.SEED
         self.offset = 0
         self.attn_impl = 0      # 0 auto, 1 exact kernels, 2 MFMA kernels
         self._ws = {}
         self._ws_ptr = {}
+        self._salt = None
 
     def next_offset(self, n):
         off = self.offset
         self.offset += int(n)
         return off
 
-    def new_step(self, seed):
-        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    def salt_word(self, step_seed):
+        step_seed = int(step_seed) & 0xFFFFFFFFFFFFFFFF
+        v = _hash32(_hash32(step_seed & 0xFFFFFFFF) ^ (step_seed >> 32))
+        return v - (1 << 32) if v >= (1 << 31) else v          # as int32 bit pattern
+
+    def new_step(self, step_seed, write_salt=True):
+        """Start the dropout stream of a step: offsets restart at 0 and the device salt becomes hash(step_seed).
+        ``write_salt=False`` only restarts the offsets (graph replay: the caller has already written the salt)."""
         self.offset = 0
+        if write_salt and torch.cuda.is_available():
+            if self._salt is None:
+                self._salt = torch.zeros(1, dtype=torch.int32, device="cuda")
+                lib.load().bevbert_set_step_salt(self._salt.data_ptr())
+            self._salt.fill_(self.salt_word(step_seed))
 
     def workspace(self, device, nfloats):
         # one scratch buffer per (device, stream): branches of the model run concurrently on separate streams
@@ -144,6 +174,7 @@ class WgradStream:
     BATCH = int(_os.environ.get("BEVBERT_WGRAD_BATCH", "6"))
     DEFER_FINALIZE = _os.environ.get("BEVBERT_DEFER_FINALIZE", "1") == "1"      # A/B knob for the split reductions
     stream = None
+    dirty = False        # work has been enqueued on the stream since the last join (ParamArena.sync)
     _keep = []
     _pending = {}        # producing stream handle -> (torch stream, [closures])
     _events = []
@@ -187,6 +218,7 @@ class WgradStream:
             ev.record(producer)
             cls.stream.wait_event(ev)
         lib.set_stream_override(cls.stream.cuda_stream)
+        cls.dirty = True
         try:
             for fn in fns:
                 fn()
@@ -242,7 +274,7 @@ _LT_UNSUPPORTED = set()
 # has ~100 problems; real batches add data-dependent row counts (masked tokens, selected cells, trajectory lengths).
 # Past this many plans new problems stay on torch's own GEMM path (the library's single heuristic pick, no timing pass)
 # so that an unbounded variety of shapes cannot turn into an unbounded number of stalls.
-_LT_PLAN_BUDGET = int(_os.environ.get("BEVBERT_LT_PLAN_BUDGET", "2048"))
+_LT_PLAN_BUDGET = int(_os.environ.get("BEVBERT_LT_PLAN_BUDGET", "8192"))
 
 
 _LT_PLANS = {}
@@ -928,28 +960,46 @@ def embed_sum_layernorm(ids, word, pos, typ, gamma, beta, eps, type_index=0):
 
 # ----------------------------------------------------------------------------- K6 segment gather
 class SegmentCSR:
-    """Host-built CSR (and its transpose) describing out[r] = sum_e w[e] * src[idx[e]]."""
+    """Host-built CSR (and its transpose) describing out[r] = sum_e w[e] * src[idx[e]].
 
-    def __init__(self, rowptr, idx, w, n_src, device):
+    ``capacity`` (entries) fixes the size of the device arrays, so that a later batch of the same shape bucket can be
+    written into the SAME buffers (``update``) -- the kernels only read the ranges the row pointers describe."""
+
+    def __init__(self, rowptr, idx, w, n_src, device, capacity=None):
+        self.n_out, self.n_src = len(rowptr) - 1, int(n_src)
+        self.capacity = int(capacity) if capacity is not None else len(idx)
+        pack, packw = self._pack(rowptr, idx, w)
+        di = torch.from_numpy(pack).to(device, non_blocking=True)
+        dw = torch.from_numpy(packw).to(device, non_blocking=True)
+        self._di, self._dw = di, dw
+        n0, n1, n2 = self.n_out + 1, self.capacity, self.n_src + 1
+        self.rowptr, self.idx = di[:n0], di[n0:n0 + n1]
+        self.t_rowptr, self.t_idx = di[n0 + n1:n0 + n1 + n2], di[n0 + n1 + n2:]
+        self.w, self.t_w = dw[:n1], dw[n1:]
+
+    def _pack(self, rowptr, idx, w):
         import numpy as np
         rowptr = np.asarray(rowptr, dtype=np.int32)
         idx = np.asarray(idx, dtype=np.int32)
         w = np.asarray(w, dtype=np.float32)
-        self.n_out, self.n_src = len(rowptr) - 1, int(n_src)
+        assert len(rowptr) == self.n_out + 1 and len(idx) <= self.capacity, "segment CSR does not fit its buffers"
         # transpose: for each src row, the (out row, weight) pairs that read it
         out_of_e = np.repeat(np.arange(self.n_out, dtype=np.int32), np.diff(rowptr))
         order = np.argsort(idx, kind="stable")
         t_rowptr = np.zeros(self.n_src + 1, dtype=np.int32)
         np.add.at(t_rowptr, idx + 1, 1)
         t_rowptr = np.cumsum(t_rowptr).astype(np.int32)
-        pack = np.concatenate([rowptr, idx, t_rowptr, out_of_e[order]]).astype(np.int32)
-        packw = np.concatenate([w, w[order]]).astype(np.float32)
-        di = torch.from_numpy(pack).to(device, non_blocking=True)
-        dw = torch.from_numpy(packw).to(device, non_blocking=True)
-        n0, n1, n2 = len(rowptr), len(idx), len(t_rowptr)
-        self.rowptr, self.idx = di[:n0], di[n0:n0 + n1]
-        self.t_rowptr, self.t_idx = di[n0 + n1:n0 + n1 + n2], di[n0 + n1 + n2:]
-        self.w, self.t_w = dw[:n1], dw[n1:]
+        pad = np.zeros(self.capacity - len(idx), dtype=np.int32)
+        padw = pad.astype(np.float32)
+        pack = np.concatenate([rowptr, idx, pad, t_rowptr, out_of_e[order], pad]).astype(np.int32)
+        packw = np.concatenate([w, padw, w[order], padw]).astype(np.float32)
+        return pack, packw
+
+    def update(self, rowptr, idx, w):
+        """Write another aggregation of the same shape (rows, sources, <= capacity entries) into the device arrays."""
+        pack, packw = self._pack(rowptr, idx, w)
+        self._di.copy_(torch.from_numpy(pack), non_blocking=True)
+        self._dw.copy_(torch.from_numpy(packw), non_blocking=True)
 
 
 class _SegmentWsum(torch.autograd.Function):

@@ -222,7 +222,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             args[18] = True          # lets the kernels skip an all-ones mask (see vilmodel._all_ones_to_none)
         return args
 
+    def loss_mean(self, batch, task):
+        """Scalar mean loss of the step (``loss.mean()`` of train_r2r.py:263).  For a static batch
+        (static_step.StaticBatch: data-dependent row counts padded to a fixed size so that the step can live in a
+        hipGraph) the padded rows carry zero weight and the mean is taken over the real rows only."""
+        return self.forward(batch, task, compute_loss="mean")
+
     def forward(self, batch, task, compute_loss=True):
+        """``compute_loss``: True / False as in the reference; "mean" (internal, see ``loss_mean``) -> scalar."""
         if not any(task.startswith(t) for t in ("mlm", "mrc", "sap", "og", "sem", "masksem")):
             raise ValueError("invalid task")
         batch = dict(batch)     # the reference works on a defaultdict COPY (pretrain_cmt.py:170): the caller's dict is untouched
@@ -261,7 +268,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             masked, targets = obj_embeds[sel], b["vp_obj_probs"][sel]
         pred = self.obj_classifier(masked).float()
         if compute_loss:
-            return F.kl_div(F.log_softmax(pred, dim=-1), targets, reduction="none").sum(dim=1)
+            loss = F.kl_div(F.log_softmax(pred, dim=-1), targets, reduction="none").sum(dim=1)
+            return loss.mean() if compute_loss == "mean" else loss
         return pred, targets
 
     def forward_og(self, b, compute_loss):
@@ -269,12 +277,27 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         _, _, obj_embeds, obj_masks = self.bert(*self._cmt_args(b), return_gmap_embeds=False, **self._host_kw(b))
         logits = self.og_head(obj_embeds).squeeze(2).float().masked_fill(obj_masks.logical_not(), -float("inf"))
         if compute_loss:
-            return F.cross_entropy(logits, b["obj_labels"], reduction="none")
+            loss = F.cross_entropy(logits, b["obj_labels"], reduction="none")
+            return loss.mean() if compute_loss == "mean" else loss
         return logits
 
     def forward_mlm(self, b, compute_loss):
         txt_embeds = self.bert.forward_mlm(*self._cmt_args(b), **self._host_kw(b))
         labels = b["txt_labels"]
+        st = b.get("_static")
+        if st is not None:
+            # loader-built positions of the masked tokens, padded to a fixed count (the padding re-reads row 0 and
+            # carries zero weight): no nonzero() sync, no host->device copy inside the step, static GEMM shapes
+            pos_in, n = st["mlm_pos"], st["mlm_n"]
+            masked = txt_embeds.reshape(-1, txt_embeds.shape[-1]).index_select(0, pos_in)
+            scores = self.mlm_head(masked).float()
+            if compute_loss == "mean":
+                per_row = F.cross_entropy(scores, st["mlm_targets"], reduction="none")
+                return (per_row * st["mlm_valid"]).sum() / st["mlm_n_dev"]     # row count of the batch in the buffers
+            scores = scores[:n]
+            if compute_loss:
+                return F.cross_entropy(scores, st["mlm_targets"][:n], reduction="none")
+            return scores
         host = b.get("txt_labels_cpu")
         if host is not None:        # host-known positions: no nonzero() sync (pretrain_cmt.py:254-256 has one)
             pos = torch.nonzero(host.reshape(-1) != -1).squeeze(1).to(labels.device, non_blocking=True)
@@ -294,7 +317,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         if pos_in is not pos:
             scores = scores[:n]
         if compute_loss:
-            return F.cross_entropy(scores, labels.reshape(-1).index_select(0, pos), reduction="none")
+            loss = F.cross_entropy(scores, labels.reshape(-1).index_select(0, pos), reduction="none")
+            return loss.mean() if compute_loss == "mean" else loss
         return scores
 
     def forward_sap(self, b, compute_loss):
@@ -318,25 +342,47 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         local_logits = self.local_sap_head(cand_embeds).squeeze(2).float() * (1 - fuse_weights)
         local_logits = local_logits.masked_fill(cand_masks.logical_not(), -float("inf"))
 
-        cand_vpids = [[None] + c[-1] for c in b["traj_cand_vpids"]]
-        src, vis_c = sap_fusion_indices(b["gmap_vpids"], _host_rows(b, "gmap_visited_masks"), cand_vpids, G,
-                                        cand_idxs.shape[1])
-        dev = global_logits.device
-        fused_logits = fuse_sap_logits(global_logits, local_logits, torch.from_numpy(src).to(dev, non_blocking=True),
-                                       torch.from_numpy(vis_c).to(dev, non_blocking=True))
+        st = b.get("_static")
+        if st is not None:          # loader-built fusion table (static_step.StaticBatch): nothing to copy inside the step
+            src_d, vis_d = st["sap_src"], st["sap_vis_c"]
+        else:
+            cand_vpids = [[None] + c[-1] for c in b["traj_cand_vpids"]]
+            src, vis_c = sap_fusion_indices(b["gmap_vpids"], _host_rows(b, "gmap_visited_masks"), cand_vpids, G,
+                                            cand_idxs.shape[1])
+            dev = global_logits.device
+            src_d = torch.from_numpy(src).to(dev, non_blocking=True)
+            vis_d = torch.from_numpy(vis_c).to(dev, non_blocking=True)
+        fused_logits = fuse_sap_logits(global_logits, local_logits, src_d, vis_d)
         if compute_loss:
-            return F.cross_entropy(global_logits, b["global_act_labels"], reduction="none") \
+            loss = F.cross_entropy(global_logits, b["global_act_labels"], reduction="none") \
                 + F.cross_entropy(local_logits, b["local_act_labels"], reduction="none") \
                 + F.cross_entropy(fused_logits, b["global_act_labels"], reduction="none")
+            return loss.mean() if compute_loss == "mean" else loss
         return global_logits, local_logits, fused_logits, b["global_act_labels"], b["local_act_labels"]
 
     def _sem_common(self, b, sel, compute_loss):
         bev_embeds = self.bert.forward_sem(*self._cmt_args(b), sem_pred_token=self.sem_pred_token, **self._host_kw(b))
+        st = b.get("_static")
+        if st is not None and compute_loss == "mean":
+            # static row selection: the supervised cells (a data-dependent count that only the device knows: it depends
+            # on which cells the splat filled) are compacted into a fixed number of rows >= the count (the loader knows
+            # an upper bound: the number of masked cells); the padding re-reads row 0 and carries zero weight
+            cap = st["sem_cap"]
+            flat = sel.reshape(-1)
+            idx = torch.nonzero_static(flat, size=cap, fill_value=0).squeeze(1)
+            count = flat.sum()
+            valid = (torch.arange(cap, device=flat.device) < count).to(torch.float32)
+            masked = bev_embeds.reshape(-1, bev_embeds.shape[-1]).index_select(0, idx)
+            sem_logits = self.local_sem_head(masked).float()
+            sem_labels = b["bev_sems"].reshape(-1, b["bev_sems"].shape[-1]).index_select(0, idx).float()
+            per = F.binary_cross_entropy_with_logits(sem_logits, sem_labels, reduction="none")
+            return (per * valid[:, None]).sum() / (count.to(torch.float32) * per.shape[1])
         masked = bev_embeds[sel]                               # data-dependent row count: one sync, as the reference
         sem_logits = self.local_sem_head(masked).float()
         sem_labels = b["bev_sems"][sel].float()
         if compute_loss:
-            return F.binary_cross_entropy_with_logits(sem_logits, sem_labels, reduction="none")
+            loss = F.binary_cross_entropy_with_logits(sem_logits, sem_labels, reduction="none")
+            return loss.mean() if compute_loss == "mean" else loss
         return sem_logits, sem_labels
 
     def forward_sem(self, b, compute_loss):

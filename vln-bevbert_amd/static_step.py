@@ -1,0 +1,177 @@
+"""Static-shape batches and hipGraph capture of the whole training step.
+
+The reference's step is ~1 000 kernel launches issued one by one from Python (pretrain_src/train_r2r.py:247-313); at
+batch 64 on an MI355X the GPU needs ~17 ms for them and the Python autograd + ctypes enqueue ~20 ms, so the step is
+host-bound.  A HIP graph replays the whole step -- lift + splat, forward, backward (weight-gradient stream forked and
+joined inside), gradient clipping, AdamW -- with one launch.  Three things make the step capturable:
+
+  * every quantity that changes from step to step lives in DEVICE memory, not in launch arguments: the dropout salt
+    (ops._Runtime / bevbert_set_step_salt) and the learning rate (ParamArena.set_lr);
+  * everything the reference builds on the host INSIDE the forward -- positions of the masked tokens, the SAP logit
+    fusion table, the global-map aggregation CSR -- is built by the loader (``StaticBatch``) next to its host->device
+    copies; data-dependent row counts (masked tokens, supervised BEV cells) are padded to a fixed size with
+    zero-weight rows, so the step has no host<->device synchronisation and fixed kernel shapes;
+  * a ``StaticBatch`` owns preallocated device buffers of one shape bucket: the loader refills them in place
+    (``load``), the graph captured on them is replayed.  Device-resident grid features
+    (feature_store.GridFeatureStore) enter as row numbers, so a refill moves kilobytes, not the 462 MB of CLIP grid
+    features the reference ships per step at batch 64.
+
+``PretrainTrainer.step(task, static_batch)`` runs such a batch eagerly twice (library plans settle, buffers warm up),
+captures the third step, and replays from then on.  Eager and replayed steps execute the same kernels with the same
+arguments: losses and parameters agree bit for bit (tests/test_gpu_zz_streams.py).
+"""
+import numpy as np
+import torch
+
+from . import ops, synthetic
+from .pretrain_cmt import sap_fusion_indices
+from .vilmodel import gmap_csr_arrays
+
+MLM_ROW_PAD = 64        # masked-token rows are padded to a multiple of this
+SEM_ROW_PAD = 128       # supervised BEV cells (MaskSEM) likewise
+GMAP_PAD = 4            # global-map width G (batch max of the node counts) is rounded up to a multiple of this
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class StaticBatch:
+    """Device buffers + loader-built index tensors of one batch of one task, in a fixed shape bucket."""
+
+    def __init__(self, cfg, task, batch, device, grid_store=None, grid_keys=None):
+        """``batch``: the collate output on the host (synthetic.collate / the reference's *_collate schema).
+        ``grid_store`` + ``grid_keys``: draw the grid features from a device-resident GridFeatureStore instead of
+        shipping ``rgbs`` / ``depths`` / ``sems`` (the keys name the samples' viewpoints)."""
+        self.cfg, self.task, self.device = cfg, task, torch.device(device)
+        self.graph = None           # set by PretrainTrainer once the step has been captured on these buffers
+        self.loss_out = None
+        self.eager_runs = 0
+        host = self._host_side(batch)
+        self.signature = host["signature"]
+        t = {}
+        src = dict(batch)
+        src.update(host["padded"])
+        for k, v in src.items():
+            if grid_store is not None and k in ("rgbs", "depths", "sems"):
+                continue
+            t[k] = v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v
+            if k in synthetic.HOST_COPIES and torch.is_tensor(v):
+                t[k + "_cpu"] = v
+        t["gmap_csr"] = (ops.SegmentCSR(*host["csr"], self.device, capacity=host["csr_capacity"]), host["G"])
+        st = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in host["static"].items()}
+        t["_static"] = st
+        if grid_store is not None:
+            grid_store.attach(t, grid_keys)
+        self.tensors = t
+        self._refresh_counts()
+
+    # -- host side: everything that is a Python loop over ids or a data-dependent count --------------------------
+    def _host_side(self, batch):
+        cfg, task = self.cfg, self.task
+        B = batch["txt_ids"].shape[0]
+        G = _round_up(int(batch["gmap_lens"].max()), GMAP_PAD)
+        padded = {}
+        for k in ("gmap_step_ids", "gmap_visited_masks", "gmap_pos_fts"):       # (B, G0, ...) -> (B, G, ...)
+            v = batch[k]
+            if v.shape[1] < G:
+                pad = v.new_zeros((B, G - v.shape[1]) + tuple(v.shape[2:]))
+                v = torch.cat([v, pad], 1)
+            padded[k] = v
+        pd = batch["gmap_pair_dists"]
+        if pd.shape[1] < G:
+            full = pd.new_zeros(B, G, G)
+            full[:, :pd.shape[1], :pd.shape[2]] = pd
+            pd = full
+        padded["gmap_pair_dists"] = pd
+        lens = batch["traj_vp_view_lens"]
+        if batch.get("traj_vp_obj_lens") is not None:
+            lens = lens + batch["traj_vp_obj_lens"]
+        n_views = batch["traj_loc_fts"].shape[1]
+        rowptr, idx, w, n_src, G = gmap_csr_arrays(list(batch["traj_step_lens"]), lens.tolist(), batch["traj_vpids"],
+                                                  batch["traj_cand_vpids"], batch["gmap_vpids"], n_views, G)
+        static = {}
+        sig = [task, B, tuple(batch["txt_ids"].shape), tuple(batch["traj_view_img_fts"].shape), G]
+        if task.startswith("mlm"):
+            labels = batch["txt_labels"].reshape(-1)
+            pos = torch.nonzero(labels != -1).squeeze(1)
+            n = int(pos.numel())
+            npad = _round_up(max(n, 1), MLM_ROW_PAD)
+            static["mlm_n"] = n
+            static["mlm_pos"] = torch.cat([pos, pos.new_zeros(npad - n)])
+            static["mlm_targets"] = torch.cat([labels[pos], labels.new_zeros(npad - n)])
+            static["mlm_valid"] = (torch.arange(npad) < n).to(torch.float32)
+            sig.append(npad)
+        elif task.startswith("sap"):
+            K = batch["bev_cand_idxs"].shape[1]
+            cand_vpids = [[None] + c[-1] for c in batch["traj_cand_vpids"]]
+            vis = padded["gmap_visited_masks"].tolist()
+            src, vis_c = sap_fusion_indices(batch["gmap_vpids"], vis, cand_vpids, G, K)
+            static["sap_src"] = torch.from_numpy(src)
+            static["sap_vis_c"] = torch.from_numpy(vis_c)
+            sig.append(K)
+        elif task.startswith("masksem"):
+            static["sem_cap"] = _round_up(max(1, int(batch["bev_mrc_masks"].sum())), SEM_ROW_PAD)
+            sig.append(static["sem_cap"])
+        elif task.startswith("sem"):
+            static["sem_cap"] = B * cfg.bev_dim * cfg.bev_dim
+        return {"padded": padded, "static": static, "csr": (rowptr, idx, w, n_src), "csr_capacity": 2 * n_src, "G": G,
+                "signature": tuple(sig)}
+
+    # -- in-place refill -----------------------------------------------------------------------------------------
+    def load(self, batch, grid_keys=None):
+        """Write another batch of the same shape bucket into these buffers (what a prefetching loader does with its
+        preallocated device buffers); a captured graph keeps replaying on them.  Raises if the bucket differs."""
+        host = self._host_side(batch)
+        if host["signature"] != self.signature:
+            raise ValueError(f"batch of shape bucket {host['signature']} does not fit the buffers of {self.signature}")
+        t = self.tensors
+        src = dict(batch)
+        src.update(host["padded"])
+        for k, v in src.items():
+            if torch.is_tensor(v):
+                if k in t and torch.is_tensor(t[k]):
+                    t[k].copy_(v, non_blocking=True)
+                if k + "_cpu" in t:
+                    t[k + "_cpu"] = v
+            elif k in t:
+                t[k] = v
+        t["gmap_csr"][0].update(*host["csr"][:3])
+        st = t["_static"]
+        for k, v in host["static"].items():
+            if torch.is_tensor(v):
+                st[k].copy_(v, non_blocking=True)
+            else:
+                st[k] = v                      # host integers (row counts): they are part of the shape bucket or a
+        if "grid_store" in t and grid_keys is not None:      # divisor the step reads from device memory (see below)
+            t["grid_rows"].copy_(t["grid_store"].rows(grid_keys), non_blocking=True)
+        self._refresh_counts()
+        return self
+
+    def _refresh_counts(self):
+        """Host-known divisors of the mean (the number of real masked-token rows) live in a device scalar, so that a
+        captured step picks up the count of the batch that currently sits in the buffers."""
+        st = self.tensors["_static"]
+        if "mlm_n" in st:
+            if "mlm_n_dev" not in st:
+                st["mlm_n_dev"] = torch.zeros((), dtype=torch.float32, device=self.device)
+            st["mlm_n_dev"].fill_(float(st["mlm_n"]))
+
+
+class GraphedStep:
+    """One captured training step bound to the buffers of a StaticBatch."""
+
+    def __init__(self, graph, loss):
+        self.graph, self.loss = graph, loss
+
+
+_POOL = {}
+
+
+def graph_pool(device):
+    """All step graphs of a process share one private memory pool: they are replayed one at a time on one stream and
+    exchange nothing through pool memory, so the pool is as large as the largest step, not the sum."""
+    key = torch.device(device).index
+    if key not in _POOL:
+        _POOL[key] = torch.cuda.graph_pool_handle()
+    return _POOL[key]

@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .static_step import GraphedStep, StaticBatch, graph_pool
 
 
 def warmup_linear_lr(step, base_lr, warmup_steps, total_steps):
@@ -105,8 +106,9 @@ class GradReducer:
             ops.WgradStream.flush_all()                              # deferred weight-gradient launches go out first
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())     # everything enqueued so far has produced `view`
-            for side in ops.Branches.side_streams():                 # ... including the model's side-stream branches
-                self.stream.wait_stream(side)
+            for side in ops.Branches.side_streams():                 # ... including side streams that carry work of
+                if ops.Branches.enabled or side is not ops.WgradStream.stream or ops.WgradStream.dirty:   # this step
+                    self.stream.wait_stream(side)
             with torch.cuda.stream(self.stream):
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -141,6 +143,8 @@ class PretrainTrainer:
         self.betas, self.wd, self.grad_norm = betas, weight_decay, grad_norm
         self.seed, self.rank, self.world = seed, rank, world_size
         self.global_step = 0
+        import os
+        self.use_graphs = os.environ.get("BEVBERT_GRAPHS", "1") == "1" and arena.device.type == "cuda"
         first_map = min(arena.slices[n][0] for n in arena.slices
                         if n.startswith("bert.local_encoder") or n.startswith("bert.global_encoder")
                         or not n.startswith("bert."))
@@ -194,25 +198,77 @@ class PretrainTrainer:
             dist.broadcast(b, src=src, group=self.reducer.group)
         a.sync_shadow()
 
+    def _step_seed(self):
+        return (self.seed + self.rank) * 1000003 + self.global_step                  # per-rank dropout stream
+
     def forward_backward(self, task, batch):
         """Forward + backward + gradient exchange of one batch; leaves the (summed) gradients in ``arena.grads``."""
         self.global_step += 1
-        ops.RT.new_step((self.seed + self.rank) * 1000003 + self.global_step)    # per-rank dropout stream
+        ops.RT.new_step(self._step_seed())
+        return self._forward_backward(task, batch)
+
+    def _forward_backward(self, task, batch):
         self.arena.zero_grad()
-        loss_vec = self.model(batch, task, compute_loss=True)
-        loss = loss_vec.mean()                                                   # train_r2r.py:263
+        if isinstance(batch, StaticBatch):
+            loss = self.model.loss_mean(batch.tensors, task)
+        else:
+            loss = self.model(batch, task, compute_loss=True).mean()                 # train_r2r.py:263
         loss.backward()
-        self.arena.sync()                      # side-stream branches have written their gradients
+        self.arena.sync()                      # side-stream work has written its gradients
         self.reducer.finish()
         return loss.detach()
 
-    def optimizer_step(self):
-        """clip_grad_norm_ + AdamW + schedule (train_r2r.py:278-313) on the flat arena."""
-        lr = warmup_linear_lr(self.global_step, self.lr, self.warmup, self.total)
+    def optimizer_step(self, lr=None):
+        """clip_grad_norm_ + AdamW + schedule (train_r2r.py:278-313) on the flat arena (lr=None: device-resident)."""
+        if lr is None:
+            lr = warmup_linear_lr(self.global_step, self.lr, self.warmup, self.total)
         self.arena.clip_and_step(lr, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
 
     def step(self, task, batch):
-        """One optimisation step on one batch (gradient_accumulation_steps == 1, as every shipped config)."""
+        """One optimisation step on one batch (gradient_accumulation_steps == 1, as every shipped config).
+
+        A ``static_step.StaticBatch`` runs eagerly ``GRAPH_WARMUP`` times, is then captured into a hipGraph (forward,
+        backward with the weight-gradient stream, clip, AdamW -- and, on several GPUs, the in-place all-reduce on its
+        side stream) and replayed from then on: one launch per step instead of ~1 000."""
+        if isinstance(batch, StaticBatch) and self.use_graphs and ops.TRACE is None:
+            return self._static_step(task, batch)
         loss = self.forward_backward(task, batch)
         self.optimizer_step()
         return loss
+
+    # ---- captured steps ----------------------------------------------------------------------------------------
+    GRAPH_WARMUP = 2
+
+    def _static_step(self, task, sb):
+        assert sb.task == task
+        self.global_step += 1
+        lr = warmup_linear_lr(self.global_step, self.lr, self.warmup, self.total)
+        a = self.arena
+        if a.exp_avg is None:                       # optimiser state exists before anything is captured
+            a.exp_avg = torch.zeros_like(a.params)
+            a.exp_avg_sq = torch.zeros_like(a.params)
+        ops.RT.new_step(self._step_seed())          # salt -> device word (a 4-byte fill on the stream)
+        a.set_lr(lr)                                # learning rate -> device word
+        gs = sb.graph
+        if gs is not None and gs.owner is self:
+            a.upload_flags()
+            gs.graph.replay()
+            return gs.loss.clone()
+        if sb.eager_runs < self.GRAPH_WARMUP:
+            sb.eager_runs += 1
+            loss = self._forward_backward(task, sb)
+            self.optimizer_step(lr=None)
+            return loss
+        # capture: flags / plans / side streams are warm, nothing below allocates outside the graph's pool
+        a.upload_flags()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, pool=graph_pool(a.device)):
+            ops.RT.new_step(0, write_salt=False)    # offsets restart; the salt word is read by the kernels at replay
+            loss = self._forward_backward(task, sb)
+            a.clip_and_step(None, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
+        gs = GraphedStep(graph, loss)
+        gs.owner = self
+        sb.graph = gs
+        graph.replay()                              # the capture recorded the step; this replay executes it
+        return loss.clone()

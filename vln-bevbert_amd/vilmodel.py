@@ -488,12 +488,12 @@ class LocalBEVEncoder(nn.Module):
         return x[:, :K], x[:, K:]
 
 
-def build_gmap_csr(traj_step_lens, view_lens_host, traj_vpids, traj_cand_vpids, gmap_vpids, n_views, device):
-    """vilmodel.py:632-666 (_aggregate_gmap_features) as a CSR over the flattened (sum_T * V) token rows.
-
-    Output row b*G + j (G = batch max incl. [stop]); [stop] and padding rows are empty segments (-> zeros)."""
+def gmap_csr_arrays(traj_step_lens, view_lens_host, traj_vpids, traj_cand_vpids, gmap_vpids, n_views, G=None):
+    """vilmodel.py:632-666 (_aggregate_gmap_features) as a CSR over the flattened (sum_T * V) token rows: returns
+    (rowptr, idx, w, n_src, G).  Output row b*G + j (G = batch max incl. [stop], or a larger padded width); [stop] and
+    padding rows are empty segments (-> zeros)."""
     B = len(traj_step_lens)
-    G = max(len(g) for g in gmap_vpids)
+    G = max(max(len(g) for g in gmap_vpids), G or 0)
     rowptr, idx, w = [0], [], []
     t0 = 0
     for i in range(B):
@@ -519,7 +519,14 @@ def build_gmap_csr(traj_step_lens, view_lens_host, traj_vpids, traj_cand_vpids, 
                     w.extend([1.0 / len(toks)] * len(toks))
             rowptr.append(len(idx))
         t0 += T
-    return ops.SegmentCSR(rowptr, idx, w, t0 * n_views, device), G
+    return rowptr, idx, w, t0 * n_views, G
+
+
+def build_gmap_csr(traj_step_lens, view_lens_host, traj_vpids, traj_cand_vpids, gmap_vpids, n_views, device, G=None,
+                   capacity=None):
+    rowptr, idx, w, n_src, G = gmap_csr_arrays(traj_step_lens, view_lens_host, traj_vpids, traj_cand_vpids, gmap_vpids,
+                                               n_views, G)
+    return ops.SegmentCSR(rowptr, idx, w, n_src, device, capacity=capacity), G
 
 
 class GlobalMapEncoder(nn.Module):
