@@ -80,12 +80,16 @@ int bevbert_bev_splat_mean(const void* feat, int feat_dtype, const int* order, c
 int bevbert_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask,
                      const float* bias, const int64_t* strides, int B, int nh, int Lq, int Lk, int head_dim,
                      float scale, int dtype, int impl, float drop_p, uint64_t seed, uint64_t offset,
-                     hipStream_t stream);
+                     uint64_t* drop_bits, hipStream_t stream);
 int bevbert_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                      float* delta_ws, void* dq, void* dk, void* dv, float* dbias, const float* key_mask,
                      const float* bias, const int64_t* strides, int B, int nh, int Lq, int Lk, int head_dim,
                      float scale, int dtype, int impl, float drop_p, uint64_t seed, uint64_t offset,
-                     hipStream_t stream);
+                     const uint64_t* drop_bits, hipStream_t stream);
+/* drop_bits (may be NULL): keep-bit matrix of the dropout mask, bevbert_attn_drop_bits_words(B, nh, Lq, Lk) 64-bit words.
+ * The bf16 forward stores the compare masks it computes anyway; the bf16 backward then reads one bit per score element
+ * instead of re-hashing (NULL: the backward regenerates the mask from (seed, offset) -- same mask, more arithmetic). */
+int64_t bevbert_attn_drop_bits_words(int B, int nh, int Lq, int Lk);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * K3  y = LayerNorm(dropout(x + bias) + residual).

@@ -40,15 +40,16 @@ def main():
             v = torch.randn(B, Lk, 768, device=dev).bfloat16().requires_grad_(True)
             km = torch.zeros(B, Lk, device=dev) if masked else None
             do = torch.randn(B, Lq, 768, device=dev).bfloat16()
-            fwd = lambda: ops._Attention.apply("sep", q, k, v, km, None, 12, p, 2)
-            t_f = timeit(lambda: fwd())
-            o = fwd()
-            t_b = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True))
-            fl = 4.0 * B * 12 * Lq * Lk * 64
-            print(json.dumps({"variant": tag, "shape": name, "B": B, "Lq": Lq, "Lk": Lk, "p": p,
-                              "fwd_us": round(t_f, 1), "bwd_us": round(t_b, 1),
-                              "fwd_tflops": round(fl / t_f / 1e6, 1), "bwd_tflops": round(2.5 * fl / t_b / 1e6, 1)}),
-                  flush=True)
+            for impl, iname in ((2, "single-pass bwd"), (3, "two-kernel bwd")):
+                fwd = lambda: ops._Attention.apply("sep", q, k, v, km, None, 12, p, impl)
+                t_f = timeit(lambda: fwd())
+                o = fwd()
+                t_b = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True))
+                fl = 4.0 * B * 12 * Lq * Lk * 64
+                print(json.dumps({"variant": tag, "impl": iname, "shape": name, "B": B, "Lq": Lq, "Lk": Lk, "p": p,
+                                  "fwd_us": round(t_f, 1), "bwd_us": round(t_b, 1),
+                                  "fwd_tflops": round(fl / t_f / 1e6, 1),
+                                  "bwd_tflops": round(2.5 * fl / t_b / 1e6, 1)}), flush=True)
 
 
 if __name__ == "__main__":

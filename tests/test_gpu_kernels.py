@@ -157,7 +157,7 @@ def test_layernorm_fwd_bwd(ops, dtype, with_res, p):
     xin = x.clone().requires_grad_(True)
     rin = res.clone().requires_grad_(True) if with_res else None
     y = ops.bias_dropout_residual_layernorm(xin, bias, rin, gam, bet, 1e-12, p, training=True, inplace_z=False)
-    keep = ops.dropout_keep_mask(rows * H, p, 1234, 0, DEV).view(rows, H) if p > 0 else None
+    keep = ops.dropout_keep_mask(rows * H, p, ops.RT.seed, 0, DEV).view(rows, H) if p > 0 else None
     if keep is not None:
         assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
     bias_r, gam_r, bet_r = (t.detach().clone().requires_grad_(True) for t in (bias, gam, bet))
@@ -305,8 +305,10 @@ def _make_attn_inputs(B, Lq, Lk, mask_kind, with_bias, dtype, seed=0):
 
 
 @pytest.mark.parametrize("case", ATTN_CASES)
-@pytest.mark.parametrize("impl,dtype", [(1, torch.float32), (2, torch.bfloat16), (1, torch.bfloat16)])
+@pytest.mark.parametrize("impl,dtype", [(1, torch.float32), (2, torch.bfloat16), (3, torch.bfloat16), (1, torch.bfloat16)])
 def test_attention_fwd_bwd(ops, case, impl, dtype):
+    """impl 1 = exact fp32-arithmetic kernels, 2 = MFMA (single-pass backward where it applies), 3 = MFMA with the
+    two-kernel backward (the path of key sequences beyond 448)."""
     B, Lq, Lk, mk, wb = case
     q, k, v, km, bias, nh = _make_attn_inputs(B, Lq, Lk, mk, wb, dtype)
     qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
@@ -329,8 +331,8 @@ def test_attention_fwd_bwd(ops, case, impl, dtype):
         assert rel_err(bi.grad, br.grad) < gt, "dbias"
 
 
-@pytest.mark.parametrize("Lk", [140, 441])
-@pytest.mark.parametrize("impl,dtype", [(1, torch.float32), (2, torch.bfloat16)])
+@pytest.mark.parametrize("Lk", [140, 441, 36])
+@pytest.mark.parametrize("impl,dtype", [(1, torch.float32), (2, torch.bfloat16), (3, torch.bfloat16)])
 def test_attention_dropout_matches_exported_mask(ops, impl, dtype, Lk):
     B, Lq, p = 2, 100, 0.1
     q, k, v, km, _, nh = _make_attn_inputs(B, Lq, Lk, "neg", False, dtype, seed=5)
@@ -338,7 +340,7 @@ def test_attention_dropout_matches_exported_mask(ops, impl, dtype, Lk):
     qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
     o = ops._Attention.apply("sep", qi, ki, vi, km, None, nh, p, impl)
     Lk2 = (Lk + 1) // 2 * 2            # the kernels index dropout elements with the key count rounded up to even
-    keep = ops.dropout_keep_mask(B * nh * Lq * Lk2, p, 99, 0, DEV).view(B, nh, Lq, Lk2)[..., :Lk]
+    keep = ops.dropout_keep_mask(B * nh * Lq * Lk2, p, ops.RT.seed, 0, DEV).view(B, nh, Lq, Lk2)[..., :Lk]
     assert abs(float(keep.float().mean()) - 0.9) < 0.01
     qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
     orf = _attn_ref(qr, kr, vr, km, None, nh, keep, p)
@@ -349,6 +351,30 @@ def test_attention_dropout_matches_exported_mask(ops, impl, dtype, Lk):
     orf.backward(do.float())
     gt = 1e-3 if dtype == torch.float32 else 3e-2
     assert rel_err(qi.grad, qr.grad) < gt and rel_err(ki.grad, kr.grad) < gt and rel_err(vi.grad, vr.grad) < gt
+
+
+@pytest.mark.parametrize("B,Lq,Lk,mk,wb,p", [(3, 441, 441, None, False, 0.1), (2, 441, 80, "neg", False, 0.1),
+                                            (3, 17, 17, "neg", True, 0.1), (2, 80, 441, None, False, 0.0),
+                                            (2, 65, 129, "neg", False, 0.1), (2, 200, 448, "neg", False, 0.1)])
+def test_attention_single_pass_backward_equals_two_kernel_backward(ops, B, Lq, Lk, mk, wb, p):
+    """attn_bwd1.hip (one workgroup per (batch, head), dQ without atomics, keep bits from the forward) against the
+    two-kernel backward on the same forward, dropout ON: the same mask, the same softmax statistics -> gradients agree
+    to bf16 rounding of dS / P (both pack them to bf16 for the second contraction)."""
+    q, k, v, km, bias, nh = _make_attn_inputs(B, Lq, Lk, mk, wb, torch.bfloat16, seed=11)
+    do = torch.randn(B, Lq, 768, device=DEV).bfloat16()
+    grads = {}
+    for impl in (2, 3):
+        ops.RT.new_step(4321)
+        qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
+        bi = bias.clone().requires_grad_(True) if wb else None
+        o = ops._Attention.apply("sep", qi, ki, vi, km, bi, nh, p, impl)
+        o.backward(do)
+        grads[impl] = (o.detach().float(), qi.grad.float(), ki.grad.float(), vi.grad.float(),
+                       bi.grad if wb else torch.zeros(1, device=DEV))
+    assert torch.equal(grads[2][0], grads[3][0])                  # one forward kernel
+    for name, a, b_ in zip(("dq", "dk", "dv", "dbias"), grads[2][1:], grads[3][1:]):
+        assert bool(torch.isfinite(a).all()), name
+        assert rel_err(a, b_) < 1e-2, (name, rel_err(a, b_))
 
 
 def test_attention_packed_layouts(ops):
@@ -488,7 +514,7 @@ def test_dropout_add_matches_exported_mask(ops, in_dtype, out_dtype, with_res):
     ops.RT.new_step(1234)
     ops.RT.offset = 4096
     y = ops.dropout(x, p, True, residual=res, out_dtype=out_dtype)
-    keep = ops.dropout_keep_mask(x.numel(), p, 1234, 4096, DEV).view_as(x).float()
+    keep = ops.dropout_keep_mask(x.numel(), p, ops.RT.seed, 4096, DEV).view_as(x).float()
     assert 0.88 < float(keep.mean()) < 0.92
     ref = x.detach().float() * keep / (1 - p)
     if with_res:

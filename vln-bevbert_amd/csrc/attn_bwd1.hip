@@ -1,0 +1,324 @@
+// K2 backward in ONE pass (bf16 in / fp32 accumulate): dQ, dK, dV of a whole (batch, head) from one workgroup.
+//
+// The two-kernel backward (attn_mfma.hip) recomputes S, P, the dropout mask and dP twice -- once per kernel -- and reads
+// Q, K, V, dO twice: 7 tile GEMMs and ~2x the softmax arithmetic for 5 GEMMs' worth of algorithmic work, on kernels that
+// are VALU-bound.  Here a workgroup owns ALL keys of one (batch, head) (Lk <= 64 * KT <= 448: the 21x21 BEV has 441 cells):
+//
+//   * 4 waves, one per SIMD; wave w owns the 16*KT keys [w*16*KT, (w+1)*16*KT): its V fragments (B operand of dP) and
+//     its dK^T / dV^T accumulators [64 d][16*KT keys] stay in registers for the whole kernel (KT = 7: 56 + 224 VGPR/AGPR);
+//   * K is staged once, row-major, in LDS: B operand of S = Q K^T by plain 16-byte reads, and -- through the
+//     transposing LDS read of gfx950 (ds_read_b64_tr_b16) -- the K^T A operand of dQ^T = K^T dS^T from the SAME image;
+//   * loop over 64-query tiles: S and dP on the matrix cores, then ONE pass of softmax-backward arithmetic per score
+//     element (p, dropout from the forward's keep-bit matrix, dS), dK^T += Q^T dS and dV^T += dO^T P with the D->B
+//     register hand-over of the two-kernel path (P / dS never leave their lanes); Q^T / dO^T A operands come out of
+//     the row-major Q / dO tiles by transposing reads -- no transposed images are ever stored;
+//   * dS (bf16) additionally goes to a shared [key][query] LDS image; after a barrier wave w computes
+//     dQ^T[16 w .. 16 w + 15][64 queries] over ALL keys (A = K^T, B = dS^T, both by transposing reads) and stores it:
+//     dQ needs no atomics, no partial buffers and no second kernel, every operand is read from HBM exactly once;
+//   * delta = rowsum(dO * O) is computed while the Q / dO tile is staged.
+//
+// Work per score element: 5 contractions x 64 MACs on MFMA and ~10 VALU instructions (two-kernel path: 7 and ~60).
+#include "attn_mfma_common.h"
+
+#define B1_LDS_DS 68     // row stride (bf16) of the dS image: 64 queries + 4 (rows stay 8-byte aligned for the tr reads)
+
+// dynamic LDS carve (bytes); NK = 64 * KT keys
+template <int KT> struct B1Lds {
+  static constexpr int NK = 64 * KT;
+  static constexpr int q_off = 0;                                  // [64][LDT] bf16   Q tile (row-major)
+  static constexpr int do_off = q_off + TK * LDT * 2;              // [64][LDT] bf16   dO tile
+  static constexpr int k_off = do_off + TK * LDT * 2;              // [NK][LDT] bf16   K (row-major), whole kernel
+  static constexpr int ds_off = k_off + NK * LDT * 2;              // [NK][B1_LDS_DS]  dS of the current query tile
+  static constexpr int bits_off = ds_off + NK * B1_LDS_DS * 2;     // [4][KT][16] u64  keep bits of the current query tile
+  static constexpr int stat_off = bits_off + 4 * KT * 16 * 8;      // [2][64] float    lse (log2 domain), delta
+  static constexpr int bytes = stat_off + 2 * TK * 4;
+};
+
+template <int KT, bool BIAS, bool DROP>
+__global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd1_kernel(AttnArgs a) {
+  typedef B1Lds<KT> L;
+  extern __shared__ __attribute__((aligned(16))) unsigned char b1_smem[];
+  bf16_raw* const s_q = reinterpret_cast<bf16_raw*>(b1_smem + L::q_off);
+  bf16_raw* const s_do = reinterpret_cast<bf16_raw*>(b1_smem + L::do_off);
+  bf16_raw* const s_k = reinterpret_cast<bf16_raw*>(b1_smem + L::k_off);
+  bf16_raw* const s_ds = reinterpret_cast<bf16_raw*>(b1_smem + L::ds_off);
+  uint2* const s_bits = reinterpret_cast<uint2*>(b1_smem + L::bits_off);
+  float* const s_lse2 = reinterpret_cast<float*>(b1_smem + L::stat_off);
+  float* const s_dlt = s_lse2 + TK;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int bh = blockIdx.x, b = bh / a.nh, h = bh - b * a.nh;
+  const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
+  const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
+  const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
+  const bf16_raw* op = (const bf16_raw*)a.o + (size_t)b * a.bso + h * ATTN_D;
+  const bf16_raw* dop = (const bf16_raw*)a.dout + (size_t)b * a.bso + h * ATTN_D;
+  const float sc2 = a.scale * LOG2E;
+  constexpr bool use_bits = DROP;          // with dropout the launcher requires the forward's keep-bit matrix
+  const bool bits_hi = (c >> 2) >= 2;      // this lane's bits sit at 16 (c >> 2) + 4 g + r of its 64-bit words
+  const int bits_sh = (16 * (c >> 2) + 4 * g) & 31;
+  const int ks_bits = __float_as_int(a.keep_scale);
+
+  // ---- per-wave key state: V fragments, additive key mask (log2 domain; -inf beyond Lk), accumulators
+  const int key0 = w * (16 * KT);                  // first key of this wave
+  bf16x8 vf[KT][2];
+  float mask2[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int key = key0 + kt * 16 + c;
+    const int r = key < a.Lk ? key : a.Lk - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) vf[kt][ks] = as_bf16x8(ld_frag_global(vp, a.ldv, r, ks * 32 + g * 8));
+    mask2[kt] = key < a.Lk ? (a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * LOG2E : 0.f) : -INFINITY;
+  }
+  f32x4 dkacc[KT][4], dvacc[KT][4];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dkacc[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dvacc[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+  // ---- K -> LDS (row-major, zero rows beyond Lk), once
+  for (int c16 = tid; c16 < L::NK * 8; c16 += 256) {
+    const int row = c16 >> 3, ch = c16 & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < a.Lk) v = ld_frag_global(kp, a.ldk, row, ch * 8);
+    *reinterpret_cast<uint4*>(s_k + row * LDT + ch * 8) = v;
+  }
+
+  // ---- staging of one 64-query tile: Q, dO rows -> LDS; delta = rowsum(dO * O); lse; keep bits
+  // thread t owns 16-byte chunks ch = t and t + 256: row ch >> 3, dims 8 (ch & 7) .. +7; a row is covered by 8 lanes
+  TileRegs qreg, doreg, oreg;
+  float lreg = 0.f;
+  uint2 breg[2];
+  auto tile_issue = [&](int q0) {
+    tile_load(qreg, qp, a.ldq, q0, a.Lq, tid);
+    tile_load(doreg, dop, a.ldo, q0, a.Lq, tid);
+    tile_load(oreg, op, a.ldo, q0, a.Lq, tid);
+    lreg = INFINITY;                            // padding rows: p = exp2(-inf) = 0
+    if (tid < TK && q0 + tid < a.Lq) lreg = a.lse[((size_t)b * a.nh + h) * a.Lq + q0 + tid] * LOG2E;
+    if (use_bits) {                             // words of (4 query-16-tiles) x (nk64 key tiles) x 16, 8 bytes each
+      const int per_q16 = a.nk64 * 16;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int wi = tid + i * 256, q16l = wi / per_q16, rest = wi - q16l * per_q16;
+        breg[i] = make_uint2(0u, 0u);
+        if (q16l < 4 && (q0 >> 4) + q16l < a.nq16)
+          breg[i] = *reinterpret_cast<const uint2*>(a.drop_bits + ((size_t)bh * a.nq16 + (q0 >> 4) + q16l) * per_q16 + rest);
+      }
+    }
+  };
+  auto tile_commit = [&]() {
+    tile_store_rows(s_q, qreg, tid);
+    tile_store_rows(s_do, doreg, tid);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t dw[4] = {doreg.v[i].x, doreg.v[i].y, doreg.v[i].z, doreg.v[i].w};
+      const uint32_t ow[4] = {oreg.v[i].x, oreg.v[i].y, oreg.v[i].z, oreg.v[i].w};
+      float dsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        dsum += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16) +
+                __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+      dsum += __shfl_xor(dsum, 1, 64);
+      dsum += __shfl_xor(dsum, 2, 64);
+      dsum += __shfl_xor(dsum, 4, 64);
+      if ((tid & 7) == 0) s_dlt[(tid + i * 256) >> 3] = dsum;
+    }
+    if (tid < TK) s_lse2[tid] = lreg;
+    if (use_bits) {
+      const int per_q16 = a.nk64 * 16;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int wi = tid + i * 256, q16l = wi / per_q16, rest = wi - q16l * per_q16;
+        if (q16l < 4) s_bits[q16l * (KT * 16) + rest] = breg[i];
+      }
+    }
+  };
+  tile_issue(0);
+  tile_commit();
+  __syncthreads();
+
+  for (int q0 = 0; q0 < a.Lq; q0 += TK) {
+    // ================= phase 1: S, dP, softmax backward, dK^T / dV^T, dS -> LDS =================
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {       // halves of 32 queries: query tiles t = 2m, 2m + 1
+      bf16x8 qa[2][2], da[2][2], qtf[4], dotf[4];
+      float lv[2][4], ndl[2][4];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * m + tt;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          qa[tt][ks] = lds_frag_rows(s_q, t, ks, lane);
+          da[tt][ks] = lds_frag_rows(s_do, t, ks, lane);
+        }
+        const float4 l4 = *reinterpret_cast<const float4*>(&s_lse2[t * 16 + g * 4]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&s_dlt[t * 16 + g * 4]);
+        lv[tt][0] = l4.x; lv[tt][1] = l4.y; lv[tt][2] = l4.z; lv[tt][3] = l4.w;
+        ndl[tt][0] = -d4.x; ndl[tt][1] = -d4.y; ndl[tt][2] = -d4.z; ndl[tt][3] = -d4.w;
+      }
+      // A operands of the two "contract over queries" products: rows d, k-slots (g, j) <-> query 32 m + 16 (j >> 2) + 4 g + (j & 3)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        qtf[dt] = lds_frag_tr(s_q, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane);
+        dotf[dt] = lds_frag_tr(s_do, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane);
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int ktg = w * KT + kt;                 // 16-key tile index within the (batch, head)
+        f32x4 sacc[2], dpacc[2];
+        const bf16x8 kf0 = lds_frag_rows(s_k, ktg, 0, lane), kf1 = lds_frag_rows(s_k, ktg, 1, lane);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          sacc[tt] = mfma16(qa[tt][0], kf0, (f32x4){0.f, 0.f, 0.f, 0.f});
+          sacc[tt] = mfma16(qa[tt][1], kf1, sacc[tt]);
+          dpacc[tt] = mfma16(da[tt][0], vf[kt][0], (f32x4){0.f, 0.f, 0.f, 0.f});
+          dpacc[tt] = mfma16(da[tt][1], vf[kt][1], dpacc[tt]);
+        }
+        // lane (key = key0 + 16 kt + c) holds S[q = q0 + 16 t + 4 g + r][key], r = 0..3
+        const float mk = mask2[kt];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * m + tt;
+          uint32_t nib = 0xfu;
+          if (DROP) {
+            // keep bits of the forward: word (q16 = t, k64 = ktg >> 2, t' = ktg & 3, r' = c & 3), bits 16 (c >> 2) + 4 g + r
+            const uint2 wd = s_bits[((t * KT + (ktg >> 2)) * 4 + (ktg & 3)) * 4 + (c & 3)];
+            nib = (bits_hi ? wd.y : wd.x) >> bits_sh;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sv = sacc[tt][r] * sc2 + mk;
+            if (BIAS) {
+              const int qi = q0 + t * 16 + g * 4 + r, key = key0 + kt * 16 + c;
+              if (qi < a.Lq && key < a.Lk) sv += a.bias[((size_t)b * a.Lq + qi) * a.Lk + key] * LOG2E;
+            }
+            const float p = fast_exp2(sv - lv[tt][r]);
+            float u, pd = p;
+            if (DROP) {     // keep: u = dp / (1 - p_drop) - delta, pd = p;  dropped: u = -delta, pd = 0  (1/(1-p) of pd: epilogue)
+              const int msk = __builtin_amdgcn_sbfe(nib, r, 1);                // all ones / zero from keep bit r
+              const float ksm = __int_as_float(ks_bits & msk);                 // 1 / (1 - p_drop) or 0
+              u = __builtin_fmaf(dpacc[tt][r], ksm, ndl[tt][r]);
+              pd = __int_as_float(__float_as_int(p) & msk);
+            } else {
+              u = dpacc[tt][r] + ndl[tt][r];
+            }
+            const float ds = p * u;
+            sacc[tt][r] = ds;
+            dpacc[tt][r] = pd;
+            if (BIAS) {
+              const int qi = q0 + t * 16 + g * 4 + r, key = key0 + kt * 16 + c;
+              if (a.dbias && qi < a.Lq && key < a.Lk) atomicAdd(a.dbias + ((size_t)b * a.Lq + qi) * a.Lk + key, ds);
+            }
+          }
+        }
+        const bf16x8 dsb = pack_pair(sacc[0], sacc[1]), pdb = pack_pair(dpacc[0], dpacc[1]);
+        {   // dS image [key][query]: this lane's 4 consecutive queries of tile t at row key  (2 x 8 bytes)
+          const uint4 dsu = __builtin_bit_cast(uint4, dsb);
+          bf16_raw* row = s_ds + (key0 + kt * 16 + c) * B1_LDS_DS + 32 * m + 4 * g;
+          *reinterpret_cast<uint2*>(row) = make_uint2(dsu.x, dsu.y);
+          *reinterpret_cast<uint2*>(row + 16) = make_uint2(dsu.z, dsu.w);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dkacc[kt][dt] = mfma16(qtf[dt], dsb, dkacc[kt][dt]);
+          dvacc[kt][dt] = mfma16(dotf[dt], pdb, dvacc[kt][dt]);
+        }
+      }
+    }
+    __syncthreads();   // dS image complete; nobody reads s_q / s_do / stats / bits of this tile any more
+
+    // ================= phase 2: next tile's loads in flight, dQ^T = K^T dS^T for d rows 16 w .. 16 w + 15 =================
+    const bool more = q0 + TK < a.Lq;
+    if (more) tile_issue(q0 + TK);
+    f32x4 dqacc[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) dqacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int ks = 0; ks < 2 * KT; ++ks) {         // k-steps of 32 keys
+      const bf16x8 ka = lds_frag_tr(s_k, LDT, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * w, lane);
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        const bf16x8 dsf = lds_frag_tr(s_ds, B1_LDS_DS, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * qt, lane);
+        dqacc[qt] = mfma16(ka, dsf, dqacc[qt]);
+      }
+    }
+    // lane (query = q0 + 16 qt + c) holds dQ^T[d = 16 w + 4 g + r][query]
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const int qi = q0 + qt * 16 + c;
+      if (qi < a.Lq) {
+        bf16_raw* dqp = (bf16_raw*)a.dq + (size_t)b * a.bsq + (size_t)qi * a.ldq + h * ATTN_D + 16 * w + 4 * g;
+        st4<bf16_raw>(dqp, make_float4(dqacc[qt][0] * a.scale, dqacc[qt][1] * a.scale, dqacc[qt][2] * a.scale,
+                                       dqacc[qt][3] * a.scale));
+      }
+    }
+    if (more) tile_commit();
+    __syncthreads();   // next tile staged; dS image free again
+  }
+
+  // ---- epilogue: dK = scale * dK^T, dV = dV^T / (1 - p_drop)
+  const float vs = DROP ? a.keep_scale : 1.0f;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int key = key0 + kt * 16 + c;
+    if (key < a.Lk) {
+      bf16_raw* dkp = (bf16_raw*)a.dk + (size_t)b * a.bsk + (size_t)key * a.ldk + h * ATTN_D;
+      bf16_raw* dvp = (bf16_raw*)a.dv + (size_t)b * a.bsv + (size_t)key * a.ldv + h * ATTN_D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        st4<bf16_raw>(dkp + dt * 16 + g * 4,
+                      make_float4(dkacc[kt][dt][0] * a.scale, dkacc[kt][dt][1] * a.scale, dkacc[kt][dt][2] * a.scale,
+                                  dkacc[kt][dt][3] * a.scale));
+        st4<bf16_raw>(dvp + dt * 16 + g * 4, make_float4(dvacc[kt][dt][0] * vs, dvacc[kt][dt][1] * vs,
+                                                         dvacc[kt][dt][2] * vs, dvacc[kt][dt][3] * vs));
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// launcher
+// =============================================================================================
+template <int KT, bool B_, bool D_>
+static int launch_bwd1(const AttnArgs& a, hipStream_t st) {
+  typedef B1Lds<KT> L;
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd1_kernel<KT, B_, D_>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes) == hipSuccess;
+  BB_REQUIRE(ok, "attention bwd (single pass): cannot raise the dynamic LDS limit to %d bytes", L::bytes);
+  hipLaunchKernelGGL((attn_mfma_bwd1_kernel<KT, B_, D_>), dim3((unsigned)a.B * a.nh), dim3(256), L::bytes, st, a);
+  BB_CHECK_LAUNCH("attn_bwd(single pass)");
+  return BB_OK;
+}
+
+template <int KT>
+static int dispatch_bwd1(const AttnArgs& a, hipStream_t st) {
+  const bool hb = a.bias != nullptr, hd = a.drop_p > 0.f;
+  if constexpr (KT <= 2) {      // the additive graph bias only occurs on the global map (a few dozen nodes)
+    if (hb && hd) return launch_bwd1<KT, true, true>(a, st);
+    if (hb) return launch_bwd1<KT, true, false>(a, st);
+  }
+  if (hd) return launch_bwd1<KT, false, true>(a, st);
+  return launch_bwd1<KT, false, false>(a, st);
+}
+
+// The single-pass kernel covers Lk <= 448 (a bias: Lk <= 128) and, with dropout, needs the forward's keep-bit matrix;
+// everything else stays on the two-kernel path (attn_mfma.hip).
+bool attn_mfma_bwd1_supported(const AttnArgs& a) {
+  return a.Lk <= (a.bias ? 128 : 448) && (a.drop_p <= 0.f || a.drop_bits != nullptr);
+}
+
+int attn_mfma_bwd1(const AttnArgs& a, hipStream_t st) {
+  BB_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0 && a.bsq % 8 == 0 && a.bsk % 8 == 0 &&
+                 a.bsv % 8 == 0 && a.bso % 8 == 0 && ((uintptr_t)a.q % 16) == 0 && ((uintptr_t)a.k % 16) == 0 &&
+                 ((uintptr_t)a.v % 16) == 0 && ((uintptr_t)a.o % 16) == 0 && ((uintptr_t)a.dout % 16) == 0 &&
+                 ((uintptr_t)a.dq % 16) == 0 && ((uintptr_t)a.dk % 16) == 0 && ((uintptr_t)a.dv % 16) == 0,
+             "attention bwd (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
+  if (a.Lk <= 64) return dispatch_bwd1<1>(a, st);
+  if (a.Lk <= 128) return dispatch_bwd1<2>(a, st);
+  if (a.Lk <= 256) return dispatch_bwd1<4>(a, st);
+  return dispatch_bwd1<7>(a, st);
+}

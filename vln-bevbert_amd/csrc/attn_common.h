@@ -25,11 +25,18 @@ struct AttnArgs {
   int B, nh, Lq, Lk;
   float scale;
   float drop_p;
+  float keep_scale;    // 1 / (1 - drop_p)
   uint32_t drop_thr;   // 16-bit threshold
   uint32_t drop_key;   // bb_site_key(seed, offset); kernels use bb_salted(drop_key, salt)
   const uint32_t* salt; // per-step salt word in device memory (bevbert_set_step_salt) or null
   int nblk;            // workgroups per (batch, head) along the tiled sequence axis (set by the launcher)
   int Lk2;             // Lk rounded up to even: dropout element index = ((b*nh + h)*Lq + q)*Lk2 + k
+  // Keep-bit matrix of the dropout mask (MFMA path, optional).  The forward kernel has every keep decision in a wave-
+  // wide compare mask anyway: it stores those masks (one 64-bit word per 16 queries x 4 keys), and the backward kernels
+  // read one bit per score element instead of hashing again.  Word / bit of element (q, k) of batch-head bh:
+  //   word = ((((bh * nq16 + (q >> 4)) * nk64 + (k >> 6)) * 4 + ((k >> 4) & 3)) * 4 + (k & 3)),  bit = 16 * ((k >> 2) & 3) + (q & 15)
+  uint64_t* drop_bits; // B * nh * nq16 * nk64 * 16 words, or null (backward then regenerates the mask from the hash)
+  int nq16, nk64;      // nq16 = 8 * ceil(Lq / 128), nk64 = ceil(Lk / 64)
   // backward only
   const void* dout;        // (B, Lq, nh*64), strides ldo/bso
   const float* delta;      // (B, nh, Lq) rowsum(dO * O)
@@ -48,6 +55,10 @@ __device__ __forceinline__ void attn_decode_block(const AttnArgs& a, int& blk, i
   const int t = w / a.nblk;
   h = t % a.nh;
   b = t / a.nh;
+}
+
+__device__ __forceinline__ size_t attn_bits_word(const AttnArgs& a, int bh, int q16, int k64, int t, int r) {
+  return ((((size_t)bh * a.nq16 + q16) * a.nk64 + k64) * 4 + t) * 4 + r;
 }
 
 __device__ __forceinline__ uint32_t attn_row_base(const AttnArgs& a, int b, int h, int q) {

@@ -29,8 +29,11 @@ int attn_simple_bwd(const AttnArgs& a, int dtype, hipStream_t st);
 int attn_delta(const AttnArgs& a, float* delta, int dtype, hipStream_t st);
 int attn_mfma_fwd(const AttnArgs& a, hipStream_t st);
 int attn_mfma_bwd(const AttnArgs& a, hipStream_t st);
+int attn_mfma_bwd1(const AttnArgs& a, hipStream_t st);
+bool attn_mfma_bwd1_supported(const AttnArgs& a);
 
-// impl: 0 = auto (bf16 -> MFMA, f32 -> exact), 1 = force exact kernels, 2 = force MFMA (bf16 only)
+// impl: 0 = auto (bf16 -> MFMA, f32 -> exact), 1 = force exact kernels, 2 = force MFMA (bf16 only),
+//       3 = MFMA with the two-kernel backward even where the single-pass backward applies (tests, A/B measurements)
 static int pick_impl(int dtype, int impl) {
   if (impl == 0) return dtype == BB_BF16 ? 2 : 1;
   return impl;
@@ -47,8 +50,10 @@ static int fill_common(AttnArgs& a, const void* q, const void* k, const void* v,
   a.ldq = strides[0]; a.ldk = strides[1]; a.ldv = strides[2]; a.ldo = strides[3];
   a.bsq = strides[4]; a.bsk = strides[5]; a.bsv = strides[6]; a.bso = strides[7];
   a.B = B; a.nh = nh; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
-  a.drop_p = drop_p; a.drop_thr = bb_drop_threshold(drop_p); a.drop_key = bb_site_key(seed, offset); a.salt = bb_step_salt();
+  a.drop_p = drop_p; a.keep_scale = 1.0f / (1.0f - drop_p); a.drop_thr = bb_drop_threshold(drop_p); a.drop_key = bb_site_key(seed, offset); a.salt = bb_step_salt();
   a.Lk2 = (Lk + 1) & ~1;
+  a.nq16 = (Lq + 127) / 128 * 8;
+  a.nk64 = (Lk + 63) / 64;
   BB_REQUIRE((double)B * nh * Lq * a.Lk2 < 4294967296.0, "attention: more than 2^32 score elements per launch");
   return BB_OK;
 }
@@ -56,14 +61,14 @@ static int fill_common(AttnArgs& a, const void* q, const void* k, const void* v,
 BEVBERT_API int bevbert_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                                  const float* key_mask, const float* bias, const int64_t* strides, int B, int nh,
                                  int Lq, int Lk, int head_dim, float scale, int dtype, int impl, float drop_p,
-                                 uint64_t seed, uint64_t offset, hipStream_t stream) {
+                                 uint64_t seed, uint64_t offset, uint64_t* drop_bits, hipStream_t stream) {
   AttnArgs a;
   int rc = fill_common(a, q, k, v, key_mask, bias, strides, B, nh, Lq, Lk, head_dim, scale, drop_p, seed, offset);
   if (rc != BB_OK) return rc;
-  a.o = o; a.lse = lse;
+  a.o = o; a.lse = lse; a.drop_bits = drop_bits;
   BB_REQUIRE(dtype == BB_F32 || dtype == BB_BF16, "attn_fwd: dtype %d unsupported", dtype);
   const int im = pick_impl(dtype, impl);
-  if (im == 2) {
+  if (im == 2 || im == 3) {
     BB_REQUIRE(dtype == BB_BF16, "attn_fwd: the MFMA path takes bf16 tensors");
     return attn_mfma_fwd(a, stream);
   }
@@ -74,17 +79,22 @@ BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, co
                                  const float* lse, float* delta_ws, void* dq, void* dk, void* dv, float* dbias,
                                  const float* key_mask, const float* bias, const int64_t* strides, int B, int nh,
                                  int Lq, int Lk, int head_dim, float scale, int dtype, int impl, float drop_p,
-                                 uint64_t seed, uint64_t offset, hipStream_t stream) {
+                                 uint64_t seed, uint64_t offset, const uint64_t* drop_bits, hipStream_t stream) {
   AttnArgs a;
   int rc = fill_common(a, q, k, v, key_mask, bias, strides, B, nh, Lq, Lk, head_dim, scale, drop_p, seed, offset);
   if (rc != BB_OK) return rc;
+  a.drop_bits = const_cast<uint64_t*>(drop_bits);
   BB_REQUIRE(dtype == BB_F32 || dtype == BB_BF16, "attn_bwd: dtype %d unsupported", dtype);
   BB_REQUIRE(lse != nullptr && delta_ws != nullptr, "attn_bwd: lse and the (B,nh,Lq) delta workspace are required");
   a.o = const_cast<void*>(o); a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta_ws;
   a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
   const int im = pick_impl(dtype, impl);
-  if (im == 2) {   // the MFMA dQ kernel computes delta itself (and publishes it for the dK/dV kernel)
+  if (im == 2 || im == 3) {   // the MFMA dQ kernel computes delta itself (and publishes it for the dK/dV kernel)
     BB_REQUIRE(dtype == BB_BF16, "attn_bwd: the MFMA path takes bf16 tensors");
+    // one pass over the scores when all keys of a (batch, head) fit one workgroup (attn_bwd1.hip); BEVBERT_ATTN_BWD=split
+    // forces the two-kernel path (A/B measurements)
+    static const bool split = [] { const char* v = getenv("BEVBERT_ATTN_BWD"); return v && v[0] == 's'; }();
+    if (!split && im == 2 && attn_mfma_bwd1_supported(a)) return attn_mfma_bwd1(a, stream);
     return attn_mfma_bwd(a, stream);
   }
   rc = attn_delta(a, delta_ws, dtype, stream);
@@ -98,6 +108,11 @@ __global__ void keep_mask_kernel(uint8_t* out, size_t n, uint32_t key, uint32_t 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
     out[i] = (uint8_t)bb_keep(key, (uint32_t)i, thr);
 }
+// Size of the keep-bit matrix of an attention call (64-bit words), see attn_common.h.
+BEVBERT_API int64_t bevbert_attn_drop_bits_words(int B, int nh, int Lq, int Lk) {
+  return (int64_t)B * nh * ((Lq + 127) / 128 * 8) * ((Lk + 63) / 64) * 16;
+}
+
 BEVBERT_API int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p, uint64_t seed, uint64_t offset,
                                           hipStream_t stream) {
   if (n <= 0) return BB_OK;

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbevbert_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "gemm.hip", "capi.hip"]
+SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "attn_bwd1.hip", "gemm.hip", "capi.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bevbert_hip.h")
 
 F32, BF16, F16 = 0, 1, 2
@@ -35,7 +35,7 @@ def dtype_code(t):
 def build(force=False, verbose=False):
     """Compile csrc/*.hip into libbevbert_hip.so for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "attn_common.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "attn_common.h", "attn_mfma_common.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -59,9 +59,9 @@ _PROTOS = {
     "bevbert_bev_lift_bin": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _F, _P, _P, _P, _P],
     "bevbert_bev_bin_points": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     "bevbert_bev_splat_mean": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P],
-    "bevbert_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _F, _U64, _U64, _P],
+    "bevbert_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _F, _U64, _U64, _P, _P],
     "bevbert_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _F,
-                         _U64, _U64, _P],
+                         _U64, _U64, _P, _P],
     "bevbert_bias_dropout_residual_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _F, _U64,
                                                     _U64, _P],
     "bevbert_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U64, _I, _P],
@@ -105,6 +105,8 @@ def load():
     lib.bevbert_gemm_tuning_export.argtypes = [ctypes.c_char_p, _I64]
     lib.bevbert_gemm_tuning_import.restype = _I
     lib.bevbert_gemm_tuning_import.argtypes = [ctypes.c_char_p]
+    lib.bevbert_attn_drop_bits_words.restype = _I64
+    lib.bevbert_attn_drop_bits_words.argtypes = [_I, _I, _I, _I]
     lib.bevbert_colsum_partial_rows.restype = _I
     lib.bevbert_colsum_partial_rows.argtypes = [_I]
     lib.bevbert_gemm_plan.restype = _I

@@ -805,6 +805,17 @@ def _strides(q, k, v, o):
     return arr
 
 
+_DROP_BITS_WORDS = {}
+
+
+def _drop_bits_words(B, nh, Lq, Lk):
+    key = (B, nh, Lq, Lk)
+    n = _DROP_BITS_WORDS.get(key)
+    if n is None:
+        n = _DROP_BITS_WORDS[key] = lib.load().bevbert_attn_drop_bits_words(B, nh, Lq, Lk)
+    return n
+
+
 class _Attention(torch.autograd.Function):
     """mode 'self': qkv packed (B,L,3H);  mode 'cross': q (B,Lq,H) + kv packed (B,Lk,2H);  mode 'sep': q,k,v."""
 
@@ -830,16 +841,21 @@ class _Attention(torch.autograd.Function):
             assert key_mask.dtype == torch.float32 and key_mask.shape == (B, Lk) and key_mask.is_contiguous()
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.shape == (B, Lq, Lk) and bias.is_contiguous()
+        bits = None
+        if drop_p > 0 and need_grad and q.dtype == torch.bfloat16 and impl != 1:
+            # keep-bit matrix of the dropout mask: the MFMA forward stores the compare masks it has anyway, the
+            # backward reads one bit per score element instead of hashing again (1 bit / element: 19 MB at 64x12x441x441)
+            bits = torch.empty(_drop_bits_words(B, nh, Lq, Lk), dtype=torch.int64, device=q.device)
         call("bevbert_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(key_mask), ptr(bias),
              _strides(q, k, v, o), B, nh, Lq, Lk, HEAD_DIM, scale, dtype_code(q), impl, float(drop_p), RT.seed, off,
-             stream())
-        ctx.save_for_backward(a, b_, c_, key_mask, bias, o, lse)
+             ptr(bits), stream())
+        ctx.save_for_backward(a, b_, c_, key_mask, bias, o, lse, bits)
         ctx.cfg = (mode, nh, float(drop_p), RT.seed, off, impl, scale)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        a, b_, c_, key_mask, bias, o, lse = ctx.saved_tensors
+        a, b_, c_, key_mask, bias, o, lse, bits = ctx.saved_tensors
         mode, nh, drop_p, seed, off, impl, scale = ctx.cfg
         do = do.contiguous()
         if mode == "self":
@@ -864,7 +880,7 @@ class _Attention(torch.autograd.Function):
         assert do.shape == o.shape
         call("bevbert_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk),
              ptr(dv), ptr(dbias), ptr(key_mask), ptr(bias), _strides(q, k, v, o), B, nh, Lq, Lk, HEAD_DIM, scale,
-             dtype_code(q), impl, drop_p, seed, off, stream())
+             dtype_code(q), impl, drop_p, seed, off, ptr(bits), stream())
         return (None,) + grads + (None, dbias, None, None, None)
 
 

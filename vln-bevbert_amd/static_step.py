@@ -163,15 +163,3 @@ class GraphedStep:
 
     def __init__(self, graph, loss):
         self.graph, self.loss = graph, loss
-
-
-_POOL = {}
-
-
-def graph_pool(device):
-    """All step graphs of a process share one private memory pool: they are replayed one at a time on one stream and
-    exchange nothing through pool memory, so the pool is as large as the largest step, not the sum."""
-    key = torch.device(device).index
-    if key not in _POOL:
-        _POOL[key] = torch.cuda.graph_pool_handle()
-    return _POOL[key]

@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .static_step import GraphedStep, StaticBatch, graph_pool
+from .static_step import GraphedStep, StaticBatch
 
 
 def warmup_linear_lr(step, base_lr, warmup_steps, total_steps):
@@ -145,6 +145,7 @@ class PretrainTrainer:
         self.global_step = 0
         import os
         self.use_graphs = os.environ.get("BEVBERT_GRAPHS", "1") == "1" and arena.device.type == "cuda"
+        self._graph_pool = None
         first_map = min(arena.slices[n][0] for n in arena.slices
                         if n.startswith("bert.local_encoder") or n.startswith("bert.global_encoder")
                         or not n.startswith("bert."))
@@ -263,7 +264,11 @@ class PretrainTrainer:
         a.upload_flags()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=graph_pool(a.device)):
+        if self._graph_pool is None:
+            # all step graphs of a trainer share one private memory pool: they are replayed one at a time on one stream
+            # and exchange nothing through pool memory, so the pool is as large as the largest step, not the sum
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(graph, pool=self._graph_pool):
             ops.RT.new_step(0, write_salt=False)    # offsets restart; the salt word is read by the kernels at replay
             loss = self._forward_backward(task, sb)
             a.clip_and_step(None, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
