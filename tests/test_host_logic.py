@@ -28,6 +28,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert set(lib._PROTOS) | {"bevbert_last_error", "bevbert_version", "bevbert_arch",
                                "bevbert_colsum_workspace_floats", "bevbert_gemm_plan_count",
                                "bevbert_gemm_plan", "bevbert_colsum_partial_rows", "bevbert_gemm_tuning_export",
+                               "bevbert_attn_drop_bits_words",
                                "bevbert_gemm_tuning_import"} == set(syms)
 
 
@@ -52,7 +53,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     rc = l.bevbert_bev_lift_bin(None, None, None, None, None, 1, 12, 64, 10.0, 21, 0.5, 0.5, None, None, None, None)
     assert rc == -1 and b"out of range" in l.bevbert_last_error()
     strides = (ctypes.c_int64 * 8)(*([768] * 8))
-    rc = l.bevbert_attn_fwd(None, None, None, None, None, None, None, strides, 1, 12, 4, 4, 32, 0.125, 1, 0, 0.0, 0, 0, None)
+    rc = l.bevbert_attn_fwd(None, None, None, None, None, None, None, strides, 1, 12, 4, 4, 32, 0.125, 1, 0, 0.0, 0, 0, None, None)
     assert rc == -1 and b"head_dim" in l.bevbert_last_error()
 
 
