@@ -114,6 +114,12 @@ int64_t bevbert_colsum_workspace_floats(int total_cols);
 int bevbert_colsum_partial_rows(int rows);
 int bevbert_colsum_finalize(const float* partials, int nblocks, int nwhich, int C, float* out0, float* out1,
                             float* out2, int accumulate, hipStream_t stream);
+/* Batched second stage.  bevbert_colsum_partials = the first stage of bevbert_colsum alone.  bevbert_multi_finalize runs
+ * `ntasks` 64-column finalize tasks in ONE launch; `tasks` is a device array of 40-byte records
+ * {u64 partials, u64 out, i32 nblocks, i32 row_stride, i32 col0, i32 ncols, i32 accumulate, i32 pad}:
+ * out[c] (+)= sum_b partials[b * row_stride + col0 + c], c < ncols <= 64, fixed summation order (deterministic). */
+int bevbert_colsum_partials(const void* dy, float* partials, int rows, int C, int dtype, hipStream_t stream);
+int bevbert_multi_finalize(const void* tasks, int ntasks, hipStream_t stream);
 
 /* K5  BertEmbeddings.forward (vilmodel.py:62-77): y = LayerNorm(word[ids] + pos[row % L] + type_row) (+dropout). */
 int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const void* pos, const void* type_row,

@@ -149,6 +149,9 @@ class ParamArena:
 
     def zero_grad(self):
         self.sync()
+        if self.device.type == "cuda":
+            from . import ops
+            ops.SCRATCH.reset()        # partial-sum addresses repeat from step to step (ops.ReduceQueue caches on them)
         self.grads.zero_()
 
     def load_state_dict_into(self, module, sd, strict=True):

@@ -212,6 +212,32 @@ static void launch_finalize(const float* partials, int nblocks, int nwhich, int 
                      nwhich, C, o, accumulate);
 }
 
+// Batched second stage: ONE launch finishes every pending column reduction of a backward pass (LayerNorm gamma / beta /
+// bias, GELU bias, projection biases: ~110 per training step, each a 6-8 us launch of a few dozen workgroups when issued
+// one by one).  A task = 64 columns of one output vector; the host builds the task table once per distinct step shape
+// (ops.ReduceQueue) and keeps it in device memory.  Same arithmetic and summation order as colsum_finalize_kernel.
+struct FinalizeTask {
+  const float* partials;   // [nblocks][row_stride] floats
+  float* out;              // 64-column slice of the output vector
+  int nblocks, row_stride, col0, ncols, accumulate, pad;
+};
+__global__ __launch_bounds__(1024) void multi_finalize_kernel(const FinalizeTask* __restrict__ tasks) {
+  __shared__ float sh[16][64];
+  const FinalizeTask t = tasks[blockIdx.x];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  float s = 0.f;
+  if (tx < t.ncols)
+    for (int b = ty; b < t.nblocks; b += 16) s += t.partials[(size_t)b * t.row_stride + t.col0 + tx];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && tx < t.ncols) {
+    float v = sh[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v += sh[k][tx];
+    t.out[tx] = t.accumulate ? t.out[tx] + v : v;
+  }
+}
+
 // =============================================================================================
 // bias + erf-GELU forward / backward, and a plain column sum (QKV bias grads)
 // =============================================================================================
@@ -630,6 +656,34 @@ BEVBERT_API int bevbert_colsum(const void* dy, float* out, float* workspace, int
   BB_CHECK_LAUNCH("colsum");
   launch_finalize(workspace, nb, 1, C, out, nullptr, nullptr, accumulate, stream);
   BB_CHECK_LAUNCH("colsum finalize");
+  return BB_OK;
+}
+
+// First stage of bevbert_colsum alone: partials [bevbert_colsum_partial_rows(rows)][C]; the second stage goes through
+// bevbert_multi_finalize together with the other pending reductions of the step.
+BEVBERT_API int bevbert_colsum_partials(const void* dy, float* partials, int rows, int C, int dtype, hipStream_t stream) {
+  BB_REQUIRE(C % 4 == 0 && rows > 0, "colsum_partials: C=%d must be a multiple of 4, rows=%d positive", C, rows);
+  const int nb = colwise_blocks(rows);
+  const dim3 grid(nb, (C + 1023) / 1024);
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL((colwise_bwd_kernel<float, 1>), grid, dim3(256), 0, stream, (const float*)dy, nullptr, nullptr, nullptr, partials, rows, C);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL((colwise_bwd_kernel<bf16_raw, 1>), grid, dim3(256), 0, stream, (const bf16_raw*)dy, nullptr, nullptr, nullptr, partials, rows, C);
+  else {
+    bb_set_error("colsum_partials: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("colsum_partials");
+  return BB_OK;
+}
+
+// tasks: device array of `ntasks` 40-byte records {u64 partials, u64 out, i32 nblocks, row_stride, col0, ncols, accumulate, pad}
+BEVBERT_API int bevbert_multi_finalize(const void* tasks, int ntasks, hipStream_t stream) {
+  static_assert(sizeof(FinalizeTask) == 40, "FinalizeTask is part of the C ABI");
+  if (ntasks <= 0) return BB_OK;
+  BB_REQUIRE(tasks != nullptr, "multi_finalize: null task table");
+  hipLaunchKernelGGL(multi_finalize_kernel, dim3(ntasks), dim3(64, 16), 0, stream, (const FinalizeTask*)tasks);
+  BB_CHECK_LAUNCH("multi_finalize");
   return BB_OK;
 }
 

@@ -74,6 +74,8 @@ _PROTOS = {
     "bevbert_grad_norm_clip": [_P, _I64, _F, _F, _P, _P, _P],
     "bevbert_adamw_step": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _F, _F, _F, _F, _F, _P],
     "bevbert_set_step_salt": [_P],
+    "bevbert_colsum_partials": [_P, _P, _I, _I, _I, _P],
+    "bevbert_multi_finalize": [_P, _I, _P],
     "bevbert_cast_f32": [_P, _P, _I64, _I, _P],
     "bevbert_accum_partials": [_P, _P, _I, _I64, _I, _P],
     "bevbert_dropout_keep_mask": [_P, _I64, _F, _U64, _U64, _P],

@@ -228,12 +228,120 @@ class WgradStream:
 
     @classmethod
     def flush_all(cls):
+        """Issue everything deferred so far, then -- in one launch -- the pending second stages of the column
+        reductions (ReduceQueue): their first stages were enqueued on the producing streams before this call."""
+        if ReduceQueue.jobs:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            if cls.active(dev):
+                h = lib.stream()
+                slot = cls._pending.get(h)
+                if slot is None:
+                    slot = cls._pending[h] = (torch.cuda.current_stream(dev), [])
+                slot[1].append(lambda: ReduceQueue.flush(dev))
+                mine = slot
+                for other in cls._pending.values():
+                    if other is not mine:
+                        cls._flush(other)
+                cls._flush(mine)
+                return
+            ReduceQueue.flush(dev)
         for slot in cls._pending.values():
             cls._flush(slot)
 
     @classmethod
     def release(cls):
         cls._keep.clear()
+
+
+class ScratchRing:
+    """Bump allocator over one device buffer for the short-lived fp32 partial sums of the two-stage column reductions.
+    ``reset()`` at the start of every step makes the addresses REPEAT from step to step (same task -> same sequence of
+    allocations), which is what lets ReduceQueue keep its task tables -- they hold raw pointers -- in device memory
+    instead of rebuilding and re-uploading them every step.  Wraps around when full (capacity >> one step's needs)."""
+
+    def __init__(self, nbytes=1 << 30):
+        self.nbytes = nbytes
+        self.buf = None
+        self.base = 0
+        self.off = 0
+
+    def reset(self):
+        self.off = 0
+
+    def alloc(self, nbytes, device):
+        if self.buf is None:
+            self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+            self.base = self.buf.data_ptr()
+        n = (int(nbytes) + 255) & ~255
+        if n > self.nbytes:
+            raise lib.BevBertHipError(f"scratch ring: {n} bytes requested, capacity {self.nbytes}")
+        if self.off + n > self.nbytes:
+            self.off = 0
+        p = self.base + self.off
+        self.off += n
+        return p
+
+
+SCRATCH = ScratchRing(int(_os.environ.get("BEVBERT_SCRATCH_MB", "1024")) << 20)
+
+
+class ReduceQueue:
+    """Pending second stages of the column reductions of a backward pass (LayerNorm gamma / beta / bias, GELU bias,
+    projection biases).  Issued one by one they are ~110 launches of 6-8 us per training step -- a tenth of the step's
+    launches and ~1 ms of GPU time spent on kernels of a few dozen workgroups.  Here the first stages leave their
+    per-block partial sums in the scratch ring, the queue collects (partials, outputs) records, and ``flush`` runs them
+    all in ONE launch (bevbert_multi_finalize) on the weight-gradient stream.  The task table of a given record list
+    is built once and kept on the device (the records hold raw pointers; ScratchRing makes them repeat)."""
+
+    jobs = []
+    _tables = {}
+    _dtype = None
+
+    @classmethod
+    def add(cls, partials_ptr, nblocks, nwhich, C, outs, accumulate=1):
+        cls.jobs.append((partials_ptr, nblocks, nwhich, C, outs[0] or 0, outs[1] or 0, outs[2] or 0, accumulate))
+
+    @classmethod
+    def _build(cls, jobs, device):
+        import numpy as np
+        if cls._dtype is None:
+            cls._dtype = np.dtype([("partials", "<u8"), ("out", "<u8"), ("nblocks", "<i4"), ("row_stride", "<i4"),
+                                   ("col0", "<i4"), ("ncols", "<i4"), ("accumulate", "<i4"), ("pad", "<i4")])
+        parts = []
+        for partials_ptr, nblocks, nwhich, C, o0, o1, o2, acc in jobs:
+            ntile = (C + 63) // 64
+            tiles = np.arange(ntile, dtype=np.int64)
+            for which, out in enumerate((o0, o1, o2)[:nwhich]):
+                if not out:
+                    continue
+                t = np.zeros(ntile, dtype=cls._dtype)
+                t["partials"] = partials_ptr
+                t["out"] = out + tiles * 256
+                t["nblocks"] = nblocks
+                t["row_stride"] = nwhich * C
+                t["col0"] = which * C + tiles * 64
+                t["ncols"] = np.minimum(64, C - tiles * 64)
+                t["accumulate"] = acc
+                parts.append(t)
+        table = np.concatenate(parts) if parts else np.zeros(0, dtype=cls._dtype)
+        dev = torch.from_numpy(table.view(np.uint8).copy()).to(device)
+        return dev, len(table)
+
+    @classmethod
+    def flush(cls, device):
+        """Launch the pending second stages (on the stream C-ABI launches currently go to)."""
+        if not cls.jobs:
+            return
+        key = tuple(cls.jobs)
+        cls.jobs = []
+        ent = cls._tables.get(key)
+        if ent is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise lib.BevBertHipError("reduction task table missing during graph capture (warm-up steps build it)")
+            if len(cls._tables) > 256:
+                cls._tables.clear()
+            ent = cls._tables[key] = cls._build(key, device)
+        call("bevbert_multi_finalize", ent[0].data_ptr(), ent[1], stream())
 
 
 def call(name, *args):
@@ -467,8 +575,14 @@ def _param_grads(w_sink, b_sink, dyc, xc):
             WgradStream._keep.append(part)
     if b_sink is not None:
         C = dyc.shape[1]
-        ws = RT.workspace(dyc.device, 512 * C)
-        call("bevbert_colsum", ptr(dyc), ptr(b_sink), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 1, stream())
+        if WgradStream.DEFER_FINALIZE and dyc.shape[0] > 0:
+            nb = _partial_rows(dyc.shape[0])
+            part = SCRATCH.alloc(nb * C * 4, dyc.device)
+            call("bevbert_colsum_partials", ptr(dyc), part, dyc.shape[0], C, dtype_code(dyc), stream())
+            ReduceQueue.add(part, nb, 1, C, (ptr(b_sink), None, None))
+        else:
+            ws = RT.workspace(dyc.device, 512 * C)
+            call("bevbert_colsum", ptr(dyc), ptr(b_sink), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 1, stream())
 
 
 _PARTIAL_ROWS = {}
@@ -577,15 +691,14 @@ class _BiasDropResLN(torch.autograd.Function):
             dx, dz_ptr = dz, None
         else:
             dz_ptr = dz
-        if ag == 1 and WgradStream.DEFER_FINALIZE and WgradStream.active(dev):
-            # arena parameters: the kernel leaves its per-block partial sums in a private buffer and the second stage
-            # of the reduction runs on the weight-gradient stream, off the activation-gradient critical path
+        if ag == 1 and WgradStream.DEFER_FINALIZE and dev.type == "cuda":
+            # arena parameters: the kernel leaves its per-block partial sums in the scratch ring; the second stage of
+            # the reduction joins the step's other pending reductions (ReduceQueue: one launch, off the critical path)
             nb = _partial_rows(rows)
-            part = torch.empty(nb * 3 * H, dtype=torch.float32, device=dev)
+            part = SCRATCH.alloc(nb * 3 * H * 4, dev)
             call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz_ptr), ptr(dx),
-                 None, None, None, ptr(part), rows, H, dtype_code(dy), drop_p, seed, off, 1, stream())
-            WgradStream.submit(dev, lambda: call("bevbert_colsum_finalize", ptr(part), nb, 3, H, ptr(dg), ptr(db),
-                                                 ptr(dbi), 1, stream()), part)
+                 None, None, None, part, rows, H, dtype_code(dy), drop_p, seed, off, 1, stream())
+            ReduceQueue.add(part, nb, 3, H, (ptr(dg), ptr(db), ptr(dbi)))
         else:
             call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz_ptr), ptr(dx),
                  ptr(dg), ptr(db), ptr(dbi), ptr(ws), rows, H, dtype_code(dy), drop_p, seed, off, ag, stream())
@@ -669,13 +782,12 @@ class _BiasGelu(torch.autograd.Function):
         sink = _sink(bias)
         if sink is not None:
             _mark_touched(bias)
-            if WgradStream.DEFER_FINALIZE and WgradStream.active(dy.device):      # second reduction stage on the weight-gradient stream (see _BiasDropResLN)
+            if WgradStream.DEFER_FINALIZE:      # second reduction stage batched with the step's others (see _BiasDropResLN)
                 nb = _partial_rows(rows)
-                part = torch.empty(nb * C, dtype=torch.float32, device=dy.device)
-                call("bevbert_bias_gelu_bwd", ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), None, ptr(part), rows, C,
+                part = SCRATCH.alloc(nb * C * 4, dy.device)
+                call("bevbert_bias_gelu_bwd", ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), None, part, rows, C,
                      dtype_code(dy), 1, stream())
-                WgradStream.submit(dy.device, lambda: call("bevbert_colsum_finalize", ptr(part), nb, 1, C, ptr(sink),
-                                                           None, None, 1, stream()), part)
+                ReduceQueue.add(part, nb, 1, C, (ptr(sink), None, None))
                 return dx, None
             call("bevbert_bias_gelu_bwd", ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), ptr(sink), ptr(ws), rows, C,
                  dtype_code(dy), 1, stream())
@@ -931,8 +1043,15 @@ class _EmbedLN(torch.autograd.Function):
         assert (sg is None) == (sb is None)
         if sg is not None:
             _mark_touched(gamma); _mark_touched(beta)
-            call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz), None,
-                 ptr(sg), ptr(sb), None, ptr(ws), rows, H, dtype_code(dy), 0.0, 0, 0, 1, stream())
+            if WgradStream.DEFER_FINALIZE:
+                nb = _partial_rows(rows)
+                part = SCRATCH.alloc(nb * 3 * H * 4, dy.device)
+                call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz), None,
+                     None, None, None, part, rows, H, dtype_code(dy), 0.0, 0, 0, 1, stream())
+                ReduceQueue.add(part, nb, 3, H, (ptr(sg), ptr(sb), None))
+            else:
+                call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz), None,
+                     ptr(sg), ptr(sb), None, ptr(ws), rows, H, dtype_code(dy), 0.0, 0, 0, 1, stream())
             rg = rb = None
         else:
             rg = torch.empty(H, dtype=torch.float32, device=dy.device)
