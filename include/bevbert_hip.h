@@ -197,6 +197,9 @@ int bevbert_gemm_plan(int M, int N, int K, int opA, int opB, int64_t lda, int64_
                       int accumulate, int64_t workspace_bytes, int autotune);
 int bevbert_gemm_run(int plan, const void* A, const void* B, void* C, const void* bias, void* workspace,
                      int64_t workspace_bytes, hipStream_t stream);
+/* D = op(A) . op(B) + Cin through an ACCUMULATING plan (beta = 1) with a separate addend of D's layout. */
+int bevbert_gemm_run_add(int plan, const void* A, const void* B, const void* Cin, void* D, const void* bias,
+                         void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int bevbert_gemm_plan_count(void);
 /* Tuning table (text): one line "<problem key> <choice> <ncand>" per autotuned plan after a header naming the hipBLASLt
  * version.  export returns the bytes the text needs (incl. the final 0) and fills buf when cap suffices; import makes

@@ -395,3 +395,66 @@ def test_static_batch_host_side_and_in_place_refill():
     bs = synthetic.make_batch(cfg, "masksem", 4, seed=8, sems_as="ids")
     cap = StaticBatch(cfg, "masksem", bs, "cpu").tensors["_static"]["sem_cap"]
     assert cap % SEM_ROW_PAD == 0 and cap >= int(bs["bev_mrc_masks"].sum())
+
+
+def test_hdf5_converter_on_synthetic_stores(tmp_path, monkeypatch):
+    """f2: feature_cache.convert_hdf5 -- the one step that touches the reference's HDF5 feature files
+    (precompute_features/grid_mp3d_clip.py:168-183 writes '<scan>_<vp>' -> (12, 196, 768) float16 gzip;
+    grid_depth.py:122-131 -> (12, 14, 14) float32; the semantic store uint8 ids; dataset.py:110-118 reads them).
+    With h5py installed the files are real HDF5; without it (this image) a duck-typed stand-in with h5py's File /
+    keys() / dataset[...] surface drives the same converter code, so that the key walk, dtype handling, sharding and
+    the reader are exercised either way."""
+    import sys
+    import types
+    from vln_bevbert_amd import feature_cache
+    rng = np.random.default_rng(3)
+    keys = [f"scan{i // 3}_vp{i:03d}" for i in range(7)]
+    data = {"rgb": {k: rng.standard_normal((12, 196, 64)).astype(np.float16) for k in keys},
+            "depth": {k: rng.uniform(0, 0.6, (12, 14, 14)).astype(np.float32) for k in keys},
+            "sem": {k: rng.integers(0, 40, (12, 14, 14)).astype(np.uint8) for k in keys}}
+    try:
+        import h5py
+        paths = {}
+        for name, d in data.items():
+            paths[name] = str(tmp_path / f"{name}.hdf5")
+            with h5py.File(paths[name], "w") as f:
+                for k, v in d.items():
+                    f.create_dataset(k, data=v, compression="gzip" if name == "rgb" else None)
+    except ImportError:
+        class _Dataset:
+            def __init__(self, arr):
+                self.arr = arr
+
+            def __getitem__(self, idx):
+                assert idx is Ellipsis
+                return self.arr
+
+        class _File:
+            def __init__(self, path, mode="r"):
+                assert mode == "r"
+                self.d = data[os.path.basename(path).split(".")[0]]
+
+            def keys(self):
+                return self.d.keys()
+
+            def __getitem__(self, k):
+                return _Dataset(self.d[k])
+
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return False
+
+        monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=_File))
+        paths = {name: str(tmp_path / f"{name}.hdf5") for name in data}
+    out = str(tmp_path / "cache")
+    n = feature_cache.convert_hdf5(paths["rgb"], paths["depth"], paths["sem"], out, shard_size=3)
+    assert n == len(keys)
+    idx = feature_cache.read_index(out)
+    assert idx["keys"] == keys and max(idx["shard_of"]) == 2 and idx["shape"] == {"V": 12, "hw": 14, "C": 64}
+    store = feature_cache.load_store(out, "cpu", keys=[keys[5], keys[1]])
+    r = store.rows([keys[1]])
+    assert torch.equal(store.rgbs[r.long()][0], torch.from_numpy(data["rgb"][keys[1]].reshape(2352, 64)))
+    assert torch.equal(store.depths[r.long()][0], torch.from_numpy(data["depth"][keys[1]]))
+    assert torch.equal(store.sems[r.long()][0], torch.from_numpy(data["sem"][keys[1]].reshape(2352)))

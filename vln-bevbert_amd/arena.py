@@ -147,6 +147,11 @@ class ParamArena:
             ops.WgradStream.dirty = False
             ops.WgradStream.release()
 
+    def backward_done(self):
+        """Call after ``loss.backward()`` when an external loop / optimiser reads the gradients: issues the deferred
+        weight-gradient and reduction launches and makes the current stream wait for them (== ``sync``)."""
+        self.sync()
+
     def zero_grad(self):
         self.sync()
         if self.device.type == "cuda":

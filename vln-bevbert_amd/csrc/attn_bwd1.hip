@@ -4,8 +4,11 @@
 // Q, K, V, dO twice: 7 tile GEMMs and ~2x the softmax arithmetic for 5 GEMMs' worth of algorithmic work, on kernels that
 // are VALU-bound.  Here a workgroup owns ALL keys of one (batch, head) (Lk <= 64 * KT <= 448: the 21x21 BEV has 441 cells):
 //
-//   * 4 waves, one per SIMD; wave w owns the 16*KT keys [w*16*KT, (w+1)*16*KT): its V fragments (B operand of dP) and
-//     its dK^T / dV^T accumulators [64 d][16*KT keys] stay in registers for the whole kernel (KT = 7: 56 + 224 VGPR/AGPR);
+//   * NW waves; wave w owns the 16*KT keys [w*16*KT, (w+1)*16*KT): its V fragments (B operand of dP) and its dK^T / dV^T
+//     accumulators [64 d][16*KT keys] stay in registers for the whole kernel.  Two geometries: NW = 4 (one wave per
+//     SIMD, up to 112 keys per wave) for short key sequences, and NW = 8 x 64 keys (two waves per SIMD, 160 accumulator
+//     + operand registers per wave) for the 441-cell BEV: the single-wave form spends 57 % of its wave cycles parked in
+//     s_waitcnt (profiles/r02a_pmc_attn_sq_counters.txt) -- a second resident wave per SIMD fills those slots;
 //   * K is staged once, row-major, in LDS: B operand of S = Q K^T by plain 16-byte reads, and -- through the
 //     transposing LDS read of gfx950 (ds_read_b64_tr_b16) -- the K^T A operand of dQ^T = K^T dS^T from the SAME image;
 //   * loop over 64-query tiles: S and dP on the matrix cores, then ONE pass of softmax-backward arithmetic per score
@@ -22,21 +25,25 @@
 
 #define B1_LDS_DS 68     // row stride (bf16) of the dS image: 64 queries + 4 (rows stay 8-byte aligned for the tr reads)
 
-// dynamic LDS carve (bytes); NK = 64 * KT keys
-template <int KT> struct B1Lds {
-  static constexpr int NK = 64 * KT;
+// dynamic LDS carve (bytes); NK = 64 * NKT keys
+template <int NKT> struct B1Lds {
+  static constexpr int NK = 64 * NKT;
   static constexpr int q_off = 0;                                  // [64][LDT] bf16   Q tile (row-major)
   static constexpr int do_off = q_off + TK * LDT * 2;              // [64][LDT] bf16   dO tile
   static constexpr int k_off = do_off + TK * LDT * 2;              // [NK][LDT] bf16   K (row-major), whole kernel
   static constexpr int ds_off = k_off + NK * LDT * 2;              // [NK][B1_LDS_DS]  dS of the current query tile
   static constexpr int bits_off = ds_off + NK * B1_LDS_DS * 2;     // [4][KT][16] u64  keep bits of the current query tile
-  static constexpr int stat_off = bits_off + 4 * KT * 16 * 8;      // [2][64] float    lse (log2 domain), delta
+  static constexpr int stat_off = bits_off + 4 * NKT * 16 * 8;      // [2][64] float    lse (log2 domain), delta
   static constexpr int bytes = stat_off + 2 * TK * 4;
 };
 
-template <int KT, bool BIAS, bool DROP>
-__global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd1_kernel(AttnArgs a) {
-  typedef B1Lds<KT> L;
+// KT: 16-key tiles per wave; NW: waves per workgroup (4 or 8); NKT: 64-key tiles of the workgroup (LDS images)
+template <int KT, int NW, int NKT, bool BIAS, bool DROP>
+__global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) void attn_mfma_bwd1_kernel(AttnArgs a) {
+  typedef B1Lds<NKT> L;
+  constexpr int NT = 64 * NW;             // threads
+  constexpr int CPT = 512 / NT;           // 16-byte chunks of a [64][64] bf16 tile per thread (2 or 1)
+  constexpr bool HOLD = (NW == 4);        // keep the Q^T / dO^T fragments of a half in registers across the key tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char b1_smem[];
   bf16_raw* const s_q = reinterpret_cast<bf16_raw*>(b1_smem + L::q_off);
   bf16_raw* const s_do = reinterpret_cast<bf16_raw*>(b1_smem + L::do_off);
@@ -61,6 +68,7 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
 
   // ---- per-wave key state: V fragments, additive key mask (log2 domain; -inf beyond Lk), accumulators
   const int key0 = w * (16 * KT);                  // first key of this wave
+  const bool has_keys = key0 < L::NK;              // NW = 8 on 448 keys: the eighth wave only stages tiles and computes dQ
   bf16x8 vf[KT][2];
   float mask2[KT];
 #pragma unroll
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
     const int key = key0 + kt * 16 + c;
     const int r = key < a.Lk ? key : a.Lk - 1;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) vf[kt][ks] = as_bf16x8(ld_frag_global(vp, a.ldv, r, ks * 32 + g * 8));
+    for (int ks = 0; ks < 2; ++ks) vf[kt][ks] = as_bf16x8(ld_frag_global(vp, a.ldv, r, ks * 32 + g * 8));      // (unused rows: clamped)
     mask2[kt] = key < a.Lk ? (a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * LOG2E : 0.f) : -INFINITY;
   }
   f32x4 dkacc[KT][4], dvacc[KT][4];
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
     }
 
   // ---- K -> LDS (row-major, zero rows beyond Lk), once
-  for (int c16 = tid; c16 < L::NK * 8; c16 += 256) {
+  for (int c16 = tid; c16 < L::NK * 8; c16 += NT) {
     const int row = c16 >> 3, ch = c16 & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < a.Lk) v = ld_frag_global(kp, a.ldk, row, ch * 8);
@@ -90,20 +98,27 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
 
   // ---- staging of one 64-query tile: Q, dO rows -> LDS; delta = rowsum(dO * O); lse; keep bits
   // thread t owns 16-byte chunks ch = t and t + 256: row ch >> 3, dims 8 (ch & 7) .. +7; a row is covered by 8 lanes
-  TileRegs qreg, doreg, oreg;
+  uint4 qreg[CPT], doreg[CPT], oreg[CPT];
   float lreg = 0.f;
-  uint2 breg[2];
+  uint2 breg[CPT];
   auto tile_issue = [&](int q0) {
-    tile_load(qreg, qp, a.ldq, q0, a.Lq, tid);
-    tile_load(doreg, dop, a.ldo, q0, a.Lq, tid);
-    tile_load(oreg, op, a.ldo, q0, a.Lq, tid);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int ch = tid + i * NT, row = ch >> 3, d0 = (ch & 7) * 8;
+      qreg[i] = doreg[i] = oreg[i] = make_uint4(0, 0, 0, 0);           // rows past the end are zero filled
+      if (q0 + row < a.Lq) {
+        qreg[i] = ld_frag_global(qp, a.ldq, q0 + row, d0);
+        doreg[i] = ld_frag_global(dop, a.ldo, q0 + row, d0);
+        oreg[i] = ld_frag_global(op, a.ldo, q0 + row, d0);
+      }
+    }
     lreg = INFINITY;                            // padding rows: p = exp2(-inf) = 0
     if (tid < TK && q0 + tid < a.Lq) lreg = a.lse[((size_t)b * a.nh + h) * a.Lq + q0 + tid] * LOG2E;
     if (use_bits) {                             // words of (4 query-16-tiles) x (nk64 key tiles) x 16, 8 bytes each
       const int per_q16 = a.nk64 * 16;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int wi = tid + i * 256, q16l = wi / per_q16, rest = wi - q16l * per_q16;
+      for (int i = 0; i < CPT; ++i) {
+        const int wi = tid + i * NT, q16l = wi / per_q16, rest = wi - q16l * per_q16;
         breg[i] = make_uint2(0u, 0u);
         if (q16l < 4 && (q0 >> 4) + q16l < a.nq16)
           breg[i] = *reinterpret_cast<const uint2*>(a.drop_bits + ((size_t)bh * a.nq16 + (q0 >> 4) + q16l) * per_q16 + rest);
@@ -111,12 +126,13 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
     }
   };
   auto tile_commit = [&]() {
-    tile_store_rows(s_q, qreg, tid);
-    tile_store_rows(s_do, doreg, tid);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const uint32_t dw[4] = {doreg.v[i].x, doreg.v[i].y, doreg.v[i].z, doreg.v[i].w};
-      const uint32_t ow[4] = {oreg.v[i].x, oreg.v[i].y, oreg.v[i].z, oreg.v[i].w};
+    for (int i = 0; i < CPT; ++i) {
+      const int ch = tid + i * NT, row = ch >> 3, d0 = (ch & 7) * 8;
+      *reinterpret_cast<uint4*>(s_q + row * LDT + d0) = qreg[i];
+      *reinterpret_cast<uint4*>(s_do + row * LDT + d0) = doreg[i];
+      const uint32_t dw[4] = {doreg[i].x, doreg[i].y, doreg[i].z, doreg[i].w};
+      const uint32_t ow[4] = {oreg[i].x, oreg[i].y, oreg[i].z, oreg[i].w};
       float dsum = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -125,15 +141,15 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
       dsum += __shfl_xor(dsum, 1, 64);
       dsum += __shfl_xor(dsum, 2, 64);
       dsum += __shfl_xor(dsum, 4, 64);
-      if ((tid & 7) == 0) s_dlt[(tid + i * 256) >> 3] = dsum;
+      if ((tid & 7) == 0) s_dlt[row] = dsum;
     }
     if (tid < TK) s_lse2[tid] = lreg;
     if (use_bits) {
       const int per_q16 = a.nk64 * 16;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int wi = tid + i * 256, q16l = wi / per_q16, rest = wi - q16l * per_q16;
-        if (q16l < 4) s_bits[q16l * (KT * 16) + rest] = breg[i];
+      for (int i = 0; i < CPT; ++i) {
+        const int wi = tid + i * NT, q16l = wi / per_q16, rest = wi - q16l * per_q16;
+        if (q16l < 4) s_bits[q16l * (NKT * 16) + rest] = breg[i];
       }
     }
   };
@@ -143,32 +159,38 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
 
   for (int q0 = 0; q0 < a.Lq; q0 += TK) {
     // ================= phase 1: S, dP, softmax backward, dK^T / dV^T, dS -> LDS =================
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {       // halves of 32 queries: query tiles t = 2m, 2m + 1
-      bf16x8 qa[2][2], da[2][2], qtf[4], dotf[4];
+#pragma unroll 1
+    for (int m = 0; m < (has_keys ? 2 : 0); ++m) {       // halves of 32 queries: query tiles t = 2m, 2m + 1
+      bf16x8 qa[2][2], da[2][2], qtf[HOLD ? 4 : 1], dotf[HOLD ? 4 : 1];
       float lv[2][4], ndl[2][4];
+      auto load_rows = [&]() {          // A operands of S / dP (rows of this half's two query tiles) and their statistics
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = 2 * m + tt;
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * m + tt;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          qa[tt][ks] = lds_frag_rows(s_q, t, ks, lane);
-          da[tt][ks] = lds_frag_rows(s_do, t, ks, lane);
+          for (int ks = 0; ks < 2; ++ks) {
+            qa[tt][ks] = lds_frag_rows(s_q, t, ks, lane);
+            da[tt][ks] = lds_frag_rows(s_do, t, ks, lane);
+          }
+          const float4 l4 = *reinterpret_cast<const float4*>(&s_lse2[t * 16 + g * 4]);
+          const float4 d4 = *reinterpret_cast<const float4*>(&s_dlt[t * 16 + g * 4]);
+          lv[tt][0] = l4.x; lv[tt][1] = l4.y; lv[tt][2] = l4.z; lv[tt][3] = l4.w;
+          ndl[tt][0] = -d4.x; ndl[tt][1] = -d4.y; ndl[tt][2] = -d4.z; ndl[tt][3] = -d4.w;
         }
-        const float4 l4 = *reinterpret_cast<const float4*>(&s_lse2[t * 16 + g * 4]);
-        const float4 d4 = *reinterpret_cast<const float4*>(&s_dlt[t * 16 + g * 4]);
-        lv[tt][0] = l4.x; lv[tt][1] = l4.y; lv[tt][2] = l4.z; lv[tt][3] = l4.w;
-        ndl[tt][0] = -d4.x; ndl[tt][1] = -d4.y; ndl[tt][2] = -d4.z; ndl[tt][3] = -d4.w;
-      }
+      };
+      if (HOLD) load_rows();
       // A operands of the two "contract over queries" products: rows d, k-slots (g, j) <-> query 32 m + 16 (j >> 2) + 4 g + (j & 3)
+      if (HOLD) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        qtf[dt] = lds_frag_tr(s_q, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane);
-        dotf[dt] = lds_frag_tr(s_do, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane);
+        for (int dt = 0; dt < 4; ++dt) {
+          qtf[dt] = lds_frag_tr(s_q, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane);
+          dotf[dt] = lds_frag_tr(s_do, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane);
+        }
       }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         const int ktg = w * KT + kt;                 // 16-key tile index within the (batch, head)
+        if (!HOLD) load_rows();                      // two waves per SIMD: re-read per key tile, keep the registers free
         f32x4 sacc[2], dpacc[2];
         const bf16x8 kf0 = lds_frag_rows(s_k, ktg, 0, lane), kf1 = lds_frag_rows(s_k, ktg, 1, lane);
 #pragma unroll
@@ -186,7 +208,7 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
           uint32_t nib = 0xfu;
           if (DROP) {
             // keep bits of the forward: word (q16 = t, k64 = ktg >> 2, t' = ktg & 3, r' = c & 3), bits 16 (c >> 2) + 4 g + r
-            const uint2 wd = s_bits[((t * KT + (ktg >> 2)) * 4 + (ktg & 3)) * 4 + (c & 3)];
+            const uint2 wd = s_bits[((t * NKT + (ktg >> 2)) * 4 + (ktg & 3)) * 4 + (c & 3)];
             nib = (bits_hi ? wd.y : wd.x) >> bits_sh;
           }
 #pragma unroll
@@ -224,8 +246,15 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dkacc[kt][dt] = mfma16(qtf[dt], dsb, dkacc[kt][dt]);
-          dvacc[kt][dt] = mfma16(dotf[dt], pdb, dvacc[kt][dt]);
+          if (HOLD) {
+            dkacc[kt][dt] = mfma16(qtf[dt], dsb, dkacc[kt][dt]);
+            dvacc[kt][dt] = mfma16(dotf[dt], pdb, dvacc[kt][dt]);
+          } else {      // two resident waves per SIMD hide the extra transposing reads; the registers are what is scarce
+            const bf16x8 qt1 = lds_frag_tr(s_q, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane);
+            const bf16x8 dot1 = lds_frag_tr(s_do, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane);
+            dkacc[kt][dt] = mfma16(qt1, dsb, dkacc[kt][dt]);
+            dvacc[kt][dt] = mfma16(dot1, pdb, dvacc[kt][dt]);
+          }
         }
       }
     }
@@ -234,29 +263,35 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
     // ================= phase 2: next tile's loads in flight, dQ^T = K^T dS^T for d rows 16 w .. 16 w + 15 =================
     const bool more = q0 + TK < a.Lq;
     if (more) tile_issue(q0 + TK);
-    f32x4 dqacc[4];
+    // NW = 4: wave w -> d rows 16 w .. +15, all four query tiles;  NW = 8: d rows 16 (w & 3), query tiles 2 (w >> 2), +1
+    constexpr int NQT = (NW == 4) ? 4 : 2;
+    const int dq_d0 = 16 * (w & 3), dq_qt0 = (NW == 4) ? 0 : 2 * (w >> 2);
+    f32x4 dqacc[NQT];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) dqacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < NQT; ++qt) dqacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
-    for (int ks = 0; ks < 2 * KT; ++ks) {         // k-steps of 32 keys
-      const bf16x8 ka = lds_frag_tr(s_k, LDT, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * w, lane);
+    for (int ks = 0; ks < 2 * NKT; ++ks) {         // k-steps of 32 keys
+      const bf16x8 ka = lds_frag_tr(s_k, LDT, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, dq_d0, lane);
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt) {
-        const bf16x8 dsf = lds_frag_tr(s_ds, B1_LDS_DS, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * qt, lane);
+      for (int qt = 0; qt < NQT; ++qt) {
+        const bf16x8 dsf = lds_frag_tr(s_ds, B1_LDS_DS, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * (dq_qt0 + qt), lane);
         dqacc[qt] = mfma16(ka, dsf, dqacc[qt]);
       }
     }
-    // lane (query = q0 + 16 qt + c) holds dQ^T[d = 16 w + 4 g + r][query]
+    // The next tile goes to LDS BEFORE this tile's dQ is stored: vmcnt counts stores as well as loads on gfx950, so a
+    // commit placed behind the (scattered, 8-byte) dQ stores would wait for their write acknowledgements too -- this
+    // way the stores drain underneath the next tile's phase 1.
+    if (more) tile_commit();
+    // lane (query = q0 + 16 qt + c) holds dQ^T[d = dq_d0 + 4 g + r][query]
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      const int qi = q0 + qt * 16 + c;
+    for (int qt = 0; qt < NQT; ++qt) {
+      const int qi = q0 + (dq_qt0 + qt) * 16 + c;
       if (qi < a.Lq) {
-        bf16_raw* dqp = (bf16_raw*)a.dq + (size_t)b * a.bsq + (size_t)qi * a.ldq + h * ATTN_D + 16 * w + 4 * g;
+        bf16_raw* dqp = (bf16_raw*)a.dq + (size_t)b * a.bsq + (size_t)qi * a.ldq + h * ATTN_D + dq_d0 + 4 * g;
         st4<bf16_raw>(dqp, make_float4(dqacc[qt][0] * a.scale, dqacc[qt][1] * a.scale, dqacc[qt][2] * a.scale,
                                        dqacc[qt][3] * a.scale));
       }
     }
-    if (more) tile_commit();
     __syncthreads();   // next tile staged; dS image free again
   }
 
@@ -265,7 +300,7 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     const int key = key0 + kt * 16 + c;
-    if (key < a.Lk) {
+    if (has_keys && key < a.Lk) {
       bf16_raw* dkp = (bf16_raw*)a.dk + (size_t)b * a.bsk + (size_t)key * a.ldk + h * ATTN_D;
       bf16_raw* dvp = (bf16_raw*)a.dv + (size_t)b * a.bsv + (size_t)key * a.ldv + h * ATTN_D;
 #pragma unroll
@@ -283,26 +318,27 @@ __global__ __launch_bounds__(256, (KT <= 2 && !BIAS) ? 2 : 1) void attn_mfma_bwd
 // =============================================================================================
 // launcher
 // =============================================================================================
-template <int KT, bool B_, bool D_>
+template <int KT, int NW, int NKT, bool B_, bool D_>
 static int launch_bwd1(const AttnArgs& a, hipStream_t st) {
-  typedef B1Lds<KT> L;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd1_kernel<KT, B_, D_>),
+  typedef B1Lds<NKT> L;
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd1_kernel<KT, NW, NKT, B_, D_>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes) == hipSuccess;
   BB_REQUIRE(ok, "attention bwd (single pass): cannot raise the dynamic LDS limit to %d bytes", L::bytes);
-  hipLaunchKernelGGL((attn_mfma_bwd1_kernel<KT, B_, D_>), dim3((unsigned)a.B * a.nh), dim3(256), L::bytes, st, a);
+  hipLaunchKernelGGL((attn_mfma_bwd1_kernel<KT, NW, NKT, B_, D_>), dim3((unsigned)a.B * a.nh), dim3(64 * NW), L::bytes,
+                     st, a);
   BB_CHECK_LAUNCH("attn_bwd(single pass)");
   return BB_OK;
 }
 
-template <int KT>
+template <int KT, int NW, int NKT>
 static int dispatch_bwd1(const AttnArgs& a, hipStream_t st) {
   const bool hb = a.bias != nullptr, hd = a.drop_p > 0.f;
-  if constexpr (KT <= 2) {      // the additive graph bias only occurs on the global map (a few dozen nodes)
-    if (hb && hd) return launch_bwd1<KT, true, true>(a, st);
-    if (hb) return launch_bwd1<KT, true, false>(a, st);
+  if constexpr (NKT <= 2) {      // the additive graph bias only occurs on the global map (a few dozen nodes)
+    if (hb && hd) return launch_bwd1<KT, NW, NKT, true, true>(a, st);
+    if (hb) return launch_bwd1<KT, NW, NKT, true, false>(a, st);
   }
-  if (hd) return launch_bwd1<KT, false, true>(a, st);
-  return launch_bwd1<KT, false, false>(a, st);
+  if (hd) return launch_bwd1<KT, NW, NKT, false, true>(a, st);
+  return launch_bwd1<KT, NW, NKT, false, false>(a, st);
 }
 
 // The single-pass kernel covers Lk <= 448 (a bias: Lk <= 128) and, with dropout, needs the forward's keep-bit matrix;
@@ -317,8 +353,11 @@ int attn_mfma_bwd1(const AttnArgs& a, hipStream_t st) {
                  ((uintptr_t)a.v % 16) == 0 && ((uintptr_t)a.o % 16) == 0 && ((uintptr_t)a.dout % 16) == 0 &&
                  ((uintptr_t)a.dq % 16) == 0 && ((uintptr_t)a.dk % 16) == 0 && ((uintptr_t)a.dv % 16) == 0,
              "attention bwd (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
-  if (a.Lk <= 64) return dispatch_bwd1<1>(a, st);
-  if (a.Lk <= 128) return dispatch_bwd1<2>(a, st);
-  if (a.Lk <= 256) return dispatch_bwd1<4>(a, st);
-  return dispatch_bwd1<7>(a, st);
+  // BEVBERT_BWD1_WAVES=4 keeps the one-wave-per-SIMD geometry for long key sequences too (A/B measurements)
+  static const bool four = [] { const char* v = getenv("BEVBERT_BWD1_WAVES"); return v && v[0] == '4'; }();
+  if (a.Lk <= 64) return dispatch_bwd1<1, 4, 1>(a, st);
+  if (a.Lk <= 128) return dispatch_bwd1<2, 4, 2>(a, st);
+  if (a.Lk <= 256) return dispatch_bwd1<4, 4, 4>(a, st);
+  if (four) return dispatch_bwd1<7, 4, 7>(a, st);
+  return dispatch_bwd1<4, 8, 7>(a, st);       // 8 waves x 64 keys on a 448-key image: two waves per SIMD
 }

@@ -196,8 +196,9 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
   p.cand.shrink_to_fit();
 }
 
+// Cin: addend of an accumulating plan when it is NOT the output buffer (D = A.B + Cin, beta = 1); null -> in place
 int run_plan(Plan& p, const void* A, const void* B, void* C, const void* bias, float alpha, void* workspace,
-             int64_t workspace_bytes, hipStream_t stream) {
+             int64_t workspace_bytes, hipStream_t stream, const void* Cin = nullptr) {
   if (!p.ok) {
     bb_set_error("gemm: plan %d has no algorithm", p.id);
     return BB_EUNSUPPORTED;
@@ -217,8 +218,8 @@ int run_plan(Plan& p, const void* A, const void* B, void* C, const void* bias, f
     }
   }
   const float beta0 = p.accumulate ? 1.f : 0.f;
-  const hipblasStatus_t st = hipblasLtMatmul(g_handle, p.desc, &alpha, B, p.la, A, p.lb, &beta0, C, p.lc, C, p.lc,
-                                             &p.algo, workspace, workspace_bytes, stream);
+  const hipblasStatus_t st = hipblasLtMatmul(g_handle, p.desc, &alpha, B, p.la, A, p.lb, &beta0, Cin ? Cin : C, p.lc, C,
+                                             p.lc, &p.algo, workspace, workspace_bytes, stream);
   if (st != HIPBLAS_STATUS_SUCCESS) {
     bb_set_error("gemm: hipblasLtMatmul failed with status %d (plan %d)", (int)st, p.id);
     return BB_ELAUNCH;
@@ -255,6 +256,16 @@ BEVBERT_API int bevbert_gemm_run(int plan, const void* A, const void* B, void* C
   std::lock_guard<std::mutex> lock(g_mu);
   BB_REQUIRE(plan >= 0 && plan < (int)g_plan_list.size(), "gemm: unknown plan id %d", plan);
   return run_plan(*g_plan_list[plan], A, B, C, bias, 1.f, workspace, workspace_bytes, stream);
+}
+
+// D = A.B + Cin with an accumulating plan (beta = 1) and a separate addend: the input-gradient GEMM of a Linear whose
+// input also feeds a residual connection folds the residual's gradient in, instead of a separate elementwise add.
+BEVBERT_API int bevbert_gemm_run_add(int plan, const void* A, const void* B, const void* Cin, void* D, const void* bias,
+                                     void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  BB_REQUIRE(plan >= 0 && plan < (int)g_plan_list.size(), "gemm: unknown plan id %d", plan);
+  BB_REQUIRE(g_plan_list[plan]->accumulate && Cin != nullptr, "gemm_run_add: needs an accumulating plan and an addend");
+  return run_plan(*g_plan_list[plan], A, B, D, bias, 1.f, workspace, workspace_bytes, stream, Cin);
 }
 
 // One-shot form: plan (cached by problem) + run.

@@ -84,6 +84,7 @@ _PROTOS = {
     "bevbert_colsum_finalize": [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     "bevbert_dropout_add": [_P, _P, _P, _I64, _I, _I, _F, _U64, _U64, _P],
     "bevbert_gemm_run": [_I, _P, _P, _P, _P, _P, _I64, _P],
+    "bevbert_gemm_run_add": [_I, _P, _P, _P, _P, _P, _P, _I64, _P],
 }
 
 

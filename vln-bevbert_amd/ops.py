@@ -329,7 +329,9 @@ class ReduceQueue:
 
     @classmethod
     def flush(cls, device):
-        """Launch the pending second stages (on the stream C-ABI launches currently go to)."""
+        """Launch the pending second stages (on the stream C-ABI launches currently go to).  Records that accumulate
+        into the SAME output vector (a parameter used twice in one backward: REVERIE's object tokens share
+        img_linear / img_layer_norm with the views) must not run concurrently: they go into successive launches."""
         if not cls.jobs:
             return
         key = tuple(cls.jobs)
@@ -340,8 +342,20 @@ class ReduceQueue:
                 raise lib.BevBertHipError("reduction task table missing during graph capture (warm-up steps build it)")
             if len(cls._tables) > 256:
                 cls._tables.clear()
-            ent = cls._tables[key] = cls._build(key, device)
-        call("bevbert_multi_finalize", ent[0].data_ptr(), ent[1], stream())
+            rounds, seen = [[]], [set()]
+            for job in key:
+                outs = {o for o in job[4:7] if o}
+                r = 0
+                while outs & seen[r]:
+                    r += 1
+                    if r == len(rounds):
+                        rounds.append([])
+                        seen.append(set())
+                rounds[r].append(job)
+                seen[r] |= outs
+            ent = cls._tables[key] = [cls._build(tuple(r), device) for r in rounds]
+        for table, n in ent:
+            call("bevbert_multi_finalize", table.data_ptr(), n, stream())
 
 
 def call(name, *args):
@@ -427,8 +441,9 @@ def save_gemm_tuning_table(path):
     return buf.value.count(b"\n") - 1
 
 
-def _lt_gemm(a, b, out, bias, M, N, K, opA, opB, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, accumulate=0):
-    """out (+)= op(a) . op(b) (+ bias) on hipBLASLt via the C ABI; False if the library has no kernel for the shape."""
+def _lt_gemm(a, b, out, bias, M, N, K, opA, opB, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0, accumulate=0, c_in=None):
+    """out (+)= op(a) . op(b) (+ bias) on hipBLASLt via the C ABI; False if the library has no kernel for the shape.
+    ``c_in`` (with accumulate=1): out = product + c_in, the addend being a separate buffer of out's layout."""
     key = (M, N, K, opA, opB, lda, ldb, ldc, batch, a.dtype, out.dtype, None if bias is None else bias.dtype,
            accumulate)
     plan = _LT_PLANS.get(key)
@@ -446,8 +461,13 @@ def _lt_gemm(a, b, out, bias, M, N, K, opA, opB, lda, ldb, ldc, batch=1, sa=0, s
     if plan in _LT_UNSUPPORTED:
         return False
     st = stream()
-    rc = _LT_RUN(plan, a.data_ptr(), b.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(),
-                 RT.gemm_workspace(a.device, st), _LT_WS_BYTES, st)
+    if c_in is not None:
+        rc = lib.load().bevbert_gemm_run_add(plan, a.data_ptr(), b.data_ptr(), c_in.data_ptr(), out.data_ptr(),
+                                             None if bias is None else bias.data_ptr(),
+                                             RT.gemm_workspace(a.device, st), _LT_WS_BYTES, st)
+    else:
+        rc = _LT_RUN(plan, a.data_ptr(), b.data_ptr(), out.data_ptr(), None if bias is None else bias.data_ptr(),
+                     RT.gemm_workspace(a.device, st), _LT_WS_BYTES, st)
     if rc == -3:
         _LT_UNSUPPORTED.add(plan)
         return False
@@ -488,18 +508,25 @@ def _linear_fwd(x, w_c, b_c):
     return F.linear(x, w_c, b_c)
 
 
-def _linear_dgrad(dy2, w_c):
-    """dx (M x K) = dy2 (M x N) w_c (N x K)."""
+def _linear_dgrad(dy2, w_c, add=None):
+    """dx (M x K) = dy2 (M x N) w_c (N x K) (+ add, an (M x K) tensor folded in as the GEMM's beta = 1 addend)."""
     N, K = w_c.shape
+    if add is not None:
+        add = add.reshape(-1, K)
+        if not add.is_contiguous() or add.dtype != dy2.dtype:
+            add = add.to(dy2.dtype).contiguous()
     if _lt_ok(dy2, w_c) and dy2.dtype == w_c.dtype and w_c.stride(1) == 1 and dy2.numel() > 0:
         d2, lda = _rows(dy2)
         M = d2.shape[0]
         dx = torch.empty(M, K, dtype=dy2.dtype, device=dy2.device)
-        if _lt_gemm(d2, w_c, dx, None, M, K, N, 0, 0, lda, w_c.stride(0), K):
+        if add is None:
+            if _lt_gemm(d2, w_c, dx, None, M, K, N, 0, 0, lda, w_c.stride(0), K):
+                return dx
+        elif _lt_gemm(d2, w_c, dx, None, M, K, N, 0, 0, lda, w_c.stride(0), K, accumulate=1, c_in=add):
             return dx
     if dy2.is_cuda:
         _warn_fallback("dgrad", dy2.shape[0], K, N)
-    return dy2.mm(w_c)
+    return dy2.mm(w_c) if add is None else torch.addmm(add, dy2, w_c)
 
 
 def _linear_wgrad(dy2, x2, S=1):
@@ -808,20 +835,26 @@ class _Linear(torch.autograd.Function):
     """y = x W^T (+ b) on hipBLASLt; backward writes dW / db straight into the gradient arena."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_c, b_c):
+    def forward(ctx, x, weight, bias, w_c, b_c, tap=False):
         y = _gemm("fwd", lambda: _linear_fwd(x, w_c, b_c), x.numel() // x.shape[-1], w_c.shape[0], w_c.shape[1])
         ctx.save_for_backward(x, w_c)
         ctx.params = (weight, bias)
-        return y
+        ctx.tap = tap
+        # tap: the input ALSO feeds a residual connection.  It is handed back as a second output, so that the residual's
+        # gradient arrives HERE and is folded into the input-gradient GEMM (dx = dy W + d_res, beta = 1) -- autograd would
+        # otherwise add the two gradients of x with a separate elementwise kernel (~50 of them per training step)
+        return (y, x.view_as(x)) if tap else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, w_c = ctx.saved_tensors
         weight, bias = ctx.params
+        if dy is None:                      # only the residual tap carried a gradient
+            return dres, None, None, None, None, None
         dy2 = dy.reshape(-1, dy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         M, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
-        dx = _gemm("dgrad", lambda: _linear_dgrad(dy2, w_c), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = _gemm("dgrad", lambda: _linear_dgrad(dy2, w_c, dres), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
         gw = gb = None
         w_sink = _sink(weight) if weight.requires_grad else None
         b_sink = _sink(bias) if (bias is not None and bias.requires_grad) else None
@@ -851,7 +884,7 @@ class _Linear(torch.autograd.Function):
             if b_sink is not None:
                 _mark_touched(bias)
             WgradStream.submit(dy.device, lambda: _param_grads(w_sink, b_sink, dyc, xc), dyc, xc, dy)
-        return dx, gw, gb, None, None
+        return dx, gw, gb, None, None, None
 
 
 def linear(x, weight, bias=None, w_c=None, b_c=None):
@@ -861,6 +894,14 @@ def linear(x, weight, bias=None, w_c=None, b_c=None):
     if bias is not None and b_c is None:
         b_c = _compute(bias)
     return _Linear.apply(x, weight, bias, w_c, b_c)
+
+
+def linear_res(x, weight, bias=None):
+    """(linear(x), x) for an input that also feeds a residual connection: use the SECOND output as the residual and
+    the gradient of the residual branch is folded into this layer's input-gradient GEMM (see _Linear.forward)."""
+    if not (x.requires_grad and torch.is_grad_enabled()):
+        return linear(x, weight, bias), x
+    return _Linear.apply(x, weight, bias, _compute(weight), None if bias is None else _compute(bias), True)
 
 
 class _PackedParam:
@@ -879,20 +920,23 @@ class _PackedParam:
 
 class _LinearPacked(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pw, pb):
+    def forward(ctx, x, pw, pb, tap=False):
         ctx.save_for_backward(x)
         ctx.packed = (pw, pb)
-        return _gemm("fwd", lambda: _linear_fwd(x, pw.compute, pb.compute), x.numel() // x.shape[-1],
-                     pw.compute.shape[0], pw.compute.shape[1])
+        y = _gemm("fwd", lambda: _linear_fwd(x, pw.compute, pb.compute), x.numel() // x.shape[-1],
+                  pw.compute.shape[0], pw.compute.shape[1])
+        return (y, x.view_as(x)) if tap else y          # residual tap: see _Linear.forward
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         (x,) = ctx.saved_tensors
         pw, pb = ctx.packed
+        if dy is None:
+            return dres, None, None, None
         dy2 = dy.reshape(-1, dy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         M, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
-        dx = _gemm("dgrad", lambda: _linear_dgrad(dy2, pw.compute), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = _gemm("dgrad", lambda: _linear_dgrad(dy2, pw.compute, dres), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
         if pw.requires_grad:
             pw.touch()
             pb.touch()
@@ -900,11 +944,18 @@ class _LinearPacked(torch.autograd.Function):
             dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
             xc = x2 if x2.is_contiguous() else x2.contiguous()
             WgradStream.submit(dy.device, lambda: _param_grads(pw.main_grad, pb.main_grad, dyc, xc), dyc, xc, dy)
-        return dx, None, None
+        return dx, None, None, None
 
 
 def linear_packed(x, pw, pb):
     return _LinearPacked.apply(x, pw, pb)
+
+
+def linear_packed_res(x, pw, pb):
+    """(packed projection of x, x as residual tap) -- see linear_res."""
+    if not (x.requires_grad and torch.is_grad_enabled()):
+        return _LinearPacked.apply(x, pw, pb), x
+    return _LinearPacked.apply(x, pw, pb, True)
 
 
 # ----------------------------------------------------------------------------- K2 attention

@@ -87,8 +87,10 @@ class BertSelfAttention(_Finalizable):
                 [f"{prefix}{k}.bias" for k in ("query", "key", "value")]]
 
     def forward(self, hidden_states, key_mask, bias=None):
-        qkv = ops.linear_packed(hidden_states, self.pw, self.pb)
-        return ops.attention_self(qkv, key_mask, bias, self.num_attention_heads, self.drop_p, self.training)
+        """Returns (attention output, hidden_states as residual tap): the caller adds the tap as its residual, and the
+        residual's gradient is folded into the QKV projection's input-gradient GEMM (ops.linear_res)."""
+        qkv, res = ops.linear_packed_res(hidden_states, self.pw, self.pb)
+        return ops.attention_self(qkv, key_mask, bias, self.num_attention_heads, self.drop_p, self.training), res
 
 
 class BertSelfOutput(nn.Module):
@@ -112,7 +114,8 @@ class BertAttention(nn.Module):
         self.output = BertSelfOutput(config)
 
     def forward(self, input_tensor, key_mask, bias=None):
-        return self.output(self.self(input_tensor, key_mask, bias), input_tensor)
+        a, res = self.self(input_tensor, key_mask, bias)
+        return self.output(a, res)
 
 
 class BertIntermediate(nn.Module):
@@ -122,7 +125,9 @@ class BertIntermediate(nn.Module):
         assert config.hidden_act == "gelu", "the path is specialised for erf-GELU (configs/*_model.json)"
 
     def forward(self, hidden_states):
-        return ops.bias_gelu(ops.linear(hidden_states, self.dense.weight), self.dense.bias)
+        """Returns (gelu(dense(x)), x as residual tap) -- BertOutput adds the tap (vilmodel.py:168-193)."""
+        h, res = ops.linear_res(hidden_states, self.dense.weight)
+        return ops.bias_gelu(h, self.dense.bias), res
 
 
 class BertOutput(nn.Module):
@@ -148,7 +153,7 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden_states, key_mask):
         a = self.attention(hidden_states, key_mask)
-        return self.output(self.intermediate(a), a)
+        return self.output(*self.intermediate(a))
 
 
 class BertPredictionHeadTransform(nn.Module):
@@ -207,9 +212,10 @@ class BertOutAttention(_Finalizable):
         return [[f"{prefix}key.weight", f"{prefix}value.weight"], [f"{prefix}key.bias", f"{prefix}value.bias"]]
 
     def forward(self, hidden_states, context, key_mask=None):
-        q = ops.linear(hidden_states, self.query.weight, self.query.bias)
+        """Returns (attention output, hidden_states as residual tap)."""
+        q, res = ops.linear_res(hidden_states, self.query.weight, self.query.bias)
         kv = ops.linear_packed(context, self.pw, self.pb)
-        return ops.attention_cross(q, kv, key_mask, self.num_attention_heads, self.drop_p, self.training)
+        return ops.attention_cross(q, kv, key_mask, self.num_attention_heads, self.drop_p, self.training), res
 
 
 class BertXAttention(nn.Module):
@@ -219,7 +225,8 @@ class BertXAttention(nn.Module):
         self.output = BertSelfOutput(config)
 
     def forward(self, input_tensor, ctx_tensor, ctx_key_mask=None):
-        return self.output(self.att(input_tensor, ctx_tensor, ctx_key_mask), input_tensor)
+        a, res = self.att(input_tensor, ctx_tensor, ctx_key_mask)
+        return self.output(a, res)
 
 
 class GraphLXRTXLayer(nn.Module):
@@ -239,16 +246,16 @@ class GraphLXRTXLayer(nn.Module):
     def forward(self, lang_feats, lang_key_mask, visn_feats, visn_key_mask, graph_sprels=None):
         a = self.visual_attention(visn_feats, lang_feats, lang_key_mask)
         a = self.visn_self_att(a, visn_key_mask, graph_sprels)
-        return self.visn_output(self.visn_inter(a), a)
+        return self.visn_output(*self.visn_inter(a))
 
     def forward_lang2visn(self, lang_feats, lang_key_mask, visn_feats, visn_key_mask):
         a = self.visual_attention(lang_feats, visn_feats, visn_key_mask)
         a = self.lang_self_att(a, lang_key_mask)
-        return self.lang_output(self.lang_inter(a), a)
+        return self.lang_output(*self.lang_inter(a))
 
     def forward_visn2visn(self, visn_feats, visn_key_mask):
         a = self.visn_self_att(visn_feats, visn_key_mask)
-        return self.visn_output(self.visn_inter(a), a)
+        return self.visn_output(*self.visn_inter(a))
 
 
 class LanguageEncoder(nn.Module):
