@@ -5,10 +5,10 @@
 // are VALU-bound.  Here a workgroup owns ALL keys of one (batch, head) (Lk <= 64 * KT <= 448: the 21x21 BEV has 441 cells):
 //
 //   * NW waves; wave w owns the 16*KT keys [w*16*KT, (w+1)*16*KT): its V fragments (B operand of dP) and its dK^T / dV^T
-//     accumulators [64 d][16*KT keys] stay in registers for the whole kernel.  Two geometries: NW = 4 (one wave per
-//     SIMD, up to 112 keys per wave) for short key sequences, and NW = 8 x 64 keys (two waves per SIMD, 160 accumulator
-//     + operand registers per wave) for the 441-cell BEV: the single-wave form spends 57 % of its wave cycles parked in
-//     s_waitcnt (profiles/r02a_pmc_attn_sq_counters.txt) -- a second resident wave per SIMD fills those slots;
+//     accumulators [64 d][16*KT keys] stay in registers for the whole kernel.  Default geometry: NW = 4, one wave per
+//     SIMD with the whole 512-entry register file (KT = 7: 224 accumulator + 56 operand registers).  An NW = 8 x 64-key
+//     form (two waves per SIMD) exists behind BEVBERT_BWD1_WAVES=8; it has to re-read every fragment per key tile to fit
+//     256 registers and measured slower;
 //   * K is staged once, row-major, in LDS: B operand of S = Q K^T by plain 16-byte reads, and -- through the
 //     transposing LDS read of gfx950 (ds_read_b64_tr_b16) -- the K^T A operand of dQ^T = K^T dS^T from the SAME image;
 //   * loop over 64-query tiles: S and dP on the matrix cores, then ONE pass of softmax-backward arithmetic per score
@@ -38,7 +38,7 @@ template <int NKT> struct B1Lds {
 };
 
 // KT: 16-key tiles per wave; NW: waves per workgroup (4 or 8); NKT: 64-key tiles of the workgroup (LDS images)
-template <int KT, int NW, int NKT, bool BIAS, bool DROP>
+template <int KT, int NW, int NKT, bool BIAS, bool DROP, bool EARLY>
 __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) void attn_mfma_bwd1_kernel(AttnArgs a) {
   typedef B1Lds<NKT> L;
   constexpr int NT = 64 * NW;             // threads
@@ -159,8 +159,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
 
   for (int q0 = 0; q0 < a.Lq; q0 += TK) {
     // ================= phase 1: S, dP, softmax backward, dK^T / dV^T, dS -> LDS =================
+    const bool more = q0 + TK < a.Lq;
 #pragma unroll 1
     for (int m = 0; m < (has_keys ? 2 : 0); ++m) {       // halves of 32 queries: query tiles t = 2m, 2m + 1
+      // EARLY: the next tile's global loads go out under the second half of this tile's arithmetic (~10^4 cycles of
+      // cover for an HBM round trip) instead of under the short dQ phase
+      if (EARLY && m == 1 && more) tile_issue(q0 + TK);
       bf16x8 qa[2][2], da[2][2], qtf[HOLD ? 4 : 1], dotf[HOLD ? 4 : 1];
       float lv[2][4], ndl[2][4];
       auto load_rows = [&]() {          // A operands of S / dP (rows of this half's two query tiles) and their statistics
@@ -261,15 +265,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
     __syncthreads();   // dS image complete; nobody reads s_q / s_do / stats / bits of this tile any more
 
     // ================= phase 2: next tile's loads in flight, dQ^T = K^T dS^T for d rows 16 w .. 16 w + 15 =================
-    const bool more = q0 + TK < a.Lq;
-    if (more) tile_issue(q0 + TK);
+    if (more && !(EARLY && has_keys)) tile_issue(q0 + TK);
     // NW = 4: wave w -> d rows 16 w .. +15, all four query tiles;  NW = 8: d rows 16 (w & 3), query tiles 2 (w >> 2), +1
     constexpr int NQT = (NW == 4) ? 4 : 2;
     const int dq_d0 = 16 * (w & 3), dq_qt0 = (NW == 4) ? 0 : 2 * (w >> 2);
     f32x4 dqacc[NQT];
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) dqacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll 4
     for (int ks = 0; ks < 2 * NKT; ++ks) {         // k-steps of 32 keys
       const bf16x8 ka = lds_frag_tr(s_k, LDT, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, dq_d0, lane);
 #pragma unroll
@@ -318,13 +321,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
 // =============================================================================================
 // launcher
 // =============================================================================================
-template <int KT, int NW, int NKT, bool B_, bool D_>
+template <int KT, int NW, int NKT, bool B_, bool D_, bool E_ = false>
 static int launch_bwd1(const AttnArgs& a, hipStream_t st) {
   typedef B1Lds<NKT> L;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd1_kernel<KT, NW, NKT, B_, D_>),
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd1_kernel<KT, NW, NKT, B_, D_, E_>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes) == hipSuccess;
   BB_REQUIRE(ok, "attention bwd (single pass): cannot raise the dynamic LDS limit to %d bytes", L::bytes);
-  hipLaunchKernelGGL((attn_mfma_bwd1_kernel<KT, NW, NKT, B_, D_>), dim3((unsigned)a.B * a.nh), dim3(64 * NW), L::bytes,
+  hipLaunchKernelGGL((attn_mfma_bwd1_kernel<KT, NW, NKT, B_, D_, E_>), dim3((unsigned)a.B * a.nh), dim3(64 * NW), L::bytes,
                      st, a);
   BB_CHECK_LAUNCH("attn_bwd(single pass)");
   return BB_OK;
@@ -336,6 +339,14 @@ static int dispatch_bwd1(const AttnArgs& a, hipStream_t st) {
   if constexpr (NKT <= 2) {      // the additive graph bias only occurs on the global map (a few dozen nodes)
     if (hb && hd) return launch_bwd1<KT, NW, NKT, true, true>(a, st);
     if (hb) return launch_bwd1<KT, NW, NKT, true, false>(a, st);
+  }
+  // BEVBERT_BWD1_EARLY=0/1: where the next query tile's global loads are issued (A/B knob; default: early for KT = 7)
+  static const int early = [] { const char* v = getenv("BEVBERT_BWD1_EARLY"); return v ? (v[0] == '1') : -1; }();
+  if constexpr (KT == 7) {
+    if (early != 0) {
+      if (hd) return launch_bwd1<KT, NW, NKT, false, true, true>(a, st);
+      return launch_bwd1<KT, NW, NKT, false, false, true>(a, st);
+    }
   }
   if (hd) return launch_bwd1<KT, NW, NKT, false, true>(a, st);
   return launch_bwd1<KT, NW, NKT, false, false>(a, st);
@@ -353,11 +364,13 @@ int attn_mfma_bwd1(const AttnArgs& a, hipStream_t st) {
                  ((uintptr_t)a.v % 16) == 0 && ((uintptr_t)a.o % 16) == 0 && ((uintptr_t)a.dout % 16) == 0 &&
                  ((uintptr_t)a.dq % 16) == 0 && ((uintptr_t)a.dk % 16) == 0 && ((uintptr_t)a.dv % 16) == 0,
              "attention bwd (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
-  // BEVBERT_BWD1_WAVES=4 keeps the one-wave-per-SIMD geometry for long key sequences too (A/B measurements)
-  static const bool four = [] { const char* v = getenv("BEVBERT_BWD1_WAVES"); return v && v[0] == '4'; }();
+  // BEVBERT_BWD1_WAVES=8: 8 waves x 64 keys (two waves per SIMD, no fragments held in registers) instead of 4 x 112.
+  // Measured on the BEV shape (B = 64, 441 x 441, p = 0.1, same box): 303 us vs 262 us -- the re-read fragments cost more
+  // LDS time than the second wave hides, so one wave per SIMD is the default.
+  static const bool eight = [] { const char* v = getenv("BEVBERT_BWD1_WAVES"); return v && v[0] == '8'; }();
   if (a.Lk <= 64) return dispatch_bwd1<1, 4, 1>(a, st);
   if (a.Lk <= 128) return dispatch_bwd1<2, 4, 2>(a, st);
   if (a.Lk <= 256) return dispatch_bwd1<4, 4, 4>(a, st);
-  if (four) return dispatch_bwd1<7, 4, 7>(a, st);
-  return dispatch_bwd1<4, 8, 7>(a, st);       // 8 waves x 64 keys on a 448-key image: two waves per SIMD
+  if (eight) return dispatch_bwd1<4, 8, 7>(a, st);
+  return dispatch_bwd1<7, 4, 7>(a, st);
 }
