@@ -120,6 +120,10 @@ int bevbert_colsum_finalize(const float* partials, int nblocks, int nwhich, int 
  * out[c] (+)= sum_b partials[b * row_stride + col0 + c], c < ncols <= 64, fixed summation order (deterministic). */
 int bevbert_colsum_partials(const void* dy, float* partials, int rows, int C, int dtype, hipStream_t stream);
 int bevbert_multi_finalize(const void* tasks, int ntasks, hipStream_t stream);
+/* Batched bevbert_accum_partials: `tasks` = device array of 40-byte records
+ * {u64 partials, u64 sink, u64 n4_total, u32 off4, u32 n4, i32 S, i32 dtype}: for the n4 float4 groups starting at
+ * off4, sink[i] += sum_{s < S} partials[s * n4_total + off4 + i] (sink already points at the range's first element). */
+int bevbert_multi_accum(const void* tasks, int ntasks, hipStream_t stream);
 
 /* K5  BertEmbeddings.forward (vilmodel.py:62-77): y = LayerNorm(word[ids] + pos[row % L] + type_row) (+dropout). */
 int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const void* pos, const void* type_row,

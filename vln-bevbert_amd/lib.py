@@ -76,6 +76,7 @@ _PROTOS = {
     "bevbert_set_step_salt": [_P],
     "bevbert_colsum_partials": [_P, _P, _I, _I, _I, _P],
     "bevbert_multi_finalize": [_P, _I, _P],
+    "bevbert_multi_accum": [_P, _I, _P],
     "bevbert_cast_f32": [_P, _P, _I64, _I, _P],
     "bevbert_accum_partials": [_P, _P, _I, _I64, _I, _P],
     "bevbert_dropout_keep_mask": [_P, _I64, _F, _U64, _U64, _P],

@@ -230,7 +230,7 @@ class WgradStream:
     def flush_all(cls):
         """Issue everything deferred so far, then -- in one launch -- the pending second stages of the column
         reductions (ReduceQueue): their first stages were enqueued on the producing streams before this call."""
-        if ReduceQueue.jobs:
+        if ReduceQueue.jobs or ReduceQueue.accum_jobs:
             dev = torch.device("cuda", torch.cuda.current_device())
             if cls.active(dev):
                 h = lib.stream()
@@ -281,8 +281,15 @@ class ScratchRing:
         self.off += n
         return p
 
+    def tensor(self, shape, dtype, device):
+        """A tensor view of freshly bumped ring memory (for operands that go through tensor-typed call paths)."""
+        nbytes = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+        p = self.alloc(nbytes, device)
+        o = p - self.base
+        return self.buf[o:o + nbytes].view(dtype).view(shape)
 
-SCRATCH = ScratchRing(int(_os.environ.get("BEVBERT_SCRATCH_MB", "1024")) << 20)
+
+SCRATCH = ScratchRing(int(_os.environ.get("BEVBERT_SCRATCH_MB", "6144")) << 20)      # ~2.5 GB / step at batch 64
 
 
 class ReduceQueue:
@@ -294,8 +301,38 @@ class ReduceQueue:
     is built once and kept on the device (the records hold raw pointers; ScratchRing makes them repeat)."""
 
     jobs = []
+    accum_jobs = []
     _tables = {}
+    _accum_tables = {}
     _dtype = None
+    _adtype = None
+
+    @classmethod
+    def add_accum(cls, partials_ptr, sink_ptr, S, n, dtype):
+        """sink[0:n] += sum of the S partial slices at partials_ptr (split-K weight-gradient products)."""
+        cls.accum_jobs.append((partials_ptr, sink_ptr, S, n, dtype))
+
+    @classmethod
+    def _build_accum(cls, jobs, device):
+        import numpy as np
+        if cls._adtype is None:
+            cls._adtype = np.dtype([("partials", "<u8"), ("sink", "<u8"), ("n4_total", "<u8"), ("off4", "<u4"),
+                                    ("n4", "<u4"), ("S", "<i4"), ("dtype", "<i4")])
+        parts = []
+        for partials_ptr, sink_ptr, S, n, dt in jobs:
+            n4 = n // 4
+            off = np.arange(0, n4, 4096, dtype=np.int64)
+            t = np.zeros(len(off), dtype=cls._adtype)
+            t["partials"] = partials_ptr
+            t["sink"] = sink_ptr + off * 16
+            t["n4_total"] = n4
+            t["off4"] = off
+            t["n4"] = np.minimum(4096, n4 - off)
+            t["S"] = S
+            t["dtype"] = dt
+            parts.append(t)
+        table = np.concatenate(parts) if parts else np.zeros(0, dtype=cls._adtype)
+        return torch.from_numpy(table.view(np.uint8).copy()).to(device), len(table)
 
     @classmethod
     def add(cls, partials_ptr, nblocks, nwhich, C, outs, accumulate=1):
@@ -332,6 +369,28 @@ class ReduceQueue:
         """Launch the pending second stages (on the stream C-ABI launches currently go to).  Records that accumulate
         into the SAME output vector (a parameter used twice in one backward: REVERIE's object tokens share
         img_linear / img_layer_norm with the views) must not run concurrently: they go into successive launches."""
+        if cls.accum_jobs:
+            akey = tuple(cls.accum_jobs)
+            cls.accum_jobs = []
+            aent = cls._accum_tables.get(akey)
+            if aent is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise lib.BevBertHipError("accumulate task table missing during graph capture (warm-up steps build it)")
+                if len(cls._accum_tables) > 256:
+                    cls._accum_tables.clear()
+                rounds, seen = [[]], [set()]
+                for job in akey:                      # a weight used twice in one backward: successive launches
+                    r = 0
+                    while job[1] in seen[r]:
+                        r += 1
+                        if r == len(rounds):
+                            rounds.append([])
+                            seen.append(set())
+                    rounds[r].append(job)
+                    seen[r].add(job[1])
+                aent = cls._accum_tables[akey] = [cls._build_accum(tuple(r), device) for r in rounds]
+            for table, n in aent:
+                call("bevbert_multi_accum", table.data_ptr(), n, stream())
         if not cls.jobs:
             return
         key = tuple(cls.jobs)
@@ -529,15 +588,18 @@ def _linear_dgrad(dy2, w_c, add=None):
     return dy2.mm(w_c) if add is None else torch.addmm(add, dy2, w_c)
 
 
-def _linear_wgrad(dy2, x2, S=1):
-    """(S x) N x K partial products dy2^T x2 over S equal chunks of the token axis (compute dtype)."""
+def _linear_wgrad(dy2, x2, S=1, scratch=False):
+    """(S x) N x K partial products dy2^T x2 over S equal chunks of the token axis (compute dtype); ``scratch``: the
+    product lives in the scratch ring (it is consumed by the batched accumulate at the end of the backward pass)."""
     M, N = dy2.shape
     K = x2.shape[1]
     if _lt_ok(dy2, x2) and dy2.dtype == x2.dtype and M > 0:
         d2, lda = _rows(dy2)
         xx, ldb = _rows(x2)
         if S == 1 or (lda == N and ldb == K):
-            part = torch.empty((S, N, K) if S > 1 else (N, K), dtype=dy2.dtype, device=dy2.device)
+            shape = (S, N, K) if S > 1 else (N, K)
+            part = SCRATCH.tensor(shape, dy2.dtype, dy2.device) if scratch else \
+                torch.empty(shape, dtype=dy2.dtype, device=dy2.device)
             Ms = M // S
             if _lt_gemm(d2, xx, part, None, N, K, Ms, 1, 0, lda, ldb, K, S, Ms * lda, Ms * ldb, N * K):
                 return part
@@ -586,7 +648,12 @@ def _wgrad_into(sink, dy2, x2):
     S = _split_k(M, N, K) if dy2.dtype != torch.float32 else 1
     if not (S > 1 and dy2.is_contiguous() and x2.is_contiguous()):
         S = 1
-    part = _gemm("wgrad", lambda: _linear_wgrad(dy2, x2, S), N, K, M)
+    batched = WgradStream.DEFER_FINALIZE and (N * K) % 4 == 0 and dy2.is_cuda
+    part = _gemm("wgrad", lambda: _linear_wgrad(dy2, x2, S, scratch=batched), N, K, M)
+    if batched:           # folded into the arena by ONE launch per backward pass, together with every other weight's
+        ReduceQueue.add_accum(part.data_ptr(), sink.data_ptr(), S, N * K, dtype_code(part))
+        WgradStream._keep.append(part)     # (a product that came from torch's fallback GEMM must outlive the flush)
+        return None
     if (N * K) % 4 == 0:
         call("bevbert_accum_partials", ptr(part), ptr(sink), S, N * K, dtype_code(part), stream())
     else:
