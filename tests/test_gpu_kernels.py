@@ -495,11 +495,15 @@ def test_lt_gemm_split_k_wgrad_into_sink(ops):
     sink = torch.ones(N, K, device=DEV)
     assert ops._split_k(M, N, K) > 1
     ops._wgrad_into(sink, dy, x)
+    ops.WgradStream.flush_all()          # the fold into the sink is batched with the step's other pending reductions
     ref = 1.0 + dy.double().t() @ x.double()
     assert rel_err(sink, ref) < 1e-2
     sink32 = torch.ones(N, K, device=DEV)
     ops._wgrad_into(sink32, dy.float(), x.float())
-    assert rel_err(sink32, 1.0 + dy.float().double().t() @ x.float().double()) < 1e-4
+    ops._wgrad_into(sink32, dy.float(), x.float())      # the same sink twice in one pass: successive launches, no race
+    ops.WgradStream.flush_all()
+    torch.cuda.synchronize()
+    assert rel_err(sink32, 1.0 + 2 * (dy.float().double().t() @ x.float().double())) < 1e-4
 
 
 @pytest.mark.parametrize("in_dtype,out_dtype", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),

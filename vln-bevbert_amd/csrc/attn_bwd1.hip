@@ -191,12 +191,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
           dotf[dt] = lds_frag_tr(s_do, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane);
         }
       }
+      // K fragments (B operand of S) and keep-bit words of a key tile are fetched from LDS one tile AHEAD, behind the
+      // matrix instructions of the current tile and in front of its ~100 VALU instructions: with one wave per SIMD an
+      // LDS round trip placed right before its first use is fully exposed (57 % of the wave cycles of the first version
+      // of this kernel were s_waitcnt time, profiles/r02a_pmc_attn_sq_counters.txt)
+      auto bits_of = [&](int t, int ktg) -> uint2 {
+        // word (q16 = t, k64 = ktg >> 2, t' = ktg & 3, r' = c & 3), bits 16 (c >> 2) + 4 g + r
+        return s_bits[((t * NKT + (ktg >> 2)) * 4 + (ktg & 3)) * 4 + (c & 3)];
+      };
+      bf16x8 kf0 = lds_frag_rows(s_k, w * KT, 0, lane), kf1 = lds_frag_rows(s_k, w * KT, 1, lane);
+      uint2 wdc[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+      if (DROP) { wdc[0] = bits_of(2 * m, w * KT); wdc[1] = bits_of(2 * m + 1, w * KT); }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         const int ktg = w * KT + kt;                 // 16-key tile index within the (batch, head)
         if (!HOLD) load_rows();                      // two waves per SIMD: re-read per key tile, keep the registers free
         f32x4 sacc[2], dpacc[2];
-        const bf16x8 kf0 = lds_frag_rows(s_k, ktg, 0, lane), kf1 = lds_frag_rows(s_k, ktg, 1, lane);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           sacc[tt] = mfma16(qa[tt][0], kf0, (f32x4){0.f, 0.f, 0.f, 0.f});
@@ -204,15 +214,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
           dpacc[tt] = mfma16(da[tt][0], vf[kt][0], (f32x4){0.f, 0.f, 0.f, 0.f});
           dpacc[tt] = mfma16(da[tt][1], vf[kt][1], dpacc[tt]);
         }
+        const uint2 wd0 = wdc[0], wd1 = wdc[1];
+        if (kt + 1 < KT) {
+          kf0 = lds_frag_rows(s_k, ktg + 1, 0, lane);
+          kf1 = lds_frag_rows(s_k, ktg + 1, 1, lane);
+          if (DROP) { wdc[0] = bits_of(2 * m, ktg + 1); wdc[1] = bits_of(2 * m + 1, ktg + 1); }
+          __builtin_amdgcn_sched_barrier(0);         // keep the prefetch HERE (the scheduler would sink it to its use)
+        }
         // lane (key = key0 + 16 kt + c) holds S[q = q0 + 16 t + 4 g + r][key], r = 0..3
         const float mk = mask2[kt];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * m + tt;
           uint32_t nib = 0xfu;
-          if (DROP) {
-            // keep bits of the forward: word (q16 = t, k64 = ktg >> 2, t' = ktg & 3, r' = c & 3), bits 16 (c >> 2) + 4 g + r
-            const uint2 wd = s_bits[((t * NKT + (ktg >> 2)) * 4 + (ktg & 3)) * 4 + (c & 3)];
+          if (DROP) {     // keep bits of the forward (prefetched above)
+            const uint2 wd = tt == 0 ? wd0 : wd1;
             nib = (bits_hi ? wd.y : wd.x) >> bits_sh;
           }
 #pragma unroll
