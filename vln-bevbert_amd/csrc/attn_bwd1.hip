@@ -43,7 +43,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
   typedef B1Lds<NKT> L;
   constexpr int NT = 64 * NW;             // threads
   constexpr int CPT = 512 / NT;           // 16-byte chunks of a [64][64] bf16 tile per thread (2 or 1)
-  constexpr bool HOLD = (NW == 4);        // keep the Q^T / dO^T fragments of a half in registers across the key tiles
+  constexpr bool HOLD = (NW == 4 && KT >= 4);   // keep the fragments of a half in registers across the key tiles
+  //                                             (short key sequences: two workgroups per CU matter more than LDS reads)
   extern __shared__ __attribute__((aligned(16))) unsigned char b1_smem[];
   bf16_raw* const s_q = reinterpret_cast<bf16_raw*>(b1_smem + L::q_off);
   bf16_raw* const s_do = reinterpret_cast<bf16_raw*>(b1_smem + L::do_off);
@@ -87,14 +88,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
       dkacc[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dvacc[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-
-  // ---- K -> LDS (row-major, zero rows beyond Lk), once
-  for (int c16 = tid; c16 < L::NK * 8; c16 += NT) {
-    const int row = c16 >> 3, ch = c16 & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < a.Lk) v = ld_frag_global(kp, a.ldk, row, ch * 8);
-    *reinterpret_cast<uint4*>(s_k + row * LDT + ch * 8) = v;
-  }
 
   // ---- staging of one 64-query tile: Q, dO rows -> LDS; delta = rowsum(dO * O); lse; keep bits
   // thread t owns 16-byte chunks ch = t and t + 256: row ch >> 3, dims 8 (ch & 7) .. +7; a row is covered by 8 lanes
@@ -153,7 +146,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
       }
     }
   };
+  // ---- prologue: the first query tile's loads and ALL of K go out together (one memory round trip, not two);
+  //      K -> LDS row-major, zero rows beyond Lk
   tile_issue(0);
+  {
+    constexpr int KCH = L::NK * 8 / NT;         // 16-byte chunks of K per thread
+    uint4 kbuf[KCH];
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int c16 = tid + i * NT, row = c16 >> 3, ch = c16 & 7;
+      kbuf[i] = make_uint4(0, 0, 0, 0);
+      if (row < a.Lk) kbuf[i] = ld_frag_global(kp, a.ldk, row, ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int c16 = tid + i * NT, row = c16 >> 3, ch = c16 & 7;
+      *reinterpret_cast<uint4*>(s_k + row * LDT + ch * 8) = kbuf[i];
+    }
+  }
   tile_commit();
   __syncthreads();
 
@@ -162,9 +172,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
     const bool more = q0 + TK < a.Lq;
 #pragma unroll 1
     for (int m = 0; m < (has_keys ? 2 : 0); ++m) {       // halves of 32 queries: query tiles t = 2m, 2m + 1
-      // EARLY: the next tile's global loads go out under the second half of this tile's arithmetic (~10^4 cycles of
-      // cover for an HBM round trip) instead of under the short dQ phase
-      if (EARLY && m == 1 && more) tile_issue(q0 + TK);
+      // EARLY: the next tile's global loads go out under this tile's arithmetic (KT = 7: under its second half, the
+      // registers are full before) instead of under the short dQ phase
+      if (EARLY && m == (KT == 7 ? 1 : 0) && more) tile_issue(q0 + TK);
       bf16x8 qa[2][2], da[2][2], qtf[HOLD ? 4 : 1], dotf[HOLD ? 4 : 1];
       float lv[2][4], ndl[2][4];
       auto load_rows = [&]() {          // A operands of S / dP (rows of this half's two query tiles) and their statistics
@@ -352,20 +362,20 @@ static int launch_bwd1(const AttnArgs& a, hipStream_t st) {
 template <int KT, int NW, int NKT>
 static int dispatch_bwd1(const AttnArgs& a, hipStream_t st) {
   const bool hb = a.bias != nullptr, hd = a.drop_p > 0.f;
+  // BEVBERT_BWD1_EARLY=0: issue the next query tile's loads only in the dQ phase (A/B knob for the 448-key form)
+  static const bool late = [] { const char* v = getenv("BEVBERT_BWD1_EARLY"); return v && v[0] == '0'; }();
   if constexpr (NKT <= 2) {      // the additive graph bias only occurs on the global map (a few dozen nodes)
-    if (hb && hd) return launch_bwd1<KT, NW, NKT, true, true>(a, st);
-    if (hb) return launch_bwd1<KT, NW, NKT, true, false>(a, st);
+    if (hb && hd) return launch_bwd1<KT, NW, NKT, true, true, true>(a, st);
+    if (hb) return launch_bwd1<KT, NW, NKT, true, false, true>(a, st);
   }
-  // BEVBERT_BWD1_EARLY=0/1: where the next query tile's global loads are issued (A/B knob; default: early for KT = 7)
-  static const int early = [] { const char* v = getenv("BEVBERT_BWD1_EARLY"); return v ? (v[0] == '1') : -1; }();
   if constexpr (KT == 7) {
-    if (early != 0) {
-      if (hd) return launch_bwd1<KT, NW, NKT, false, true, true>(a, st);
-      return launch_bwd1<KT, NW, NKT, false, false, true>(a, st);
+    if (late) {
+      if (hd) return launch_bwd1<KT, NW, NKT, false, true, false>(a, st);
+      return launch_bwd1<KT, NW, NKT, false, false, false>(a, st);
     }
   }
-  if (hd) return launch_bwd1<KT, NW, NKT, false, true>(a, st);
-  return launch_bwd1<KT, NW, NKT, false, false>(a, st);
+  if (hd) return launch_bwd1<KT, NW, NKT, false, true, true>(a, st);
+  return launch_bwd1<KT, NW, NKT, false, false, true>(a, st);
 }
 
 // The single-pass kernel covers Lk <= 448 (a bias: Lk <= 128) and, with dropout, needs the forward's keep-bit matrix;

@@ -13,9 +13,9 @@
 //   O^T = V^T P^T (A = V^T tile rows from LDS, B = P packed to bf16 straight from the S accumulators)
 // The contraction index of the second product is *defined* as  k-slot (g, j) <-> key 16 (2m + (j>>2)) + 4 g + (j&3)
 // for both operands, which is exactly the order the S accumulators already have: P never moves between lanes and
-// never touches LDS.  K tiles are staged row-major [key][d]; V tiles are staged transposed [d][key] so the A
-// fragments of the second product are two 8-byte LDS reads.  Row stride 72 bf16 (144 B) keeps 16-byte reads of 16
-// consecutive rows on distinct banks.
+// never touches LDS.  K and V tiles are staged row-major [key][d]; the V^T A fragments of the second product are two
+// transposing 8-byte LDS reads (ds_read_b64_tr_b16) of the row-major V tile -- the forward stores no transposed image.
+// Row stride 72 bf16 (144 B) keeps 16-byte reads of 16 consecutive rows on distinct banks.
 #include "attn_mfma_common.h"
 
 // =============================================================================================
@@ -25,7 +25,7 @@ template <int QT, bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
   // double-buffered tiles: while tile j is consumed from buffer j&1, tile j+1 is written to the other one
   __shared__ __attribute__((aligned(16))) bf16_raw s_k[2][TK * LDT];
-  __shared__ __attribute__((aligned(16))) bf16_raw s_vt[2][ATTN_D * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_v[2][TK * LDT];      // row-major; the V^T operand comes out of it by transposing reads
   __shared__ __attribute__((aligned(16))) float s_mask[2][TK];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
   int blk, h, b;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
   tile_load(vreg, vp, a.ldv, 0, a.Lk, tid);
   mreg = mask_of(0);
   tile_store_rows(s_k[0], kreg, tid);
-  tile_store_cols(s_vt[0], vreg, tid);
+  tile_store_rows(s_v[0], vreg, tid);
   if (tid < TK) s_mask[0][tid] = mreg;
   if (TK < a.Lk) {
     tile_load(kreg, kp, a.ldk, TK, a.Lk, tid);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
   __syncthreads();
   for (int kv0 = 0, cur = 0; kv0 < a.Lk; kv0 += TK, cur ^= 1) {
     const bf16_raw* ck = s_k[cur];
-    const bf16_raw* cvt = s_vt[cur];
+    const bf16_raw* cv = s_v[cur];
     const float* cmask = s_mask[cur];
 
     // ---- S^T = K Q^T
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
     //      the LDS writes overlap the softmax arithmetic below; then start the global loads of tile j+2
     if (kv0 + TK < a.Lk) {
       tile_store_rows(s_k[cur ^ 1], kreg, tid);
-      tile_store_cols(s_vt[cur ^ 1], vreg, tid);
+      tile_store_rows(s_v[cur ^ 1], vreg, tid);
       if (tid < TK) s_mask[cur ^ 1][tid] = mreg;
       if (kv0 + 2 * TK < a.Lk) {
         tile_load(kreg, kp, a.ldk, kv0 + 2 * TK, a.Lk, tid);
@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(AttnArgs a) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const bf16x8 vf = lds_frag_cols(cvt, dt, m, lane);
+        // rows d = 16 dt + (l & 15), k-slots (g, j) <-> key 32 m + 16 (j >> 2) + 4 g + (j & 3): ds_read_b64_tr_b16 x 2
+        const bf16x8 vf = lds_frag_tr(cv, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = mfma16(vf, pb[qt][m], oacc[qt][dt]);
       }
