@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--no-kernel-pass", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--save-gemm-tuning", default="", help="write the hipBLASLt choice table of this run to a file")
+    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
+                    help="how the step is issued: eager (~700 launches from Python), graph (hipGraph replay), or auto = time "
+                         "both in the untimed preparation and keep the faster one (BEVBERT_GRAPHS=0/1 in the environment "
+                         "forces eager / graph as well)")
     return ap.parse_args()
 
 
@@ -148,6 +152,10 @@ def main():
     model.train()
     model.set_dropout(0.1)                                  # train_r2r.py:157
     trainer = PretrainTrainer(model, arena, rank=rank, world_size=world, force_collectives=force)
+    launch = a.launch
+    if launch == "auto" and os.environ.get("BEVBERT_GRAPHS") in ("0", "1"):
+        launch = "graph" if os.environ["BEVBERT_GRAPHS"] == "1" else "eager"
+    trainer.use_graphs = launch != "eager"
     # the reference draws the task of each step at random with ratio 5:5:1 (MetaLoader); the bench walks that mix as
     # a fixed 11-step cycle so that every run (and every K that is a multiple of 11) times exactly the same work
     cycle = ["mlm", "sap", "mlm", "sap", "mlm", "sap", "masksem", "mlm", "sap", "mlm", "sap"]
@@ -187,6 +195,29 @@ def main():
             for bt in batches[t]:
                 trainer.step(t, bt)
     n_graphs = sum(bt.graph is not None for t in tasks for bt in batches[t])
+    calibration = None
+    if launch == "auto":
+        # Eager issue and graph replay execute the same kernels on the same buffers (bit-identical losses:
+        # tests/test_gpu_zz_streams.py); which one is faster depends on the box: eager keeps the weight-gradient work on
+        # a second hardware queue but needs ~16-21 ms of host time per step, the replay needs none but ROCm runs a graph
+        # with two branches through its slower multi-stream path.  Time one task cycle of each (untimed preparation)
+        # and keep the faster mechanism for the warm-up and the timed region.
+        def cycle_ms(use_graphs):
+            trainer.use_graphs = use_graphs
+            run(len(cycle))
+            barrier()
+            t0 = time.perf_counter()
+            run(len(cycle))
+            barrier()
+            return 1000.0 * (time.perf_counter() - t0) / len(cycle)
+        ms = torch.tensor([cycle_ms(False), cycle_ms(True)], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ms, op=dist.ReduceOp.MAX)       # every rank takes the same decision
+        ms_eager, ms_graph = (float(x) for x in ms.tolist())
+        trainer.use_graphs = ms_graph < ms_eager
+        calibration = {"eager_ms_per_step": round(ms_eager, 3), "graph_ms_per_step": round(ms_graph, 3)}
+        log(f"launch calibration: eager {ms_eager:.2f} ms/step, hipGraph replay {ms_graph:.2f} ms/step -> "
+            f"{'graph' if trainer.use_graphs else 'eager'}")
     log("warm-up")
     run(a.warmup)
     barrier()
@@ -214,7 +245,9 @@ def main():
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "params_M": round(arena.n_params / 1e6, 1), "gemm": f"hipBLASLt via the C ABI, {n_rows} shapes from the shipped choice table, others timed on first use"},
         "host_enqueue_ms_per_step": round(1000.0 * t_host / a.steps, 3),
-        "step_launch": f"hipGraph replay ({n_graphs} captured steps, one per resident batch)" if n_graphs else "eager",
+        "step_launch": f"hipGraph replay ({n_graphs} captured steps, one per resident batch)"
+                       if (n_graphs and trainer.use_graphs) else "eager",
+        "launch_calibration": calibration,
         "final_loss": round(float(losses[-1].item()), 4),
     }
 

@@ -135,6 +135,13 @@ int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const 
 int bevbert_embedding_grad(const int64_t* ids, const void* d, float* table_grad, int rows, int H, int dtype,
                            hipStream_t stream);
 
+/* backward of nn.Embedding lookups on SMALL tables (vilmodel.py:452 nav_type_embedding, :567 gmap_step_embedding, the
+ * token-type row): partials[s][t][:] = sum of d[r, :] over the rows r of slice s (rows_per_slice rows each) with
+ * ids[r] == t; ceil(rows / rows_per_slice) slices of table_rows * H floats, folded into the table gradient by
+ * bevbert_multi_accum / bevbert_accum_partials.  No atomics: the summation order is fixed. */
+int bevbert_embedding_grad_sliced(const int64_t* ids, const void* d, float* partials, int rows, int H, int table_rows,
+                                  int rows_per_slice, int dtype, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * K4  y = gelu_erf(x + bias)  -- BertIntermediate.forward + gelu (vilmodel.py:31-37,177-180); F.gelu in the pano
  * encoder (transformer.py:178).  bwd: dx = dy * gelu'(x + bias) (dx may alias dy), dbias (C) written/accumulated. */

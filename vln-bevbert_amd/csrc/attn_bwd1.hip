@@ -38,7 +38,11 @@ template <int NKT> struct B1Lds {
 };
 
 // KT: 16-key tiles per wave; NW: waves per workgroup (4 or 8); NKT: 64-key tiles of the workgroup (LDS images)
-template <int KT, int NW, int NKT, bool BIAS, bool DROP, bool EARLY>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// KMASK: an additive key mask exists (a.key_mask).  Without one the scores need no mask term at all: keys beyond Lk have
+// zero K rows in LDS (their dS rows meet zeros in the dQ product) and their dK / dV rows are never stored.
+template <int KT, int NW, int NKT, bool BIAS, bool DROP, bool EARLY, bool KMASK>
 __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) void attn_mfma_bwd1_kernel(AttnArgs a) {
   typedef B1Lds<NKT> L;
   constexpr int NT = 64 * NW;             // threads
@@ -65,7 +69,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
   constexpr bool use_bits = DROP;          // with dropout the launcher requires the forward's keep-bit matrix
   const bool bits_hi = (c >> 2) >= 2;      // this lane's bits sit at 16 (c >> 2) + 4 g + r of its 64-bit words
   const int bits_sh = (16 * (c >> 2) + 4 * g) & 31;
-  const int ks_bits = __float_as_int(a.keep_scale);
+  // dropout: with ks = 1 / (1 - p_drop) the kernel works on dS / ks = P (dP keep - delta / ks) and on P keep; the factor ks
+  // goes into the three output scalings (dQ, dK, dV), so the keep decision enters as a plain 0.0 / 1.0 factor
+  const float inv_ks = DROP ? 1.0f / a.keep_scale : 1.0f;
+  const float out_ks = DROP ? a.keep_scale : 1.0f;
+  const float dq_scale = a.scale * out_ks;
 
   // ---- per-wave key state: V fragments, additive key mask (log2 domain; -inf beyond Lk), accumulators
   const int key0 = w * (16 * KT);                  // first key of this wave
@@ -78,7 +86,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
     const int r = key < a.Lk ? key : a.Lk - 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) vf[kt][ks] = as_bf16x8(ld_frag_global(vp, a.ldv, r, ks * 32 + g * 8));      // (unused rows: clamped)
-    mask2[kt] = key < a.Lk ? (a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * LOG2E : 0.f) : -INFINITY;
+    mask2[kt] = 0.f;
+    if (KMASK || BIAS) mask2[kt] = key < a.Lk ? (a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * LOG2E : 0.f) : -INFINITY;
   }
   f32x4 dkacc[KT][4], dvacc[KT][4];
 #pragma unroll
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
       dsum += __shfl_xor(dsum, 1, 64);
       dsum += __shfl_xor(dsum, 2, 64);
       dsum += __shfl_xor(dsum, 4, 64);
-      if ((tid & 7) == 0) s_dlt[row] = dsum;
+      if ((tid & 7) == 0) s_dlt[row] = dsum * inv_ks;
     }
     if (tid < TK) s_lse2[tid] = lreg;
     if (use_bits) {
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
           }
           const float4 l4 = *reinterpret_cast<const float4*>(&s_lse2[t * 16 + g * 4]);
           const float4 d4 = *reinterpret_cast<const float4*>(&s_dlt[t * 16 + g * 4]);
-          lv[tt][0] = l4.x; lv[tt][1] = l4.y; lv[tt][2] = l4.z; lv[tt][3] = l4.w;
+          lv[tt][0] = -l4.x; lv[tt][1] = -l4.y; lv[tt][2] = -l4.z; lv[tt][3] = -l4.w;      // -lse (log2 domain)
           ndl[tt][0] = -d4.x; ndl[tt][1] = -d4.y; ndl[tt][2] = -d4.z; ndl[tt][3] = -d4.w;
         }
       };
@@ -231,39 +240,68 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
           if (DROP) { wdc[0] = bits_of(2 * m, ktg + 1); wdc[1] = bits_of(2 * m + 1, ktg + 1); }
           __builtin_amdgcn_sched_barrier(0);         // keep the prefetch HERE (the scheduler would sink it to its use)
         }
-        // lane (key = key0 + 16 kt + c) holds S[q = q0 + 16 t + 4 g + r][key], r = 0..3
+        // lane (key = key0 + 16 kt + c) holds S[q = q0 + 16 t + 4 g + r][key], r = 0..3.  The MFMA results are wanted in
+        // VGPRs (the VALU cannot read the accumulation registers; left alone the allocator parks them there and copies
+        // every element out again), and the arithmetic runs on pairs (v_pk_fma_f32 / v_pk_mul_f32).
+        asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(dpacc[0]), "+v"(dpacc[1]));
         const float mk = mask2[kt];
+        const f32x2 sc2v = {sc2, sc2}, mkv = {mk, mk};
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * m + tt;
-          uint32_t nib = 0xfu;
-          if (DROP) {     // keep bits of the forward (prefetched above)
+          uint32_t spread = 0x01010101u;
+          if (DROP) {     // keep bits of the forward (prefetched above): bit r of the nibble -> byte r (0 / 1)
             const uint2 wd = tt == 0 ? wd0 : wd1;
-            nib = (bits_hi ? wd.y : wd.x) >> bits_sh;
+            const uint32_t nib = ((bits_hi ? wd.y : wd.x) >> bits_sh) & 0xfu;
+            spread = (nib * 0x00204081u) & 0x01010101u;
+          }
+          float keepf[4] = {1.f, 1.f, 1.f, 1.f};
+          if (DROP) {
+            // (written as instructions: from the C expression the compiler re-derives each byte from the nibble with a
+            //  bit-field extract + convert, two operations per element instead of one)
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(keepf[0]) : "v"(spread));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(keepf[1]) : "v"(spread));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(keepf[2]) : "v"(spread));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(keepf[3]) : "v"(spread));
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float sv = sacc[tt][r] * sc2 + mk;
+          for (int rp = 0; rp < 2; ++rp) {
+            const int r = 2 * rp;
+            f32x2 s2 = {sacc[tt][r], sacc[tt][r + 1]};
+            const f32x2 nl2 = {lv[tt][r], lv[tt][r + 1]};
+            f32x2 e2;
+            if (KMASK || BIAS) e2 = s2 * sc2v + mkv;
             if (BIAS) {
-              const int qi = q0 + t * 16 + g * 4 + r, key = key0 + kt * 16 + c;
-              if (qi < a.Lq && key < a.Lk) sv += a.bias[((size_t)b * a.Lq + qi) * a.Lk + key] * LOG2E;
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const int qi = q0 + t * 16 + g * 4 + r + j, key = key0 + kt * 16 + c;
+                if (qi < a.Lq && key < a.Lk) e2[j] += a.bias[((size_t)b * a.Lq + qi) * a.Lk + key] * LOG2E;
+              }
             }
-            const float p = fast_exp2(sv - lv[tt][r]);
-            float u, pd = p;
-            if (DROP) {     // keep: u = dp / (1 - p_drop) - delta, pd = p;  dropped: u = -delta, pd = 0  (1/(1-p) of pd: epilogue)
-              const int msk = __builtin_amdgcn_sbfe(nib, r, 1);                // all ones / zero from keep bit r
-              const float ksm = __int_as_float(ks_bits & msk);                 // 1 / (1 - p_drop) or 0
-              u = __builtin_fmaf(dpacc[tt][r], ksm, ndl[tt][r]);
-              pd = __int_as_float(__float_as_int(p) & msk);
+            if (KMASK || BIAS) e2 = e2 + nl2;
+            else e2 = s2 * sc2v + nl2;
+            const f32x2 p2 = {fast_exp2(e2[0]), fast_exp2(e2[1])};
+            const f32x2 dp2 = {dpacc[tt][r], dpacc[tt][r + 1]};
+            const f32x2 nd2 = {ndl[tt][r], ndl[tt][r + 1]};
+            f32x2 u2, pd2;
+            if (DROP) {     // keep: u = dp - delta / ks, pd = p;  dropped: u = -delta / ks, pd = 0   (ks: output scalings)
+              const f32x2 k2 = {keepf[r], keepf[r + 1]};
+              u2 = dp2 * k2 + nd2;
+              pd2 = p2 * k2;
             } else {
-              u = dpacc[tt][r] + ndl[tt][r];
+              u2 = dp2 + nd2;
+              pd2 = p2;
             }
-            const float ds = p * u;
-            sacc[tt][r] = ds;
-            dpacc[tt][r] = pd;
+            const f32x2 ds2 = p2 * u2;
+            sacc[tt][r] = ds2[0]; sacc[tt][r + 1] = ds2[1];
+            dpacc[tt][r] = pd2[0]; dpacc[tt][r + 1] = pd2[1];
             if (BIAS) {
-              const int qi = q0 + t * 16 + g * 4 + r, key = key0 + kt * 16 + c;
-              if (a.dbias && qi < a.Lq && key < a.Lk) atomicAdd(a.dbias + ((size_t)b * a.Lq + qi) * a.Lk + key, ds);
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const int qi = q0 + t * 16 + g * 4 + r + j, key = key0 + kt * 16 + c;
+                if (a.dbias && qi < a.Lq && key < a.Lk)
+                  atomicAdd(a.dbias + ((size_t)b * a.Lq + qi) * a.Lk + key, ds2[j] * out_ks);
+              }
             }
           }
         }
@@ -317,15 +355,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
       const int qi = q0 + (dq_qt0 + qt) * 16 + c;
       if (qi < a.Lq) {
         bf16_raw* dqp = (bf16_raw*)a.dq + (size_t)b * a.bsq + (size_t)qi * a.ldq + h * ATTN_D + dq_d0 + 4 * g;
-        st4<bf16_raw>(dqp, make_float4(dqacc[qt][0] * a.scale, dqacc[qt][1] * a.scale, dqacc[qt][2] * a.scale,
-                                       dqacc[qt][3] * a.scale));
+        st4<bf16_raw>(dqp, make_float4(dqacc[qt][0] * dq_scale, dqacc[qt][1] * dq_scale, dqacc[qt][2] * dq_scale,
+                                       dqacc[qt][3] * dq_scale));
       }
     }
     __syncthreads();   // next tile staged; dS image free again
   }
 
   // ---- epilogue: dK = scale * dK^T, dV = dV^T / (1 - p_drop)
-  const float vs = DROP ? a.keep_scale : 1.0f;
+  const float vs = out_ks;
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     const int key = key0 + kt * 16 + c;
@@ -335,8 +373,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         st4<bf16_raw>(dkp + dt * 16 + g * 4,
-                      make_float4(dkacc[kt][dt][0] * a.scale, dkacc[kt][dt][1] * a.scale, dkacc[kt][dt][2] * a.scale,
-                                  dkacc[kt][dt][3] * a.scale));
+                      make_float4(dkacc[kt][dt][0] * dq_scale, dkacc[kt][dt][1] * dq_scale, dkacc[kt][dt][2] * dq_scale,
+                                  dkacc[kt][dt][3] * dq_scale));
         st4<bf16_raw>(dvp + dt * 16 + g * 4, make_float4(dvacc[kt][dt][0] * vs, dvacc[kt][dt][1] * vs,
                                                          dvacc[kt][dt][2] * vs, dvacc[kt][dt][3] * vs));
       }
@@ -347,35 +385,38 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
 // =============================================================================================
 // launcher
 // =============================================================================================
-template <int KT, int NW, int NKT, bool B_, bool D_, bool E_ = false>
+template <int KT, int NW, int NKT, bool B_, bool D_, bool E_, bool M_>
 static int launch_bwd1(const AttnArgs& a, hipStream_t st) {
   typedef B1Lds<NKT> L;
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd1_kernel<KT, NW, NKT, B_, D_, E_>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes) == hipSuccess;
+  static const bool ok =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd1_kernel<KT, NW, NKT, B_, D_, E_, M_>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes) == hipSuccess;
   BB_REQUIRE(ok, "attention bwd (single pass): cannot raise the dynamic LDS limit to %d bytes", L::bytes);
-  hipLaunchKernelGGL((attn_mfma_bwd1_kernel<KT, NW, NKT, B_, D_, E_>), dim3((unsigned)a.B * a.nh), dim3(64 * NW), L::bytes,
-                     st, a);
+  hipLaunchKernelGGL((attn_mfma_bwd1_kernel<KT, NW, NKT, B_, D_, E_, M_>), dim3((unsigned)a.B * a.nh), dim3(64 * NW),
+                     L::bytes, st, a);
   BB_CHECK_LAUNCH("attn_bwd(single pass)");
   return BB_OK;
 }
 
 template <int KT, int NW, int NKT>
 static int dispatch_bwd1(const AttnArgs& a, hipStream_t st) {
-  const bool hb = a.bias != nullptr, hd = a.drop_p > 0.f;
+  const bool hb = a.bias != nullptr, hd = a.drop_p > 0.f, km = a.key_mask != nullptr;
   // BEVBERT_BWD1_EARLY=0: issue the next query tile's loads only in the dQ phase (A/B knob for the 448-key form)
   static const bool late = [] { const char* v = getenv("BEVBERT_BWD1_EARLY"); return v && v[0] == '0'; }();
   if constexpr (NKT <= 2) {      // the additive graph bias only occurs on the global map (a few dozen nodes)
-    if (hb && hd) return launch_bwd1<KT, NW, NKT, true, true, true>(a, st);
-    if (hb) return launch_bwd1<KT, NW, NKT, true, false, true>(a, st);
+    if (hb && hd) return launch_bwd1<KT, NW, NKT, true, true, true, true>(a, st);
+    if (hb) return launch_bwd1<KT, NW, NKT, true, false, true, true>(a, st);
   }
   if constexpr (KT == 7) {
     if (late) {
-      if (hd) return launch_bwd1<KT, NW, NKT, false, true, false>(a, st);
-      return launch_bwd1<KT, NW, NKT, false, false, false>(a, st);
+      if (hd) return launch_bwd1<KT, NW, NKT, false, true, false, true>(a, st);
+      return launch_bwd1<KT, NW, NKT, false, false, false, true>(a, st);
     }
   }
-  if (hd) return launch_bwd1<KT, NW, NKT, false, true, true>(a, st);
-  return launch_bwd1<KT, NW, NKT, false, false, true>(a, st);
+  if (hd) return km ? launch_bwd1<KT, NW, NKT, false, true, true, true>(a, st)
+                    : launch_bwd1<KT, NW, NKT, false, true, true, false>(a, st);
+  return km ? launch_bwd1<KT, NW, NKT, false, false, true, true>(a, st)
+            : launch_bwd1<KT, NW, NKT, false, false, true, false>(a, st);
 }
 
 // The single-pass kernel covers Lk <= 448 (a bias: Lk <= 128) and, with dropout, needs the forward's keep-bit matrix;

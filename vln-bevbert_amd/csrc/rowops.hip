@@ -374,6 +374,33 @@ __global__ __launch_bounds__(192) void embedding_grad_kernel(const int64_t* __re
   }
 }
 
+// Small tables (2 .. ~128 rows: navigation types, step ids, token types) with MANY gradient rows: the atomic version
+// piles 28 224 rows onto two destination rows.  Here workgroup (t, s) sums the rows of slice s whose id is t and writes
+// partials[s][t][:]; the slices are folded into the fp32 table gradient by the step's batched accumulate
+// (bevbert_multi_accum): no atomics, a fixed summation order.  The id test is wave-uniform; the loads of a group of
+// four rows are issued together.
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_grad_sliced_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d,
+                                                                    float* __restrict__ partials, int rows, int H,
+                                                                    int rows_per_slice, int ntab) {
+  const int t = blockIdx.x, s = blockIdx.y;
+  const int r0 = s * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r < r1; r += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r + j < r1 && ids[r + j] == t) v[j] = ld4<T>(d + (size_t)(r + j) * H + c);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+    }
+    *reinterpret_cast<float4*>(partials + ((size_t)s * ntab + t) * H + c) = acc;
+  }
+}
+
 // =============================================================================================
 // Flat-arena optimiser kernels.  The arena is padded so every tensor starts on a 1024-element
 // boundary; flags[i] describes chunk i: bit0 = apply weight decay, bit1 = tensor has ever had a
@@ -772,6 +799,29 @@ BEVBERT_API int bevbert_embedding_grad(const int64_t* ids, const void* d, float*
     return BB_EUNSUPPORTED;
   }
   BB_CHECK_LAUNCH("embedding_grad");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_embedding_grad_sliced(const int64_t* ids, const void* d, float* partials, int rows, int H,
+                                              int table_rows, int rows_per_slice, int dtype, hipStream_t stream) {
+  BB_REQUIRE(H % 4 == 0, "embedding_grad_sliced: H=%d must be a multiple of 4", H);
+  BB_REQUIRE(table_rows > 0 && rows_per_slice > 0 && rows > 0, "embedding_grad_sliced: empty problem (%d table rows, %d rows)",
+             table_rows, rows);
+  const int slices = (rows + rows_per_slice - 1) / rows_per_slice;
+  BB_REQUIRE(slices <= 65535, "embedding_grad_sliced: %d slices exceed the grid limit", slices);
+  const int nt = H / 4 < 256 ? ((H / 4 + 63) / 64) * 64 : 256;
+  const dim3 grid(table_rows, slices);
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL(embedding_grad_sliced_kernel<float>, grid, dim3(nt), 0, stream, ids, (const float*)d, partials, rows, H,
+                       rows_per_slice, table_rows);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL(embedding_grad_sliced_kernel<bf16_raw>, grid, dim3(nt), 0, stream, ids, (const bf16_raw*)d, partials,
+                       rows, H, rows_per_slice, table_rows);
+  else {
+    bb_set_error("embedding_grad_sliced: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("embedding_grad_sliced");
   return BB_OK;
 }
 

@@ -67,6 +67,7 @@ _PROTOS = {
     "bevbert_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U64, _I, _P],
     "bevbert_embed_sum_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _U64, _U64, _P],
     "bevbert_embedding_grad": [_P, _P, _P, _I, _I, _I, _P],
+    "bevbert_embedding_grad_sliced": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "bevbert_bias_gelu_fwd": [_P, _P, _P, _I, _I, _I, _P],
     "bevbert_bias_gelu_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "bevbert_colsum": [_P, _P, _P, _I, _I, _I, _I, _P],

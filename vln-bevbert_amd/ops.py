@@ -173,6 +173,7 @@ class WgradStream:
     enabled = _os.environ.get("BEVBERT_WGRAD_STREAM", "1") == "1"
     BATCH = int(_os.environ.get("BEVBERT_WGRAD_BATCH", "6"))
     DEFER_FINALIZE = _os.environ.get("BEVBERT_DEFER_FINALIZE", "1") == "1"      # A/B knob for the split reductions
+    OWN_STREAM = _os.environ.get("BEVBERT_WGRAD_OWN_STREAM", "0") == "1"         # separate stream even next to ops.Branches
     stream = None
     dirty = False        # work has been enqueued on the stream since the last join (ParamArena.sync)
     _keep = []
@@ -208,7 +209,7 @@ class WgradStream:
         if not fns:
             return
         if cls.stream is None:
-            shared = Branches._streams.get(producer.device.index) if Branches.enabled else None
+            shared = Branches._streams.get(producer.device.index) if Branches.enabled and not cls.OWN_STREAM else None
             cls.stream = shared if shared is not None else torch.cuda.Stream(producer.device)
             Branches._streams["wgrad"] = cls.stream       # joined by ParamArena.sync / GradReducer like the branches
             cls._events = [torch.cuda.Event() for _ in range(64)]
@@ -659,6 +660,19 @@ def _wgrad_into(sink, dy2, x2):
     else:
         _on_launch_stream(lambda: sink.add_(part if S == 1 else part.sum(0)))
     return part
+
+
+def embedding_grad_small(ids, d, sink, table_rows):
+    """sink (fp32 arena view, table_rows x H) += scatter-sum of d's rows by ids, for tables of a few rows: sliced partial
+    sums in the scratch ring (bevbert_embedding_grad_sliced), folded in by the batched accumulate of ReduceQueue."""
+    rows, H = d.shape
+    per = 32 if table_rows <= 8 else 64
+    while (rows + per - 1) // per * table_rows > 4096:        # keep the launch at a few thousand workgroups
+        per *= 2
+    slices = (rows + per - 1) // per
+    part = SCRATCH.alloc(slices * table_rows * H * 4, d.device)
+    call("bevbert_embedding_grad_sliced", ptr(ids), ptr(d), part, rows, H, table_rows, per, dtype_code(d), stream())
+    ReduceQueue.add_accum(part, sink.data_ptr(), slices, table_rows * H, dtype_code(sink))
 
 
 def _param_grads(w_sink, b_sink, dyc, xc):

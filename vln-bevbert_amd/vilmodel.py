@@ -441,8 +441,14 @@ class _GatherRows(torch.autograd.Function):
             return None, None, None
         sink = ops._sink(table)
         d = dy.reshape(-1, dy.shape[-1])
-        # the tables here have 2..100 rows: a one-hot GEMM (rows x N) @ (N x H) is deterministic and avoids the
-        # atomic pile-up of index_add_ on two or three destination rows (0.3 ms per call at N = 28 224)
+        if sink is not None and d.is_cuda and d.shape[1] % 4 == 0 and ops.WgradStream.DEFER_FINALIZE:
+            # the tables here have 2..100 rows and up to 28 224 gradient rows: per-(table row, row slice) sums without
+            # atomics (index_add_ piles 0.3 ms of atomics onto two destination rows), folded into the arena by the
+            # step's batched accumulate -- one launch here, none for the fold
+            ops._mark_touched(table)
+            ops.embedding_grad_small(idx.reshape(-1), d.contiguous(), sink, table.shape[0])
+            return None, None, None
+        # fallback (CPU reference runs, no arena): a one-hot GEMM (rows x N) @ (N x H), deterministic as well
         onehot = F.one_hot(idx.reshape(-1), table.shape[0]).to(d.dtype)
         g = onehot.t().mm(d)
         if sink is not None:
