@@ -137,8 +137,9 @@ int bevbert_embedding_grad(const int64_t* ids, const void* d, float* table_grad,
 
 /* backward of nn.Embedding lookups on SMALL tables (vilmodel.py:452 nav_type_embedding, :567 gmap_step_embedding, the
  * token-type row): partials[s][t][:] = sum of d[r, :] over the rows r of slice s (rows_per_slice rows each) with
- * ids[r] == t; ceil(rows / rows_per_slice) slices of table_rows * H floats, folded into the table gradient by
- * bevbert_multi_accum / bevbert_accum_partials.  No atomics: the summation order is fixed. */
+ * ids[r] == t; ceil(rows / rows_per_slice) slices of table_rows * H floats, folded into the table gradient by the
+ * second stage of the column reductions (bevbert_multi_finalize with row_stride = table_rows * H).  No atomics: the
+ * summation order is fixed. */
 int bevbert_embedding_grad_sliced(const int64_t* ids, const void* d, float* partials, int rows, int H, int table_rows,
                                   int rows_per_slice, int dtype, hipStream_t stream);
 
@@ -227,6 +228,29 @@ int bevbert_gemm_tuning_import(const char* text);
  * (transformer.py:170-182).  The backward of x is the same call on dy with residual = NULL. */
 int bevbert_dropout_add(const void* x, const void* residual, void* y, int64_t n, int in_dtype, int out_dtype,
                         float drop_p, uint64_t seed, uint64_t offset, hipStream_t stream);
+
+/* Tail of forward_sap (pretrain_src/model/pretrain_cmt.py:225-275) behind the three prediction heads, one launch:
+ * fw = sigmoid(fuse_raw) (fuse_raw NULL: 0.5); global logits = global_raw * fw with -inf on visited nodes and beyond
+ * gmap_lens; local logits = local_raw * (1 - fw) with -inf where nav_masks[b, cand_idxs[b, k]] == 0; fused logits =
+ * global + [local | sum of local over vis_c | 0][src]; loss[b] = CE(global) + CE(local) + CE(fused) (labels:
+ * global_labels twice, local_labels).  dG (B,G) / dL (B,K) / dF (B): fp32 gradients w.r.t. global_raw / local_raw /
+ * fuse_raw for dloss[b] = 1.  bool tensors are bytes.  G <= 64, K <= 62.  bevbert_sap_loss_bwd: d_*_raw = d* * dloss[b]
+ * in the heads' dtype (d_fuse_raw may be NULL). */
+int bevbert_sap_loss_fwd(const void* global_raw, const void* local_raw, const void* fuse_raw, const uint8_t* visited,
+                         const int64_t* gmap_lens, const uint8_t* nav_masks, const int64_t* cand_idxs, const int64_t* src,
+                         const uint8_t* vis_c, const int64_t* global_labels, const int64_t* local_labels, float* loss,
+                         float* dG, float* dL, float* dF, int B, int G, int K, int P, int dtype, hipStream_t stream);
+int bevbert_sap_loss_bwd(const float* dG, const float* dL, const float* dF, const float* dloss, void* d_global_raw,
+                         void* d_local_raw, void* d_fuse_raw, int B, int G, int K, int dtype, hipStream_t stream);
+
+/* F.cross_entropy(logits.float(), target, reduction="none") on wide rows -- the MLM head (pretrain_cmt.py:262-266,
+ * rows = masked tokens, C = vocabulary): logits are read in their own dtype (bf16 / fp32, rows x C contiguous, base
+ * 16-byte aligned, any C), statistics in fp32; loss[r] and lse[r] out.  bwd: dlogits = (softmax - onehot) * dloss[r]
+ * in the logits' dtype (dlogits may alias logits). */
+int bevbert_cross_entropy_fwd(const void* logits, const int64_t* target, float* loss, float* lse, int rows, int C,
+                              int dtype, hipStream_t stream);
+int bevbert_cross_entropy_bwd(const void* logits, const int64_t* target, const float* lse, const float* dloss,
+                              void* dlogits, int rows, int C, int dtype, hipStream_t stream);
 
 /* Per-step dropout salt.  Every dropout site derives its mask from hash(seed, offset) -- launch arguments, frozen in a
  * captured hipGraph.  After bevbert_set_step_salt(word) (word: 4 bytes of device memory owned by the caller, NULL to

@@ -255,6 +255,74 @@ def test_small_table_embedding_grad_sliced(ops, table_rows, rows, dtype):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dtype,fuse", [(torch.float32, True), (torch.float32, False), (torch.bfloat16, True)])
+def test_fused_sap_loss_tail_matches_the_torch_composition(ops, dtype, fuse):
+    """ops.sap_loss == pretrain_cmt.forward_sap's tail written with torch ops (masked fills, fuse_sap_logits, three
+    cross-entropies): loss per sample and the gradients w.r.t. the three head outputs."""
+    import torch.nn.functional as F
+    from vln_bevbert_amd.pretrain_cmt import fuse_sap_logits
+    torch.manual_seed(9)
+    B, G, K, P = 7, 23, 6, 441
+    graw = torch.randn(B, G, device=DEV).to(dtype).requires_grad_(True)
+    lraw = torch.randn(B, K, device=DEV).to(dtype).requires_grad_(True)
+    fraw = torch.randn(B, 1, device=DEV).to(dtype).requires_grad_(True) if fuse else None
+    gmap_lens = torch.randint(4, G + 1, (B,), device=DEV)
+    visited = torch.rand(B, G, device=DEV) < 0.3
+    visited[:, 1] = False                                   # the labelled node stays selectable
+    nav_masks = torch.rand(B, P, device=DEV) < 0.7
+    cand_idxs = torch.randint(0, P, (B, K), device=DEV)
+    nav_masks[torch.arange(B, device=DEV), cand_idxs[:, 2]] = True
+    src = torch.randint(0, K + 2, (B, G), device=DEV)       # K: "sum over visited candidates", K + 1: nothing
+    src[:, 1] = K + 1                                       # (the labelled node must not inherit a masked candidate's -inf)
+    vis_c = torch.rand(B, K, device=DEV) < 0.4
+    vis_c &= nav_masks[torch.arange(B, device=DEV)[:, None], cand_idxs]      # (a masked visited candidate gives -inf)
+    gl_lab = torch.ones(B, dtype=torch.long, device=DEV)
+    ll_lab = torch.full((B,), 2, dtype=torch.long, device=DEV)
+    w = torch.randn(B, device=DEV)
+
+    loss = ops.sap_loss(graw, lraw, fraw, visited, gmap_lens, nav_masks, cand_idxs, src, vis_c, gl_lab, ll_lab)
+    (loss * w).sum().backward()
+    got = [loss.detach().clone()] + [t.grad.clone() for t in (graw, lraw) + ((fraw,) if fuse else ())]
+
+    ref_in = [t.detach().float().clone().requires_grad_(True) for t in (graw, lraw) + ((fraw,) if fuse else ())]
+    g2, l2 = ref_in[0], ref_in[1]
+    fw = torch.sigmoid(ref_in[2]) if fuse else 0.5
+    gl = (g2 * fw).masked_fill(visited, -float("inf"))
+    gl = gl.masked_fill(torch.arange(G, device=DEV)[None] >= gmap_lens[:, None], -float("inf"))
+    cm = nav_masks[torch.arange(B, device=DEV)[:, None], cand_idxs]
+    ll = (l2 * (1 - fw)).masked_fill(cm.logical_not(), -float("inf"))
+    fu = fuse_sap_logits(gl, ll, src, vis_c)
+    want = F.cross_entropy(gl, gl_lab, reduction="none") + F.cross_entropy(ll, ll_lab, reduction="none") \
+        + F.cross_entropy(fu, gl_lab, reduction="none")
+    (want * w).sum().backward()
+    ref = [want.detach()] + [t.grad for t in ref_in]
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert torch.isfinite(want).all()
+    for a_, r_ in zip(got, ref):
+        assert float((a_.float() - r_).abs().max()) <= tol * max(1.0, float(r_.abs().max())), (a_, r_)
+
+
+@pytest.mark.parametrize("rows,C,dtype", [(5, 30522, torch.bfloat16), (3, 30522, torch.float32), (4, 250002, torch.bfloat16),
+                                          (7, 41, torch.float32), (2, 4, torch.bfloat16)])
+def test_cross_entropy_rows_matches_torch(ops, rows, C, dtype):
+    """The MLM head's loss: F.cross_entropy(logits.float(), target, reduction='none') and its gradient, read straight
+    from the logits' dtype; vocabulary sizes that are not multiples of four exercise the ragged row ends."""
+    import torch.nn.functional as F
+    torch.manual_seed(13)
+    x = (3 * torch.randn(rows, C, device=DEV)).to(dtype).requires_grad_(True)
+    t = torch.randint(0, C, (rows,), device=DEV)
+    t[0] = C - 1
+    w = torch.randn(rows, device=DEV)
+    loss = ops.cross_entropy_rows(x, t)
+    (loss * w).sum().backward()
+    xr = x.detach().float().requires_grad_(True)
+    want = F.cross_entropy(xr, t, reduction="none")
+    (want * w).sum().backward()
+    assert float((loss - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    tol = 1e-6 if dtype == torch.float32 else 4e-3          # bf16: one rounding of the fp32 gradient
+    assert float((x.grad.float() - xr.grad).abs().max()) <= tol * max(1.0, float(xr.grad.abs().max()))
+
+
 def test_segment_wsum_matches_oracle_aggregation(ops):
     from vln_bevbert_amd.vilmodel import build_gmap_csr
     cfg = BevBertConfig()

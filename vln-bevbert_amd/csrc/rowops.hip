@@ -376,8 +376,8 @@ __global__ __launch_bounds__(192) void embedding_grad_kernel(const int64_t* __re
 
 // Small tables (2 .. ~128 rows: navigation types, step ids, token types) with MANY gradient rows: the atomic version
 // piles 28 224 rows onto two destination rows.  Here workgroup (t, s) sums the rows of slice s whose id is t and writes
-// partials[s][t][:]; the slices are folded into the fp32 table gradient by the step's batched accumulate
-// (bevbert_multi_accum): no atomics, a fixed summation order.  The id test is wave-uniform; the loads of a group of
+// partials[s][t][:]; the slices are folded into the fp32 table gradient by the step's batched second reduction stage
+// (bevbert_multi_finalize): no atomics, a fixed summation order.  The id test is wave-uniform; the loads of a group of
 // four rows are issued together.
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_grad_sliced_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d,

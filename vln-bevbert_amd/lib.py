@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbevbert_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "attn_bwd1.hip", "gemm.hip", "capi.hip"]
+SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "attn_bwd1.hip", "sap_loss.hip", "gemm.hip", "capi.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bevbert_hip.h")
 
 F32, BF16, F16 = 0, 1, 2
@@ -85,6 +85,10 @@ _PROTOS = {
                      _I64, _I, _P],
     "bevbert_colsum_finalize": [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     "bevbert_dropout_add": [_P, _P, _P, _I64, _I, _I, _F, _U64, _U64, _P],
+    "bevbert_sap_loss_fwd": [_P] * 15 + [_I, _I, _I, _I, _I, _P],
+    "bevbert_sap_loss_bwd": [_P] * 7 + [_I, _I, _I, _I, _P],
+    "bevbert_cross_entropy_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "bevbert_cross_entropy_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "bevbert_gemm_run": [_I, _P, _P, _P, _P, _P, _I64, _P],
     "bevbert_gemm_run_add": [_I, _P, _P, _P, _P, _P, _P, _I64, _P],
 }

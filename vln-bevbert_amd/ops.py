@@ -664,15 +664,16 @@ def _wgrad_into(sink, dy2, x2):
 
 def embedding_grad_small(ids, d, sink, table_rows):
     """sink (fp32 arena view, table_rows x H) += scatter-sum of d's rows by ids, for tables of a few rows: sliced partial
-    sums in the scratch ring (bevbert_embedding_grad_sliced), folded in by the batched accumulate of ReduceQueue."""
+    sums in the scratch ring (bevbert_embedding_grad_sliced), folded in by the step's batched column reduction
+    (ReduceQueue / bevbert_multi_finalize: 16 row lanes per 64 columns, so hundreds of slices are fine)."""
     rows, H = d.shape
-    per = 32 if table_rows <= 8 else 64
+    per = 64
     while (rows + per - 1) // per * table_rows > 4096:        # keep the launch at a few thousand workgroups
         per *= 2
     slices = (rows + per - 1) // per
     part = SCRATCH.alloc(slices * table_rows * H * 4, d.device)
     call("bevbert_embedding_grad_sliced", ptr(ids), ptr(d), part, rows, H, table_rows, per, dtype_code(d), stream())
-    ReduceQueue.add_accum(part, sink.data_ptr(), slices, table_rows * H, dtype_code(sink))
+    ReduceQueue.add(part, slices, 1, table_rows * H, (sink.data_ptr(), None, None))
 
 
 def _param_grads(w_sink, b_sink, dyc, xc):
@@ -863,6 +864,80 @@ def dropout(x, p, training, residual=None, out_dtype=None):
         y = x if out_dtype is None or out_dtype == x.dtype else x.to(out_dtype)
         return y if residual is None else residual + y
     return _DropoutAdd.apply(x.contiguous(), residual, float(p), out_dtype)
+
+
+# ----------------------------------------------------------------------------- SAP loss tail
+class _SapLoss(torch.autograd.Function):
+    """loss (B,) of forward_sap behind the three heads (pretrain_cmt.py:225-275) in one launch; see bevbert_sap_loss_fwd."""
+
+    @staticmethod
+    def forward(ctx, graw, lraw, fraw, visited, gmap_lens, nav_masks, cand_idxs, src, vis_c, glabels, llabels):
+        B, G = graw.shape
+        K = lraw.shape[1]
+        dev = graw.device
+        assert lraw.dtype == graw.dtype and (fraw is None or fraw.dtype == graw.dtype)
+        graw, lraw = graw.contiguous(), lraw.contiguous()
+        fraw = None if fraw is None else fraw.contiguous()
+        buf = torch.empty(B * (G + K + 2), dtype=torch.float32, device=dev)
+        loss, dG, dL, dF = buf[:B], buf[B:B + B * G], buf[B + B * G:B + B * (G + K)], buf[B + B * (G + K):]
+        as_u8 = lambda t: t.contiguous().view(torch.uint8)
+        call("bevbert_sap_loss_fwd", ptr(graw), ptr(lraw), ptr(fraw), ptr(as_u8(visited)), ptr(gmap_lens.contiguous()),
+             ptr(as_u8(nav_masks)), ptr(cand_idxs.contiguous()), ptr(src.contiguous()), ptr(as_u8(vis_c)),
+             ptr(glabels.contiguous()), ptr(llabels.contiguous()), ptr(loss), ptr(dG), ptr(dL), ptr(dF), B, G, K,
+             nav_masks.shape[1], dtype_code(graw), stream())
+        ctx.save_for_backward(buf)
+        ctx.dims = (B, G, K, graw.dtype, fraw is not None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (buf,) = ctx.saved_tensors
+        B, G, K, dt, has_f = ctx.dims
+        dG, dL, dF = buf[B:B + B * G], buf[B + B * G:B + B * (G + K)], buf[B + B * (G + K):]
+        out = torch.empty(B * (G + K + 1), dtype=dt, device=buf.device)
+        dgr, dlr, dfr = out[:B * G].view(B, G), out[B * G:B * (G + K)].view(B, K), out[B * (G + K):].view(B, 1)
+        call("bevbert_sap_loss_bwd", ptr(dG), ptr(dL), ptr(dF), ptr(dloss.contiguous().float()), ptr(dgr), ptr(dlr),
+             ptr(dfr) if has_f else None, B, G, K, dtype_code(out), stream())
+        return (dgr, dlr, dfr if has_f else None) + (None,) * 8
+
+
+def sap_loss_supported(graw, lraw):
+    return graw.is_cuda and graw.shape[1] <= 64 and lraw.shape[1] <= 62 and graw.dtype in (torch.float32, torch.bfloat16)
+
+
+def sap_loss(graw, lraw, fraw, visited, gmap_lens, nav_masks, cand_idxs, src, vis_c, glabels, llabels):
+    """(B,) loss of the SAP task from the raw head outputs: graw (B,G), lraw (B,K), fraw (B,1) or None."""
+    return _SapLoss.apply(graw, lraw, fraw, visited, gmap_lens, nav_masks, cand_idxs, src, vis_c, glabels, llabels)
+
+
+class _CrossEntropy(torch.autograd.Function):
+    """F.cross_entropy(logits.float(), target, reduction="none") without the fp32 copy of the logits."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        rows, C = logits.shape
+        logits = logits.contiguous()
+        out = torch.empty(2, rows, dtype=torch.float32, device=logits.device)
+        call("bevbert_cross_entropy_fwd", ptr(logits), ptr(target.contiguous()), ptr(out[0]), ptr(out[1]), rows, C,
+             dtype_code(logits), stream())
+        ctx.save_for_backward(logits, target, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target, out = ctx.saved_tensors
+        rows, C = logits.shape
+        d = torch.empty_like(logits)
+        call("bevbert_cross_entropy_bwd", ptr(logits), ptr(target.contiguous()), ptr(out[1]),
+             ptr(dloss.contiguous().float()), ptr(d), rows, C, dtype_code(logits), stream())
+        return d, None
+
+
+def cross_entropy_rows(logits, target):
+    """(rows,) fp32 losses of (rows, C) logits in the compute dtype (the MLM head's vocabulary rows)."""
+    if logits.is_cuda and logits.dtype in (torch.float32, torch.bfloat16):
+        return _CrossEntropy.apply(logits, target)
+    return torch.nn.functional.cross_entropy(logits.float(), target, reduction="none")
 
 
 # ----------------------------------------------------------------------------- K4 bias + GELU

@@ -290,10 +290,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             # carries zero weight): no nonzero() sync, no host->device copy inside the step, static GEMM shapes
             pos_in, n = st["mlm_pos"], st["mlm_n"]
             masked = txt_embeds.reshape(-1, txt_embeds.shape[-1]).index_select(0, pos_in)
-            scores = self.mlm_head(masked).float()
             if compute_loss == "mean":
-                per_row = F.cross_entropy(scores, st["mlm_targets"], reduction="none")
+                # cross-entropy straight from the head's logits (fp32 statistics, no fp32 copy of rows x vocabulary)
+                per_row = ops.cross_entropy_rows(self.mlm_head(masked), st["mlm_targets"])
                 return (per_row * st["mlm_valid"]).sum() / st["mlm_n_dev"]     # row count of the batch in the buffers
+            scores = self.mlm_head(masked).float()
             scores = scores[:n]
             if compute_loss:
                 return F.cross_entropy(scores, st["mlm_targets"][:n], reduction="none")
@@ -324,13 +325,27 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def forward_sap(self, b, compute_loss):
         cfg = self.config
         gmap_embeds, bev_embeds, _, _ = self.bert(*self._cmt_args(b), **self._host_kw(b))
+        center = (cfg.bev_dim * cfg.bev_dim - 1) // 2
+        G = gmap_embeds.shape[1]
+        st = b.get("_static")
+        if compute_loss and st is not None and G <= 64 and b["bev_cand_idxs"].shape[1] <= 62 and gmap_embeds.is_cuda:
+            # static batch (loader-built fusion table on the device): the whole tail behind the heads -- masks, logit
+            # fusion, three cross-entropies and their backward -- is one C-ABI launch each way (ops.sap_loss)
+            cand_idxs = b["bev_cand_idxs"]
+            bi = torch.arange(cand_idxs.shape[0], device=cand_idxs.device)[:, None]
+            graw = self.global_sap_head(gmap_embeds).squeeze(2)
+            lraw = self.local_sap_head(bev_embeds[bi, cand_idxs]).squeeze(2)
+            fraw = None if self.sap_fuse_linear is None else self.sap_fuse_linear(
+                torch.cat([gmap_embeds[:, 0], bev_embeds[:, center]], 1))
+            loss = ops.sap_loss(graw, lraw, fraw, b["gmap_visited_masks"], b["gmap_lens"], b["bev_nav_masks"],
+                                cand_idxs, st["sap_src"], st["sap_vis_c"], b["global_act_labels"],
+                                b["local_act_labels"])
+            return loss.mean() if compute_loss == "mean" else loss
         if self.sap_fuse_linear is None:
             fuse_weights = 0.5
         else:
-            center = (cfg.bev_dim * cfg.bev_dim - 1) // 2
             fuse_weights = torch.sigmoid(self.sap_fuse_linear(
                 torch.cat([gmap_embeds[:, 0], bev_embeds[:, center]], 1)).float())
-        G = gmap_embeds.shape[1]
         global_logits = self.global_sap_head(gmap_embeds).squeeze(2).float() * fuse_weights
         global_logits = global_logits.masked_fill(b["gmap_visited_masks"], -float("inf"))
         global_logits = global_logits.masked_fill(gen_seq_masks(b["gmap_lens"], G).logical_not(), -float("inf"))
