@@ -111,9 +111,10 @@ class Branches:
     stream and tells the caching allocator that the given side-allocated tensors are now used on the current stream.
     Autograd replays every backward op on the stream its forward ran on and inserts the cross-stream waits itself."""
 
-    # measured on MI355X (in-run A/B, batch 64): 26.9-27.9 ms/step with the side stream vs 23.7-24.8 without --
-    # the 28 224-row GEMMs already fill the chip and the extra cross-stream waits cost more than the overlap buys,
-    # so the side stream is OFF by default (BEVBERT_STREAMS=1 turns it on, e.g. for small batches)
+    # Issued eagerly the extra fork / join events cost ~3 ms of host time per step at batch 64 and the step becomes
+    # host-bound (round 2, one call: 19.27 with vs 19.35 ms without), so the side stream is OFF for eager steps
+    # (BEVBERT_STREAMS=1 turns it on); CAPTURED steps turn it on themselves (train.PretrainTrainer.graph_branches),
+    # where the edges cost nothing on the host: 18.58 vs 19.32 ms/step.
     enabled = _os.environ.get("BEVBERT_STREAMS", "0") == "1"
     _streams = {}
 
@@ -166,14 +167,16 @@ class WgradStream:
     also joins the stream) instead of being tracked by the caching allocator -- with 288 GB of HBM the extra lifetime
     of one backward's activation gradients is free."""
 
-    # With the model-branch side stream on (ops.Branches) the deferred work SHARES that stream: three concurrent streams
-    # (main + branch + a separate weight-gradient stream) stalled at batch 64 on the MI355X (unexplained), two do not.
-    # In-run A/B at batch 64: 24.9 ms/step with neither, 23.3 with this stream alone (22.5 after the LayerNorm / GELU
-    # reduction tails moved here too), 22.8 with the branch stream alone, 23.6-24.5 with both on one shared stream.
+    # Round-1 in-run A/B at batch 64: 24.9 ms/step with neither side stream, 23.3 with this stream alone (22.5 after the
+    # LayerNorm / GELU reduction tails moved here too), 22.8 with the branch stream alone, 23.6-24.5 with both on one
+    # shared stream.
     enabled = _os.environ.get("BEVBERT_WGRAD_STREAM", "1") == "1"
     BATCH = int(_os.environ.get("BEVBERT_WGRAD_BATCH", "6"))
     DEFER_FINALIZE = _os.environ.get("BEVBERT_DEFER_FINALIZE", "1") == "1"      # A/B knob for the split reductions
-    OWN_STREAM = _os.environ.get("BEVBERT_WGRAD_OWN_STREAM", "0") == "1"         # separate stream even next to ops.Branches
+    # own stream even next to ops.Branches (three streams).  Round 1 shared one side stream because three streams had
+    # stalled once at batch 64; that stall does not reproduce (scripts/probes/three_stream_probe.py, and bench.py with
+    # BEVBERT_STREAMS=1 on separate streams, eager and captured), and three streams measure fastest (DESIGN.md section 3)
+    OWN_STREAM = _os.environ.get("BEVBERT_WGRAD_OWN_STREAM", "1") == "1"
     stream = None
     dirty = False        # work has been enqueued on the stream since the last join (ParamArena.sync)
     _keep = []
