@@ -248,6 +248,7 @@ def main():
         "step_launch": f"hipGraph replay ({n_graphs} captured steps, one per resident batch)"
                        if (n_graphs and trainer.use_graphs) else "eager",
         "launch_calibration": calibration,
+        "graph_error": trainer.graph_error,
         "final_loss": round(float(losses[-1].item()), 4),
     }
 

@@ -151,6 +151,7 @@ class PretrainTrainer:
         # Measured in one call on one MI355X at batch 64: eager 18.83, graph with the weight-gradient stream only 19.32,
         # + branch stream 18.58 ms/step.  BEVBERT_GRAPH_BRANCHES=0 turns it off.
         self.graph_branches = os.environ.get("BEVBERT_GRAPH_BRANCHES", "1") == "1"
+        self.graph_error = None            # set (and use_graphs cleared) if a capture ever fails
         self._graph_pool = None
         first_map = min(arena.slices[n][0] for n in arena.slices
                         if n.startswith("bert.local_encoder") or n.startswith("bert.global_encoder")
@@ -287,6 +288,18 @@ class PretrainTrainer:
                 ops.RT.new_step(0, write_salt=False)    # offsets restart; the salt word is read by the kernels at replay
                 loss = self._forward_backward(task, sb)
                 a.clip_and_step(None, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
+        except Exception as e:      # noqa: BLE001 -- a step that cannot be captured (e.g. a collective library that refuses
+            # stream capture) is not fatal: nothing has executed yet, the trainer says so loudly and goes on eagerly
+            import warnings
+            self.graph_error = f"{type(e).__name__}: {e}"[:400]
+            self.use_graphs = False
+            warnings.warn(f"hipGraph capture of the {task} step failed, continuing with eager steps: {self.graph_error}")
+            ops.Branches.enabled = branches
+            torch.cuda.synchronize()
+            ops.RT.new_step(self._step_seed())
+            loss = self._forward_backward(task, sb)
+            self.optimizer_step(lr=None)
+            return loss
         finally:
             ops.Branches.enabled = branches
         gs = GraphedStep(graph, loss)
