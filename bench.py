@@ -155,6 +155,11 @@ def main():
     launch = a.launch
     if launch == "auto" and os.environ.get("BEVBERT_GRAPHS") in ("0", "1"):
         launch = "graph" if os.environ["BEVBERT_GRAPHS"] == "1" else "eager"
+    if launch == "auto" and world > 1:
+        # captured steps with a real multi-rank RCCL exchange inside have never run on hardware (one-rank RCCL captures and
+        # replays fine: profiles/r02_launch_mode_and_stream_ab.txt); a scaling run takes the plain eager path unless
+        # BEVBERT_GRAPHS=1 / --launch graph asks for the capture explicitly
+        launch = "eager"
     trainer.use_graphs = launch != "eager"
     # the reference draws the task of each step at random with ratio 5:5:1 (MetaLoader); the bench walks that mix as
     # a fixed 11-step cycle so that every run (and every K that is a multiple of 11) times exactly the same work

@@ -159,6 +159,62 @@ def test_phase_a_gradients_are_final_when_the_text_hook_fires(env, dtype):
         handle.remove()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_text_layer_regions_are_final_when_their_hooks_fire(env, dtype):
+    """Phase B of the gradient exchange is pipelined through the text encoder's backward: the arena region of the text
+    layers >= k is all-reduced when d loss / d (input of layer k) is complete (train.PretrainTrainer.text_layer_regions).
+    Same check as for phase A: snapshot each region when its hook fires (after the flush GradReducer._launch does),
+    compare with the region after the whole backward -- bit for bit, for every task."""
+    from vln_bevbert_amd import ops
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=4, num_x_layers=1, vocab_size=400)
+    model, arena = _fresh(cfg, dtype)
+    regions = PretrainTrainer.text_layer_regions(model, arena, "1,2,3")
+    assert [k for k, _, _ in regions] == [3, 2, 1] and all(lo < hi for _, lo, hi in regions)
+    n3 = sum(k for n, (o, k) in arena.slices.items() if n.startswith("bert.lang_encoder.layer.3."))
+    assert n3 <= regions[0][2] - regions[0][1] < n3 + 1024 * 32          # (tensors start on 1024-element boundaries)
+    auto = PretrainTrainer.text_layer_regions(model, arena, "auto")
+    assert [k for k, _, _ in auto] == [3, 1]
+    snap, handles = {}, []
+
+    def make(k, lo, hi):
+        def at_hook(g):
+            ops.WgradStream.flush_all()
+            torch.cuda.synchronize()
+            snap[k] = arena.grads[lo:hi].clone()
+            return g
+
+        def pre_hook(mod, inputs):
+            if inputs[0].requires_grad and torch.is_grad_enabled():
+                inputs[0].register_hook(at_hook)
+        return pre_hook
+
+    for k, lo, hi in regions:
+        handles.append(model.bert.lang_encoder.layer[k].register_forward_pre_hook(make(k, lo, hi)))
+    try:
+        for step, task in enumerate(("sap", "mlm", "masksem")):
+            snap.clear()
+            ops.RT.new_step(700 + step)
+            arena.zero_grad()
+            b = synthetic.batch_to(synthetic.make_batch(cfg, task, 3, seed=95 + step, ragged=True), DEV)
+            model(b, task).mean().backward()
+            arena.sync()
+            torch.cuda.synchronize()
+            for k, lo, hi in regions:
+                assert k in snap, (task, k)
+                final = arena.grads[lo:hi]
+                late = (snap[k] != final).nonzero()
+                if late.numel():
+                    off = int(late[0]) + lo
+                    name = [n for n, (o, kk) in arena.slices.items() if o <= off < o + kk]
+                    raise AssertionError(f"{task}: {late.shape[0]} gradient elements of text layers >= {k} changed after "
+                                         f"their hook, first in {name}")
+                assert float(final.abs().sum()) > 0
+    finally:
+        for h in handles:
+            h.remove()
+
+
 # ----------------------------------------------------------------------------- static batches and captured steps
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_static_batch_step_equals_the_reference_api_step(env, dtype):

@@ -163,17 +163,33 @@ class PretrainTrainer:
             self.broadcast_state()             # replicas start from rank 0's weights, as under DistributedDataParallel
         if self.overlap:
             model.bert.lang_encoder.register_forward_hook(self._hook_text)
-            # opt-in finer pipeline (BEVBERT_REDUCE_TEXT_LAYERS="2,4,6"; not validated on a multi-GPU node yet): when the
+            # finer pipeline for phase B (embeddings + text + panorama encoders, 43 % of the gradient bytes): when the
             # gradient w.r.t. the INPUT of text layer k is complete, every kernel of the text layers >= k has been
-            # enqueued, so their arena region can go out while the earlier layers are still in backward
-            import os
-            layers = [int(x) for x in os.environ.get("BEVBERT_REDUCE_TEXT_LAYERS", "").split(",") if x.strip()]
-            n_layers = len(model.bert.lang_encoder.layer)
-            hi = max(o + k for n, (o, k) in arena.slices.items() if n.startswith("bert.lang_encoder."))
-            for k in sorted({x for x in layers if 0 < x < n_layers}, reverse=True):
-                lo = min(o for n, (o, _) in arena.slices.items() if n.startswith(f"bert.lang_encoder.layer.{k}."))
+            # enqueued (or deferred: GradReducer._launch flushes the weight-gradient queue first), so their arena region
+            # goes out while the earlier layers are still in backward.  BEVBERT_REDUCE_TEXT_LAYERS: comma-separated layer
+            # indices, "auto" (default) = the layers at one and two thirds of the stack, "" = off.  The hook-time
+            # finality of every region is tested on the GPU (test_text_layer_regions_are_final_when_their_hooks_fire).
+            for k, lo, hi in self.text_layer_regions(model, arena):
                 model.bert.lang_encoder.layer[k].register_forward_pre_hook(self._make_layer_hook(lo, hi))
-                hi = lo
+
+    @staticmethod
+    def text_layer_regions(model, arena, spec=None):
+        """[(layer k, lo, hi)]: arena region of the text layers k .. (next hooked layer - 1), last hooked layer first."""
+        import os
+        if spec is None:
+            spec = os.environ.get("BEVBERT_REDUCE_TEXT_LAYERS", "auto")
+        n_layers = len(model.bert.lang_encoder.layer)
+        if spec.strip() == "auto":
+            layers = {round(n_layers / 3), round(2 * n_layers / 3)}
+        else:
+            layers = {int(x) for x in spec.split(",") if x.strip()}
+        hi = max(o + k for n, (o, k) in arena.slices.items() if n.startswith("bert.lang_encoder."))
+        out = []
+        for k in sorted({x for x in layers if 0 < x < n_layers}, reverse=True):
+            lo = min(o for n, (o, _) in arena.slices.items() if n.startswith(f"bert.lang_encoder.layer.{k}."))
+            out.append((k, lo, hi))
+            hi = lo
+        return out
 
     def _make_layer_hook(self, lo, hi):
         def pre_hook(module, inputs):
@@ -283,8 +299,18 @@ class PretrainTrainer:
             # and exchange nothing through pool memory, so the pool is as large as the largest step, not the sum
             self._graph_pool = torch.cuda.graph_pool_handle()
         ops.Branches.enabled = branches or self.graph_branches
+        mode = "global"
+        if self.reducer.active:
+            # ProcessGroupNCCL's watchdog thread polls the completion events of the EAGER collectives issued so far; an
+            # event query from another thread while a capture in "global" mode is open is an error that takes the
+            # process down (hipErrorStreamCaptureUnsupported thrown inside the watchdog).  The device is idle (synchronize
+            # above): give the watchdog one polling period to retire those works, and capture in thread-local mode so
+            # that a straggling query is legal.  Collectives issued DURING capture are not handed to the watchdog.
+            import time
+            time.sleep(0.3)
+            mode = "thread_local"
         try:
-            with torch.cuda.graph(graph, pool=self._graph_pool):
+            with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):
                 ops.RT.new_step(0, write_salt=False)    # offsets restart; the salt word is read by the kernels at replay
                 loss = self._forward_backward(task, sb)
                 a.clip_and_step(None, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
