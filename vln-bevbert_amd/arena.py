@@ -142,7 +142,7 @@ class ParamArena:
             ops.WgradStream.flush_all()
             cur = torch.cuda.current_stream(self.device)
             for side in ops.Branches.side_streams():
-                if ops.Branches.enabled or side is not ops.WgradStream.stream or ops.WgradStream.dirty:
+                if ops.Branches.enabled or side not in ops.WgradStream.streams or ops.WgradStream.dirty:
                     cur.wait_stream(side)
             ops.WgradStream.dirty = False
             ops.WgradStream.release()

@@ -178,6 +178,12 @@ class WgradStream:
     # BEVBERT_STREAMS=1 on separate streams, eager and captured), and three streams measure fastest
     OWN_STREAM = _os.environ.get("BEVBERT_WGRAD_OWN_STREAM", "1") == "1"
     stream = None
+    streams = []
+    # BEVBERT_WGRAD_STREAMS=2: batches of deferred work alternate between two streams (independent weight-gradient GEMMs
+    # of different layers next to each other).  Only sensible inside captured steps, where the extra events are free.
+    NSTREAMS = int(_os.environ.get("BEVBERT_WGRAD_STREAMS", "2"))
+    _rr = 0
+    _target = None       # stream the deferred closures are being issued on right now
     dirty = False        # work has been enqueued on the stream since the last join (ParamArena.sync)
     _keep = []
     _pending = {}        # producing stream handle -> (torch stream, [closures])
@@ -207,7 +213,7 @@ class WgradStream:
             cls._flush(slot)
 
     @classmethod
-    def _flush(cls, slot):
+    def _flush(cls, slot, final=False):
         producer, fns = slot
         if not fns:
             return
@@ -216,18 +222,33 @@ class WgradStream:
             cls.stream = shared if shared is not None else torch.cuda.Stream(producer.device)
             Branches._streams["wgrad"] = cls.stream       # joined by ParamArena.sync / GradReducer like the branches
             cls._events = [torch.cuda.Event() for _ in range(64)]
-        if producer.cuda_stream != cls.stream.cuda_stream:          # same stream: already in order
+            cls.streams = [cls.stream]
+            for i in range(1, cls.NSTREAMS):              # further streams: batches of deferred work go round robin
+                st = torch.cuda.Stream(producer.device)
+                Branches._streams[f"wgrad{i}"] = st
+                cls.streams.append(st)
+        if final or len(cls.streams) == 1:
+            target = cls.stream
+        else:
+            cls._rr += 1
+            target = cls.streams[cls._rr % len(cls.streams)]
+        if producer.cuda_stream != target.cuda_stream:              # same stream: already in order
             ev = cls._events[cls._next_event % len(cls._events)]
             cls._next_event += 1
             ev.record(producer)
-            cls.stream.wait_event(ev)
-        lib.set_stream_override(cls.stream.cuda_stream)
+            target.wait_event(ev)
+        if final:        # the batched reductions read what every weight-gradient stream produced
+            for st in cls.streams[1:]:
+                target.wait_stream(st)
+        lib.set_stream_override(target.cuda_stream)
+        cls._target = target
         cls.dirty = True
         try:
             for fn in fns:
                 fn()
         finally:
             lib.set_stream_override(None)
+            cls._target = None
             fns.clear()
 
     @classmethod
@@ -246,7 +267,7 @@ class WgradStream:
                 for other in cls._pending.values():
                     if other is not mine:
                         cls._flush(other)
-                cls._flush(mine)
+                cls._flush(mine, final=True)
                 return
             ReduceQueue.flush(dev)
         for slot in cls._pending.values():
@@ -618,7 +639,7 @@ def _on_launch_stream(fn):
     """Run a torch op on the stream the C-ABI launches currently go to (fallback paths inside a WgradStream section)."""
     if lib._override is None:
         return fn()
-    with torch.cuda.stream(WgradStream.stream):
+    with torch.cuda.stream(WgradStream._target or WgradStream.stream):
         return fn()
 
 

@@ -107,7 +107,7 @@ class GradReducer:
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())     # everything enqueued so far has produced `view`
             for side in ops.Branches.side_streams():                 # ... including side streams that carry work of
-                if ops.Branches.enabled or side is not ops.WgradStream.stream or ops.WgradStream.dirty:   # this step
+                if ops.Branches.enabled or side not in ops.WgradStream.streams or ops.WgradStream.dirty:   # this step
                     self.stream.wait_stream(side)
             with torch.cuda.stream(self.stream):
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
