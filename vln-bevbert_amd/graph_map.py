@@ -6,12 +6,17 @@ dict-of-dicts Floyd graph, and rebuilds the navigation inputs of every step with
 (map_nav_src/r2r/agent.py:194-337).  Between the three model calls of a step this is what the fine-tune path waits on.
 
 Here:
-  * ``FloydGraph``: the same incremental all-pairs relaxation on dense numpy matrices (one vectorised update per visited
-    node instead of a V^2 Python loop); distances, next-hop table and ``path`` reproduce the reference exactly.
-  * ``GraphMapBatch``: all B episodes of a rollout.  Node embeddings live in ONE (B, cap, H) device tensor of running
-    sums + a count tensor, updated functionally with two ``index_put`` per step (autograd flows through them across
-    steps like it does through the reference's stored tensors); the per-step navigation inputs
-    (``nav_gmap_variable``) are assembled with numpy fancy indexing and one device gather.
+  * ``GraphMapBatch``: all B episodes of a rollout as dense BATCHED arrays -- node positions (B, cap, 3), the Floyd
+    distance and next-hop matrices (B, cap, cap), visited flags, step ids, embedding slots.  The incremental all-pairs
+    relaxation is one masked minimum for the new edges of the whole batch plus ONE batched comparison through the
+    current viewpoints per step; hop counts come from the next-hop tables bottom-up (no recursion); the per-step
+    navigation inputs (``nav_gmap_variable``: visited-first ordering by a stable argsort, pair distances, position
+    features) are numpy over (B, nodes).  Python only resolves viewpoint names to node indices.  Distances, next-hop
+    tables, paths, orderings and features reproduce the reference bit for bit (golden ``graph_nav.npz``).
+  * Node embeddings live in ONE (B, cap, H) device tensor of running sums + a count tensor, updated functionally with
+    two ``index_put`` per step (autograd flows through them across steps like it does through the reference's stored
+    tensors) and read with one device gather.
+  * ``FloydGraph`` is the single-episode form of the same relaxation (kept for callers that want one graph).
   * Point clouds are never stored: a node remembers its row in the device-resident ``feature_store.GridFeatureStore``
     and its camera poses; ``bev_inputs`` returns, per sample, the store rows of the current viewpoint and its visited
     neighbours (``pc_order`` hops) in the order the reference concatenates them, the depths gathered from the store and
@@ -121,50 +126,151 @@ class FloydGraph:
         return m
 
 
-class _Episode:
-    def __init__(self, start_vp):
+class _EpisodeView:
+    """Per-episode window onto the batched state (what callers that think in episodes see: tests, ``gather_nodes``)."""
+
+    def __init__(self, owner, b, start_vp):
+        self._o, self._b = owner, b
         self.start_vp = start_vp
-        self.node_positions = {}        # insertion order = the reference's node_positions order
-        self.graph = FloydGraph()
+        self.index = {}                 # vp -> node index: registration order = the reference's node_positions order
+        self.names = []
         self.node_slot = {}             # vp -> column of the batch's embedding buffers
-        self.node_step_ids = {}
         self.pc_nodes = {}              # vp -> (store row, T_c2w (V,4,4) float32): visited nodes, in visit order
+        self.graph = self
+
+    # FloydGraph's read interface (graph_utils.py:44-94) on the batched matrices
+    def visited(self, k):
+        i = self.index.get(k)
+        return i is not None and bool(self._o.visited[self._b, i])
+
+    def distance(self, x, y):
+        if x == y:
+            return 0
+        i, j = self.index.get(x), self.index.get(y)
+        return float(_INF) if i is None or j is None else float(self._o.dis[self._b, i, j])
+
+    def path(self, x, y):
+        if x == y:
+            return []
+        i, j = self.index[x], self.index[y]
+        k = int(self._o.point[self._b, i, j])
+        if k < 0:
+            return [y]
+        kn = self.names[k]
+        return self.path(x, kn) + self.path(kn, y)
+
+    @property
+    def node_positions(self):
+        return {vp: tuple(self._o.pos[self._b, i]) for i, vp in enumerate(self.names)}
+
+    @property
+    def node_step_ids(self):
+        st = self._o.step_ids[self._b]
+        return {vp: int(st[i]) for i, vp in enumerate(self.names) if st[i] != 0}
 
 
 class GraphMapBatch:
-    def __init__(self, start_vps, hidden_size, device, dtype=torch.float32, capacity=64):
-        self.eps = [_Episode(vp) for vp in start_vps]
+    """All B episodes of a rollout as dense batched arrays: positions (B, cap, 3), Floyd distance / next-hop matrices
+    (B, cap, cap), visited flags, step ids, embedding slots -- every per-step builder is numpy over (B, nodes); Python
+    only resolves viewpoint names to node indices (a few dict lookups per sample)."""
+
+    def __init__(self, start_vps, hidden_size, device, dtype=torch.float32, capacity=64, node_capacity=32):
         self.B, self.H, self.device, self.dtype = len(start_vps), hidden_size, torch.device(device), dtype
+        self.eps = [_EpisodeView(self, b, vp) for b, vp in enumerate(start_vps)]
         self.cap = capacity
         self.embed_sum = torch.zeros(self.B, capacity, hidden_size, dtype=dtype, device=self.device)
         self.embed_cnt = torch.zeros(self.B, capacity, dtype=torch.float32, device=self.device)
+        self.ncap = 0
+        self.n = np.zeros(self.B, dtype=np.int64)
+        self._alloc(node_capacity)
+        self._hops = None               # hop counts of the current graphs (rebuilt after update_graph)
+
+    def _alloc(self, ncap):
+        B, old = self.B, self.ncap
+        pos = np.zeros((B, ncap, 3))
+        dis = np.full((B, ncap, ncap), float(_INF))
+        point = np.full((B, ncap, ncap), -1, dtype=np.int32)             # -1: direct edge ("" in the reference)
+        visited = np.zeros((B, ncap), dtype=bool)
+        step_ids = np.zeros((B, ncap), dtype=np.int64)
+        slot = np.full((B, ncap), -1, dtype=np.int64)
+        if old:
+            pos[:, :old], visited[:, :old], step_ids[:, :old], slot[:, :old] = self.pos, self.visited, self.step_ids, self.slot
+            dis[:, :old, :old], point[:, :old, :old] = self.dis, self.point
+        self.pos, self.dis, self.point, self.visited, self.step_ids, self.slot = pos, dis, point, visited, step_ids, slot
+        self.ncap = ncap
+
+    def _node(self, b, vp):
+        ep = self.eps[b]
+        i = ep.index.get(vp)
+        if i is None:
+            i = ep.index[vp] = len(ep.names)
+            ep.names.append(vp)
+            self.n[b] = i + 1
+            if i >= self.ncap:
+                self._alloc(2 * self.ncap)
+        return i
 
     # -- graph structure (host) ----------------------------------------------------------------------------------
     def update_graph(self, obs, ended=None):
-        """GraphMap.update_graph for every live episode (graph_utils.py:109-115; agent.py:447-449,556-559)."""
-        for i, ob in enumerate(obs):
-            if ended is not None and ended[i]:
+        """GraphMap.update_graph for every live episode (graph_utils.py:109-115; agent.py:447-449,556-559): edges of the
+        whole batch in one masked minimum, then ONE batched relaxation through the current viewpoints."""
+        eb, ei, ej, pa, pb_, lb, lk = [], [], [], [], [], [], []
+        for b, ob in enumerate(obs):
+            if ended is not None and ended[b]:
                 continue
-            ep = self.eps[i]
-            ep.node_positions[ob["viewpoint"]] = ob["position"]
+            cur = self._node(b, ob["viewpoint"])
+            self.pos[b, cur] = ob["position"]
             for cc in ob["candidate"]:
-                ep.node_positions[cc["viewpointId"]] = cc["position"]
-                a, b = ob["position"], cc["position"]
-                dist = np.sqrt((b[0] - a[0]) ** 2 + (b[1] - a[1]) ** 2 + (b[2] - a[2]) ** 2)
-                ep.graph.add_edge(ob["viewpoint"], cc["viewpointId"], dist)
-            ep.graph.update(ob["viewpoint"])
+                j = self._node(b, cc["viewpointId"])
+                self.pos[b, j] = cc["position"]
+                eb.append(b)
+                ei.append(cur)
+                ej.append(j)
+                pa.append(ob["position"])
+                pb_.append(cc["position"])
+            lb.append(b)
+            lk.append(cur)
+        if not lb:
+            return
+        self._hops = None
+        if eb:
+            eb, ei, ej = np.asarray(eb), np.asarray(ei), np.asarray(ej)
+            d = np.asarray(pb_, dtype=np.float64) - np.asarray(pa, dtype=np.float64)
+            dist = np.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2 + d[:, 2] ** 2)
+            better = dist < self.dis[eb, ei, ej]
+            eb, ei, ej, dist = eb[better], ei[better], ej[better], dist[better]
+            self.dis[eb, ei, ej] = dist
+            self.dis[eb, ej, ei] = dist
+            self.point[eb, ei, ej] = -1
+            self.point[eb, ej, ei] = -1
+        # relax every pair through k = the current viewpoint (graph_utils.py:63-72).  Row / column k cannot change
+        # during the reference's double loop (the diagonal stays 'infinite'), so one comparison is the same sequence
+        lb, lk = np.asarray(lb), np.asarray(lk)
+        nm = int(self.n[lb].max())
+        d = self.dis[lb, :nm, :nm]
+        ar = np.arange(len(lb))
+        via = d[ar, :, lk][:, :, None] + d[ar, lk, :][:, None, :]
+        better = via < d
+        better[:, np.arange(nm), np.arange(nm)] = False
+        d[better] = via[better]
+        pt = self.point[lb, :nm, :nm]
+        pt[better] = np.broadcast_to(lk[:, None, None], better.shape)[better]
+        self.dis[lb, :nm, :nm] = d
+        self.point[lb, :nm, :nm] = pt
+        self.visited[lb, lk] = True
 
     def set_step_ids(self, obs, t, ended=None):
         """agent.py:471-474."""
-        for i, ob in enumerate(obs):
-            if ended is None or not ended[i]:
-                self.eps[i].node_step_ids[ob["viewpoint"]] = t + 1
+        for b, ob in enumerate(obs):
+            if ended is None or not ended[b]:
+                self.step_ids[b, self._node(b, ob["viewpoint"])] = t + 1
 
-    def _slot(self, i, vp):
-        ep = self.eps[i]
+    def _slot(self, b, vp):
+        ep = self.eps[b]
         s = ep.node_slot.get(vp)
         if s is None:
             s = ep.node_slot[vp] = len(ep.node_slot)
+            self.slot[b, self._node(b, vp)] = s
             if s >= self.cap:
                 grow = self.cap
                 self.embed_sum = torch.cat([self.embed_sum, self.embed_sum.new_zeros(self.B, grow, self.H)], 1)
@@ -185,7 +291,7 @@ class GraphMapBatch:
             rb.append(i)
             rs.append(self._slot(i, ob["viewpoint"]))
             for j, vp in enumerate(cand_vpids[i]):
-                if not ep.graph.visited(vp):
+                if not ep.visited(vp):
                     ab.append(i)
                     as_.append(self._slot(i, vp))
                     aj.append(j)
@@ -207,107 +313,116 @@ class GraphMapBatch:
         s = self.eps[i].node_slot[vp]
         return self.embed_sum[i, s] / self.embed_cnt[i, s]
 
+    # -- hop counts -------------------------------------------------------------------------------------------------
+    def hops(self):
+        """(B, nmax, nmax) int: len(FloydGraph.path(x, y)) for every pair, from the next-hop tables the way the
+        reference's recursion reads them (path(x, y) = path(x, k) + path(k, y), k = point[x][y]; a direct edge -- or no
+        known path -- is one hop; x == y is none).  Resolved bottom-up: an entry is known once both halves are."""
+        if self._hops is not None:
+            return self._hops
+        nm = max(1, int(self.n.max()))
+        P = self.point[:, :nm, :nm]
+        L = np.where(P < 0, 1, -1).astype(np.int64)
+        L[:, np.arange(nm), np.arange(nm)] = 0
+        Pc = np.clip(P, 0, None).astype(np.int64)
+        for _ in range(nm + 1):
+            todo = L < 0
+            if not todo.any():
+                break
+            lik = np.take_along_axis(L, Pc, axis=2)             # L[b, i, k(b, i, j)]
+            lkj = np.take_along_axis(L, Pc, axis=1)             # L[b, k(b, i, j), j]
+            ok = todo & (lik >= 0) & (lkj >= 0)
+            L[ok] = (lik + lkj)[ok]
+        self._hops = L
+        return L
+
     # -- per-step navigation inputs ------------------------------------------------------------------------------
+    def _pos_fts_rows(self, b, cur, tgt, heading, elevation, angle_feat_size):
+        """Rows of get_pos_fts (graph_utils.py:149-172) for flat index arrays: sample b, origin node cur, target node
+        tgt (all (n,)), the agent's heading / elevation per row."""
+        h, e, d = rel_pos_fts(self.pos[b, cur], self.pos[b, tgt], heading, elevation)
+        ang = angle_fts(h.astype(np.float32), e.astype(np.float32), angle_feat_size)
+        same = cur == tgt
+        gd = np.where(same, 0.0, self.dis[b, cur, tgt])
+        hp = self.hops()[b, cur, tgt]
+        dist = np.stack([d / MAX_DIST, gd / MAX_DIST, hp / MAX_STEP], 1).astype(np.float32)
+        return np.concatenate([ang, dist], 1)
+
     def pos_fts(self, i, cur_vp, vpids, cur_heading, cur_elevation, angle_feat_size=4):
-        """GraphMap.get_pos_fts (graph_utils.py:149-172), vectorised over the nodes; None = the [stop] token."""
+        """GraphMap.get_pos_fts for one sample; None = the [stop] token."""
         ep = self.eps[i]
         out = np.zeros((len(vpids), angle_feat_size + 3), dtype=np.float32)
+        out[:, :angle_feat_size] = angle_fts(np.zeros(1, np.float32), np.zeros(1, np.float32), angle_feat_size)
         real = [k for k, vp in enumerate(vpids) if vp is not None]
-        ang = np.zeros((len(vpids), 2), dtype=np.float32)
-        dists = np.zeros((len(vpids), 3), dtype=np.float32)
         if real:
-            pos = np.asarray([ep.node_positions[vpids[k]] for k in real], dtype=np.float64)
-            h, e, d = rel_pos_fts(ep.node_positions[cur_vp], pos, cur_heading, cur_elevation)
-            ang[real, 0], ang[real, 1] = h, e
-            dists[real, 0] = d / MAX_DIST
-            dists[real, 1] = [ep.graph.distance(cur_vp, vpids[k]) / MAX_DIST for k in real]
-            dists[real, 2] = [len(ep.graph.path(cur_vp, vpids[k])) / MAX_STEP for k in real]
-        out[:, :angle_feat_size] = angle_fts(ang[:, 0], ang[:, 1], angle_feat_size)
-        out[:, angle_feat_size:] = dists
+            tgt = np.asarray([ep.index[vpids[k]] for k in real])
+            cur = np.full(len(real), ep.index[cur_vp])
+            out[real] = self._pos_fts_rows(np.full(len(real), i), cur, tgt, cur_heading, cur_elevation, angle_feat_size)
         return out
 
-    def pos_fts_batch(self, obs, vpid_lists, angle_feat_size=4):
-        """pos_fts for every sample with ONE pass of numpy over all (sample, node) pairs: per-sample Python only walks
-        the graphs (distances are matrix rows, hop counts come from the next-hop table)."""
-        org, tgt, bh, be, gd, hops, where = [], [], [], [], [], [], []
-        for i, (ob, g) in enumerate(zip(obs, vpid_lists)):
-            ep = self.eps[i]
-            cur = ob["viewpoint"]
-            a = ep.node_positions[cur]
-            for k, vp in enumerate(g):
-                if vp is None:
-                    continue
-                org.append(a)
-                tgt.append(ep.node_positions[vp])
-                bh.append(ob["heading"])
-                be.append(ob["elevation"])
-                gd.append(ep.graph.distance(cur, vp))
-                hops.append(len(ep.graph.path(cur, vp)))
-                where.append((i, k))
-        stop = angle_fts(np.zeros(1, np.float32), np.zeros(1, np.float32), angle_feat_size)   # angles (0, 0) -> (0, 1, 0, 1)
-        outs = [np.zeros((len(g), angle_feat_size + 3), dtype=np.float32) for g in vpid_lists]
-        for o in outs:
-            o[:, :angle_feat_size] = stop
-        if where:
-            h, e, d = rel_pos_fts(np.asarray(org), np.asarray(tgt), np.asarray(bh), np.asarray(be))
-            ang = angle_fts(h.astype(np.float32), e.astype(np.float32), angle_feat_size)
-            dist = np.stack([d / MAX_DIST, np.asarray(gd) / MAX_DIST, np.asarray(hops) / MAX_STEP], 1).astype(np.float32)
-            for r, (i, k) in enumerate(where):
-                outs[i][k, :angle_feat_size] = ang[r]
-                outs[i][k, angle_feat_size:] = dist[r]
-        return outs
-
     def nav_gmap_variable(self, obs, enc_full_graph=True, act_visited_nodes=False, angle_feat_size=4):
-        """agent.py:194-276 (_nav_gmap_variable): [stop] + map nodes per sample, padded to the batch maximum."""
+        """agent.py:194-276 (_nav_gmap_variable): [stop] + map nodes per sample (visited nodes first, each group in
+        registration order), padded to the batch maximum."""
         B = self.B
-        vpids, visited, step_ids, pos, pair, slots, no_left = [], [], [], [], [], [], []
-        for i, ob in enumerate(obs):
-            ep = self.eps[i]
-            vis, unvis = [], []
-            for k in ep.node_positions.keys():
-                is_vis = (k == ob["viewpoint"]) if act_visited_nodes else ep.graph.visited(k)
-                (vis if is_vis else unvis).append(k)
-            no_left.append(len(unvis) == 0)
-            if enc_full_graph:
-                g = [None] + vis + unvis
-                m = [0] + [1] * len(vis) + [0] * len(unvis)
-            else:
-                g = [None] + unvis
-                m = [0] * len(g)
-            vpids.append(g)
-            visited.append(m)
-            step_ids.append([ep.node_step_ids.get(vp, 0) for vp in g])
-            pd = np.zeros((len(g), len(g)), dtype=np.float32)
-            if len(g) > 1:
-                pd[1:, 1:] = (ep.graph.submatrix(g[1:]) / MAX_DIST).astype(np.float32)
-            pair.append(pd)
-            slots.append([-1] + [ep.node_slot[vp] for vp in g[1:]])
-        pos = self.pos_fts_batch(obs, vpids, angle_feat_size)
-        lens = np.asarray([len(g) for g in vpids])
-        G = int(lens.max())
-        pad = lambda rows, fill, dt: np.stack([np.concatenate([np.asarray(r, dtype=dt),
-                                                               np.full((G - len(r),) + np.asarray(r).shape[1:], fill, dtype=dt)])
-                                               for r in rows])
-        slot_np = pad(slots, -1, np.int64)
+        n = self.n
+        nm = max(1, int(n.max()))
+        cur = np.asarray([self.eps[b].index[ob["viewpoint"]] for b, ob in enumerate(obs)])
+        heading = np.asarray([ob["heading"] for ob in obs], dtype=np.float64)
+        elevation = np.asarray([ob["elevation"] for ob in obs], dtype=np.float64)
+        col = np.arange(nm)
+        valid = col[None] < n[:, None]
+        vis = (col[None] == cur[:, None]) if act_visited_nodes else self.visited[:, :nm]
+        vis = vis & valid
+        key = np.where(valid, np.where(vis, 0, 1), 2) * nm + col[None]
+        order = np.argsort(key, axis=1, kind="stable")                      # visited | unvisited | unused, each in order
+        nvis = vis.sum(1)
+        first = np.zeros(B, dtype=np.int64) if enc_full_graph else nvis
+        cnt = n - first
+        G = 1 + int(cnt.max())
+        j = np.arange(G - 1)
+        real = j[None] < cnt[:, None]                                       # (B, G-1)
+        node = np.take_along_axis(order, np.minimum(first[:, None] + j[None], nm - 1), axis=1)
+        node = np.where(real, node, 0)
+        bi = np.arange(B)[:, None]
+        lens = cnt + 1
+        masks = np.arange(G)[None] < lens[:, None]
+        visited = np.zeros((B, G), dtype=bool)
+        if enc_full_graph:
+            visited[:, 1:] = vis[bi, node] & real
+        step_ids = np.zeros((B, G), dtype=np.int64)
+        step_ids[:, 1:] = np.where(real, self.step_ids[bi, node], 0)
+        slot_np = np.full((B, G), -1, dtype=np.int64)
+        slot_np[:, 1:] = np.where(real, self.slot[bi, node], -1)
         pair_np = np.zeros((B, G, G), dtype=np.float32)
-        for i, pd in enumerate(pair):
-            pair_np[i, :len(pd), :len(pd)] = pd
+        sub = self.dis[bi[:, :, None], node[:, :, None], node[:, None, :]] / MAX_DIST
+        sub[:, np.arange(G - 1), np.arange(G - 1)] = 0.0
+        pair_np[:, 1:, 1:] = np.where(real[:, :, None] & real[:, None, :], sub, 0.0).astype(np.float32)
+        pos = np.zeros((B, G, angle_feat_size + 3), dtype=np.float32)
+        pos[:, :, :angle_feat_size] = np.where(masks[..., None],
+                                               angle_fts(np.zeros(1, np.float32), np.zeros(1, np.float32), angle_feat_size), 0)
+        rb, rj = np.nonzero(real)
+        if len(rb):
+            pos[rb, rj + 1] = self._pos_fts_rows(rb, cur[rb], node[rb, rj], heading[rb], elevation[rb], angle_feat_size)
+        vpids = []
+        for b in range(B):
+            names = self.eps[b].names
+            vpids.append([None] + [names[k] for k in node[b, :cnt[b]]])
         dev = self.device
         slot_t = torch.from_numpy(slot_np).to(dev)
-        valid = slot_t >= 0
-        bi = torch.arange(B, device=dev)[:, None].expand(-1, G)
+        ok = slot_t >= 0
+        bt = torch.arange(B, device=dev)[:, None].expand(-1, G)
         si = slot_t.clamp(min=0)
-        cnt = self.embed_cnt[bi, si].clamp(min=1.0).to(self.dtype)
-        embeds = (self.embed_sum[bi, si] / cnt[..., None]) * valid[..., None].to(self.dtype)    # [stop] / padding = 0
+        c = self.embed_cnt[bt, si].clamp(min=1.0).to(self.dtype)
+        embeds = (self.embed_sum[bt, si] / c[..., None]) * ok[..., None].to(self.dtype)    # [stop] / padding = 0
         return {
             "gmap_vpids": vpids, "gmap_img_embeds": embeds,
-            "gmap_step_ids": torch.from_numpy(pad(step_ids, 0, np.int64)).to(dev),
-            "gmap_pos_fts": torch.from_numpy(pad(pos, 0, np.float32)).to(dev),
-            "gmap_visited_masks": torch.from_numpy(pad(visited, 0, np.int64).astype(bool)).to(dev),
-            "gmap_visited_masks_cpu": torch.from_numpy(pad(visited, 0, np.int64).astype(bool)),
+            "gmap_step_ids": torch.from_numpy(step_ids).to(dev),
+            "gmap_pos_fts": torch.from_numpy(pos).to(dev),
+            "gmap_visited_masks": torch.from_numpy(visited).to(dev),
+            "gmap_visited_masks_cpu": torch.from_numpy(visited),
             "gmap_pair_dists": torch.from_numpy(pair_np).to(dev),
-            "gmap_masks": torch.from_numpy(np.arange(G)[None] < lens[:, None]).to(dev),
-            "no_vp_left": no_left,
+            "gmap_masks": torch.from_numpy(masks).to(dev),
+            "no_vp_left": [bool(x) for x in (n - nvis) == 0],
         }
 
     # -- BEV inputs: store rows instead of stored point clouds ---------------------------------------------------------
@@ -319,10 +434,10 @@ class GraphMapBatch:
         if not live:
             return
         xyzhe = np.zeros((len(live), views, 5))             # float64 like the agent's; the matrices are cast to fp32
-        for r, i in enumerate(live):
-            x, y, z = obs[i]["position"]
-            xyzhe[r, :, 0], xyzhe[r, :, 1], xyzhe[r, :, 2] = x, z, -y
-            xyzhe[r, :, 3] = -(np.arange(views) * np.radians(30) + obs[i]["heading"])
+        p = np.asarray([obs[i]["position"] for i in live], dtype=np.float64)
+        xyzhe[:, :, 0], xyzhe[:, :, 1], xyzhe[:, :, 2] = p[:, None, 0], p[:, None, 2], -p[:, None, 1]
+        hd = np.asarray([obs[i]["heading"] for i in live], dtype=np.float64)
+        xyzhe[:, :, 3] = -(np.arange(views)[None] * np.radians(30) + hd[:, None])
         xyzhe[:, :, 4] = np.pi
         T = pose_matrix(xyzhe.reshape(-1, 5)).reshape(len(live), views, 4, 4)
         for r, i in enumerate(live):
@@ -334,7 +449,8 @@ class GraphMapBatch:
         ep = self.eps[i]
         if order == 0:
             return [vp]
-        return [c for c in ep.pc_nodes.keys() if len(ep.graph.path(vp, c)) <= order]
+        hp = self.hops()[i, ep.index[vp]]
+        return [c for c in ep.pc_nodes.keys() if hp[ep.index[c]] <= order]
 
     def bev_inputs(self, obs, store, pc_order=1, bev_dim=21, bev_res=0.5):
         """agent.py:143-192,282-337 (splat + _nav_bev_variable) as inputs of the fused kernels: per sample the R store
@@ -345,18 +461,20 @@ class GraphMapBatch:
         R = max(len(n) for n in nodes)
         V = store.V
         rows = np.zeros((B, R), dtype=np.int32)
-        T_c2w = np.zeros((B, R * V, 4, 4), dtype=np.float32)
+        T_c2w = np.zeros((B, R, V, 4, 4), dtype=np.float32)
         live = np.zeros((B, R), dtype=bool)
         for i, ns in enumerate(nodes):
+            pc = self.eps[i].pc_nodes
             for r, vp in enumerate(ns):
-                rows[i, r], T_c2w[i, r * V:(r + 1) * V] = self.eps[i].pc_nodes[vp]
-                live[i, r] = True
+                rows[i, r], T_c2w[i, r] = pc[vp]
+            live[i, :len(ns)] = True
             rows[i, len(ns):] = rows[i, 0]
         dev = self.device
         rows_t = torch.from_numpy(rows).to(dev)
         depths = store.depths.index_select(0, rows_t.reshape(-1).long()).reshape(B, R * V, store.hw, store.hw)
         depths = depths * torch.from_numpy(live).to(dev).repeat_interleave(V, 1)[..., None, None]   # padding: no depth
-        S = np.asarray([[ob["position"][0], ob["position"][2], -ob["position"][1]] for ob in obs], dtype=np.float32)
+        P = np.asarray([ob["position"] for ob in obs], dtype=np.float32)
+        S = np.stack([P[:, 0], P[:, 2], -P[:, 1]], 1)
         xyzhe = np.zeros((B, 5))
         xyzhe[:, 3] = [ob["heading"] for ob in obs]
         K = bev_dim * bev_dim
@@ -369,33 +487,42 @@ class GraphMapBatch:
             cand_np[i, 0] = (K - 1) // 2                      # [stop]: the centre cell (agent.py:318)
             cand_np[i, 1:1 + len(c)] = c
             nav_masks[i, cand_np[i, :1 + len(c)]] = True
-        gpos = [g[0] for g in self.pos_fts_batch(obs, [[ep.start_vp] for ep in self.eps])]
+        ar = np.arange(B)
+        cur = np.asarray([self.eps[b].index[ob["viewpoint"]] for b, ob in enumerate(obs)])
+        start = np.asarray([self.eps[b].index[self.eps[b].start_vp] for b in range(B)])
+        gpos = self._pos_fts_rows(ar, cur, start, np.asarray([ob["heading"] for ob in obs], dtype=np.float64),
+                                  np.asarray([ob["elevation"] for ob in obs], dtype=np.float64), 4)
         return {
-            "grid_rows": rows_t, "depths": depths, "T_c2w": torch.from_numpy(T_c2w).to(dev),
+            "grid_rows": rows_t, "depths": depths, "T_c2w": torch.from_numpy(T_c2w.reshape(B, R * V, 4, 4)).to(dev),
             "T_w2c": torch.from_numpy(pose_matrix(xyzhe)).to(dev)[:, None], "S_w2c": torch.from_numpy(S).to(dev)[:, None],
             "bev_nav_masks": torch.from_numpy(nav_masks).to(dev), "bev_cand_idxs": torch.from_numpy(cand_np).to(dev),
-            "bev_cand_vpids": cand_vpids, "bev_gpos_fts": torch.from_numpy(np.stack(gpos)).to(dev)[:, None],
+            "bev_cand_vpids": cand_vpids, "bev_gpos_fts": torch.from_numpy(gpos).to(dev)[:, None],
         }
 
     @staticmethod
     def cand_cells_batch(obs, bev_dim, bev_res):
-        """cand_cells for every sample: the poses of the whole batch come from one pose_matrix call; the 4-term
-        products stay per-sample numpy matmuls (same BLAS path, hence the same roundings, as the reference's np.dot)."""
-        flip = np.array([1, 1, -1], dtype=np.float32)
+        """cand_cells for every sample: one pass of numpy over all candidates of the batch; only the 4-term products stay
+        per-sample numpy matmuls (same BLAS path, hence the same roundings, as the reference's np.dot)."""
+        counts = [len(ob["candidate"]) for ob in obs]
+        total = sum(counts)
+        if total == 0:
+            return [np.zeros(0, dtype=np.int64) for _ in obs]
         xyzhe = np.zeros((len(obs), 5))
         xyzhe[:, 3] = [-ob["heading"] for ob in obs]
         T = pose_matrix(xyzhe)
-        out = []
-        for i, ob in enumerate(obs):
-            if not ob["candidate"]:
-                out.append(np.zeros(0, dtype=np.int64))
-                continue
-            S = np.asarray(ob["position"], dtype=np.float32)[[0, 2, 1]] * flip
-            p = np.asarray([c["position"] for c in ob["candidate"]], dtype=np.float32)[:, [0, 2, 1]] * flip - S
-            p1 = np.concatenate([p, np.ones((p.shape[0], 1), dtype=np.float32)], -1) @ T[i]    # see cand_cells
-            c = np.clip(np.round(p1[:, [0, 2]] / bev_res) + (bev_dim - 1) // 2, 0, bev_dim - 1).astype(np.int64)
-            out.append(c[:, 1] * bev_dim + c[:, 0])
-        return out
+        flip = np.array([1, 1, -1], dtype=np.float32)
+        S = np.asarray([ob["position"] for ob in obs], dtype=np.float32)[:, [0, 2, 1]] * flip
+        P = np.asarray([c["position"] for ob in obs for c in ob["candidate"]], dtype=np.float32)[:, [0, 2, 1]] * flip
+        P = P - np.repeat(S, counts, axis=0)
+        p1 = np.concatenate([P, np.ones((total, 1), dtype=np.float32)], -1)
+        ends = np.cumsum(counts)
+        q = np.empty((total, 4), dtype=np.float32)
+        for i, n in enumerate(counts):
+            if n:
+                q[ends[i] - n:ends[i]] = p1[ends[i] - n:ends[i]] @ T[i]                              # see cand_cells
+        c = np.clip(np.round(q[:, [0, 2]] / bev_res) + (bev_dim - 1) // 2, 0, bev_dim - 1).astype(np.int64)
+        cells = c[:, 1] * bev_dim + c[:, 0]
+        return [cells[ends[i] - n:ends[i]] for i, n in enumerate(counts)]
 
     @staticmethod
     def cand_cells(ob, bev_dim, bev_res):
