@@ -557,8 +557,7 @@ def test_lt_gemm_linear_fwd_dgrad_wgrad(ops, M, N, K, dtype):
     b = torch.randn(N, generator=g).to(DEV, dtype)
     dy = torch.randn(M, N, generator=g).to(DEV, dtype)
     tol = 1e-4 if dtype == torch.float32 else 1e-2
-    from vln_bevbert_amd import lib
-    before = lib.load().bevbert_gemm_plan_count()
+    fallbacks_before = sum(ops.GEMM_FALLBACKS.values())
     ops._linear_fwd(x, w, b)          # first launch of the problem: candidates are timed, the plan is final afterwards
     y = ops._linear_fwd(x, w, b)
     ref = x.double() @ w.double().t() + b.double()
@@ -567,8 +566,8 @@ def test_lt_gemm_linear_fwd_dgrad_wgrad(ops, M, N, K, dtype):
     assert rel_err(dx, dy.double() @ w.double()) < tol
     dw = ops._linear_wgrad(dy, x)
     assert rel_err(dw, dy.double().t() @ x.double()) < tol
-    if not ops._LT_UNSUPPORTED:
-        assert lib.load().bevbert_gemm_plan_count() >= before + 3      # the C-ABI path ran, not torch
+    if not ops._LT_UNSUPPORTED:      # the C-ABI path ran, not torch (plans may exist already when other tests ran first)
+        assert sum(ops.GEMM_FALLBACKS.values()) == fallbacks_before, ops.GEMM_FALLBACKS
     # cached plan: same answer on the second call, and a strided (row-sliced) input is honoured
     assert torch.equal(ops._linear_fwd(x, w, b), y)
     wide = torch.randn(M, K + 64, generator=g).to(DEV, dtype)
