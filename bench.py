@@ -22,7 +22,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")     # see vln_bevbert_amd/__init__.py; before hipBLASLt loads
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

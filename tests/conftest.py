@@ -1,4 +1,6 @@
 import os
+
+os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")     # see vln_bevbert_amd/__init__.py
 import sys
 
 import pytest

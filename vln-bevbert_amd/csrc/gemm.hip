@@ -151,6 +151,12 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
                hipStream_t stream) {
   const float alpha = 1.f, beta0 = p.accumulate ? 1.f : 0.f;
   void* scratch = nullptr;
+  // Time in isolation: the candidate list contains stream-K kernels whose workgroups spin on flags written by peer
+  // workgroups.  Exercised while another stream holds part of the chip with a kernel of the same kind, two partially
+  // resident grids can wait for each other's unscheduled peers (observed: a run with concurrent weight-gradient and
+  // forward timing passes on three streams never returned from hipEventSynchronize).  Nothing else is in flight after
+  // this call, and the host thread stays here until the choice is made.
+  (void)hipDeviceSynchronize();
   if (p.accumulate) {
     if (hipMalloc(&scratch, p.c_bytes) != hipSuccess || hipMemsetAsync(scratch, 0, p.c_bytes, stream) != hipSuccess) {
       if (scratch) (void)hipFree(scratch);

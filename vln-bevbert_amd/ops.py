@@ -174,8 +174,8 @@ class WgradStream:
     BATCH = int(_os.environ.get("BEVBERT_WGRAD_BATCH", "6"))
     DEFER_FINALIZE = _os.environ.get("BEVBERT_DEFER_FINALIZE", "1") == "1"      # A/B knob for the split reductions
     # own stream even next to ops.Branches (three streams).  Round 1 shared one side stream because three streams had
-    # stalled once at batch 64; that stall does not reproduce (scripts/probes/three_stream_probe.py, and bench.py with
-    # BEVBERT_STREAMS=1 on separate streams, eager and captured), and three streams measure fastest
+    # stalled at batch 64: stream-K library GEMMs spinning on each other across streams (the
+    # package sets TENSILE_STREAMK_DATA_PARALLEL=1); three to four streams measure fastest
     OWN_STREAM = _os.environ.get("BEVBERT_WGRAD_OWN_STREAM", "1") == "1"
     stream = None
     streams = []
@@ -644,6 +644,7 @@ def _on_launch_stream(fn):
 
 
 _SPLITK_ENABLED = _os.environ.get("BEVBERT_SPLITK", "1") == "1"     # A/B knob
+_SPLITK_MAX = int(_os.environ.get("BEVBERT_SPLITK_MAX", "16"))
 
 
 def _split_k(M, N, K):
@@ -656,7 +657,7 @@ def _split_k(M, N, K):
         return 1
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     s = 1
-    while s * 2 <= min(16, M // 640) and s * 2 * tiles <= 256 and M % (s * 2) == 0:
+    while s * 2 <= min(_SPLITK_MAX, M // 640) and s * 2 * tiles <= 256 and M % (s * 2) == 0:
         s *= 2
     return s
 
