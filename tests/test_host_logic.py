@@ -458,3 +458,45 @@ def test_hdf5_converter_on_synthetic_stores(tmp_path, monkeypatch):
     assert torch.equal(store.rgbs[r.long()][0], torch.from_numpy(data["rgb"][keys[1]].reshape(2352, 64)))
     assert torch.equal(store.depths[r.long()][0], torch.from_numpy(data["depth"][keys[1]]))
     assert torch.equal(store.sems[r.long()][0], torch.from_numpy(data["sem"][keys[1]].reshape(2352)))
+
+
+def test_text_layer_regions_partition_the_text_encoder():
+    """train.PretrainTrainer.text_layer_regions: the arena regions that go out during the text encoder's backward are
+    adjacent, ordered from the last hooked layer down, end where the text encoder ends, and stay below the map encoders
+    (whose region is phase A)."""
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=6, num_x_layers=1, vocab_size=300)
+    model = GlocalTextPathCMTPreTraining(cfg)
+    arena = model.finalize("cpu", torch.float32)
+    first_map = min(o for n, (o, k) in arena.slices.items()
+                    if n.startswith("bert.local_encoder") or n.startswith("bert.global_encoder") or not n.startswith("bert."))
+    text_end = max(o + k for n, (o, k) in arena.slices.items() if n.startswith("bert.lang_encoder."))
+    auto = PretrainTrainer.text_layer_regions(model, arena, "auto")
+    assert [k for k, _, _ in auto] == [4, 2]
+    for spec, want in (("auto", [4, 2]), ("1,3,5", [5, 3, 1]), ("", []), ("0,6,9", [])):
+        regs = PretrainTrainer.text_layer_regions(model, arena, spec)
+        assert [k for k, _, _ in regs] == want
+        hi = text_end
+        for k, lo, h in regs:
+            assert h == hi and lo < h <= first_map
+            assert lo == min(o for n, (o, _) in arena.slices.items() if n.startswith(f"bert.lang_encoder.layer.{k}."))
+            hi = lo
+
+
+def test_graph_map_hop_counts_equal_the_recursive_path_lengths():
+    """GraphMapBatch.hops() (bottom-up over the next-hop tables, all pairs of the whole batch at once) against
+    len(path(x, y)) of the reference's recursion, after every update of a rollout; nodes out of each other's reach and
+    x == y included."""
+    from vln_bevbert_amd.graph_map import GraphMapBatch
+    B, T = 6, 7
+    obs_all, ended_all = synthetic.make_nav_episodes(B, T, seed=5, n_nodes=12)
+    gm = GraphMapBatch([ob["viewpoint"] for ob in obs_all[0]], 8, "cpu", node_capacity=4)      # capacity 4: growth
+    for t in range(T):
+        gm.update_graph(obs_all[t], None if t == 0 else ended_all[t - 1])
+        L = gm.hops()
+        for b in range(B):
+            names = gm.eps[b].names
+            for i, x in enumerate(names):
+                for j, y in enumerate(names):
+                    assert L[b, i, j] == len(gm.eps[b].path(x, y)), (t, b, x, y)
