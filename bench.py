@@ -206,8 +206,8 @@ def main():
     if launch == "auto":
         # Eager issue and graph replay execute the same kernels on the same buffers (bit-identical losses:
         # tests/test_gpu_zz_streams.py); which one is faster depends on the box: eager keeps the weight-gradient work on
-        # a second hardware queue but needs ~16-21 ms of host time per step, the replay needs none but ROCm runs a graph
-        # with two branches through its slower multi-stream path.  Time one task cycle of each (untimed preparation)
+        # a second hardware queue but needs ~16-21 ms of host time per step; the replay needs ~2 ms and overlaps more
+        # streams, but runs through ROCm's multi-stream graph path.  Time one task cycle of each (untimed preparation)
         # and keep the faster mechanism for the warm-up and the timed region.
         def cycle_ms(use_graphs):
             trainer.use_graphs = use_graphs
@@ -225,6 +225,14 @@ def main():
         calibration = {"eager_ms_per_step": round(ms_eager, 3), "graph_ms_per_step": round(ms_graph, 3)}
         log(f"launch calibration: eager {ms_eager:.2f} ms/step, hipGraph replay {ms_graph:.2f} ms/step -> "
             f"{'graph' if trainer.use_graphs else 'eager'}")
+    # host cost of issuing ONE step with nothing queued behind it: a burst of 6 steps after a device synchronise.  The
+    # timed region's host_enqueue figure also contains the time the runtime makes the host wait once ~10 graph launches
+    # are in flight (back-pressure, not work: with 11 timed steps it reads 1.9 ms/step, with 22 steps 9.7 ms/step).
+    barrier()
+    t0 = time.perf_counter()
+    run(6)
+    host_burst_ms = 1000.0 * (time.perf_counter() - t0) / 6
+    barrier()
     log("warm-up")
     run(a.warmup)
     barrier()
@@ -252,6 +260,7 @@ def main():
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "params_M": round(arena.n_params / 1e6, 1), "gemm": f"hipBLASLt via the C ABI, {n_rows} shapes from the shipped choice table, others timed on first use"},
         "host_enqueue_ms_per_step": round(1000.0 * t_host / a.steps, 3),
+        "host_issue_ms_per_step_unthrottled": round(host_burst_ms, 3),
         "step_launch": f"hipGraph replay ({n_graphs} captured steps, one per resident batch)"
                        if (n_graphs and trainer.use_graphs) else "eager",
         "launch_calibration": calibration,
