@@ -9,7 +9,7 @@ follows.
 
 Allowed users: ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg -- as the checker / timed CPU baseline, never as the product
-path.  Nothing under ``vln-bevbert_amd/`` imports this module.
+path.  Nothing under ``vln_bevbert_amd/`` imports this module.
 
 Pinning: the reference has no tests of its own, so this oracle is
 pinned against golden vectors produced by importing the reference in the build

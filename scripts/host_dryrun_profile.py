@@ -85,6 +85,6 @@ st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(18)
 print("---- product functions by cumulative time (ms per step, cProfile-inflated) ----")
 rows = [(ct / n * 1e3, nc // n, f"{os.path.basename(fn)}:{ln}({name})") for (fn, ln, name), (cc, nc, tt, ct, _) in st.stats.items()
-        if "vln-bevbert_amd" in fn]
+        if "vln_bevbert_amd" in fn]
 for ct, nc, label in sorted(rows, reverse=True)[:22]:
     print(f"{ct:8.2f} ms  {nc:5d} calls  {label}")

@@ -12,7 +12,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, "vln-bevbert_amd", "tunableop_results.csv")
+OUT = os.path.join(ROOT, "vln_bevbert_amd", "tunableop_results.csv")
 os.environ.setdefault("PYTORCH_TUNABLEOP_ROCBLAS_ENABLED", "0")
 
 import torch  # noqa: E402

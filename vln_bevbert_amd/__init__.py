@@ -1,4 +1,4 @@
-"""vln-bevbert_amd: MI355X-native (gfx950) implementation of BEVBert's cross-modal transformer hot path.
+"""vln_bevbert_amd: MI355X-native (gfx950) implementation of BEVBert's cross-modal transformer hot path.
 
 Public surface (mirrors the reference's module boundary):
     GlocalTextPathCMT, GlocalTextPathCMTPreTraining      (pretrain_src/model/{vilmodel,pretrain_cmt}.py)
