@@ -80,16 +80,22 @@ int bevbert_bev_splat_mean(const void* feat, int feat_dtype, const int* order, c
 int bevbert_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask,
                      const float* bias, const int64_t* strides, int B, int nh, int Lq, int Lk, int head_dim,
                      float scale, int dtype, int impl, float drop_p, uint64_t seed, uint64_t offset,
-                     uint64_t* drop_bits, hipStream_t stream);
+                     uint64_t* drop_bits, int bits_ready, hipStream_t stream);
 int bevbert_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                      float* delta_ws, void* dq, void* dk, void* dv, float* dbias, const float* key_mask,
                      const float* bias, const int64_t* strides, int B, int nh, int Lq, int Lk, int head_dim,
                      float scale, int dtype, int impl, float drop_p, uint64_t seed, uint64_t offset,
                      const uint64_t* drop_bits, hipStream_t stream);
-/* drop_bits (may be NULL): keep-bit matrix of the dropout mask, bevbert_attn_drop_bits_words(B, nh, Lq, Lk) 64-bit words.
- * The bf16 forward stores the compare masks it computes anyway; the bf16 backward then reads one bit per score element
- * instead of re-hashing (NULL: the backward regenerates the mask from (seed, offset) -- same mask, more arithmetic). */
+/* drop_bits (may be NULL): keep-bit workspace of the dropout mask on the attention probabilities (nn.Dropout,
+ * vilmodel.py:134), bevbert_attn_drop_bits_words(B, nh, Lq, Lk) 64-bit words: the mask as one bit per score element,
+ * once in the lane layout of the forward's accumulators and once in the backward's.  The bf16 kernels read the bits with
+ * scalar loads and drop with one select per element instead of hashing per element.  bevbert_attn_drop_bits fills the
+ * workspace (any stream, any time before the forward: the mask is a pure function of seed, offset, step salt and
+ * element index); bevbert_attn_fwd does that itself first when bits_ready == 0.  NULL: both directions derive the mask
+ * from (seed, offset) inline (round-2 kernels) -- same mask, more arithmetic. */
 int64_t bevbert_attn_drop_bits_words(int B, int nh, int Lq, int Lk);
+int bevbert_attn_drop_bits(uint64_t* drop_bits, int B, int nh, int Lq, int Lk, float drop_p, uint64_t seed,
+                           uint64_t offset, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * K3  y = LayerNorm(dropout(x + bias) + residual).

@@ -467,6 +467,42 @@ def test_attention_single_pass_backward_equals_two_kernel_backward(ops, B, Lq, L
         assert rel_err(a, b_) < 1e-2, (name, rel_err(a, b_))
 
 
+@pytest.mark.parametrize("B,Lq,Lk", [(2, 441, 441), (1, 100, 140), (2, 80, 36), (1, 33, 448)])
+def test_attention_keep_bit_workspace_holds_the_exported_mask_in_both_layouts(ops, B, Lq, Lk):
+    """bevbert_attn_drop_bits: the forward-layout words (bit l = query 16 q16 + (l & 15), key 64 k64 + 16 t + 4 (l >> 4) + r)
+    and the backward-layout words (bit l = query 32 q32 + 16 tt + 4 (l >> 4) + r, key 16 k16 + (l & 15)) both decode to
+    the mask of the element-indexed stream every other dropout consumer uses."""
+    nh, p = 12, 0.1
+    ops.RT.new_step(77)
+    bits = ops.attn_drop_bits(B, nh, Lq, Lk, p, ops.RT.seed, 5, DEV).cpu().numpy().view(np.uint64)
+    Lk2 = (Lk + 1) // 2 * 2
+    keep = ops.dropout_keep_mask(B * nh * Lq * Lk2, p, ops.RT.seed, 5, DEV).view(B * nh, Lq, Lk2).cpu().numpy()
+    nq16, nk64 = (Lq + 127) // 128 * 8, (Lk + 63) // 64
+    half = B * nh * nq16 * nk64 * 16
+    assert bits.shape[0] == 2 * half
+    lanes = np.arange(64)
+    f = bits[:half].reshape(B * nh, nq16, nk64, 4, 4)
+    q = np.arange(nq16)[:, None, None, None, None] * 16 + (lanes & 15)
+    k = (np.arange(nk64)[None, :, None, None, None] * 64 + np.arange(4)[None, None, :, None, None] * 16
+         + (lanes >> 4) * 4 + np.arange(4)[None, None, None, :, None])
+    got = ((f[..., None] >> lanes.astype(np.uint64)) & np.uint64(1)).astype(bool)         # (bh, q16, k64, t, r, lane)
+    ok = (q < Lq) & (k < Lk)
+    qq, kk = np.broadcast_arrays(np.minimum(q, Lq - 1), np.minimum(k, Lk - 1))
+    want = keep[:, qq, kk]
+    assert np.array_equal(got[:, ok], want[:, ok]), "forward layout"
+    if not 256 < Lk <= 448:          # the backward layout is only produced for the shapes the 7+1-wave backward takes
+        return
+    bw = bits[half:].reshape(B * nh, nq16 // 2, nk64 * 4, 2, 4)
+    q = (np.arange(nq16 // 2)[:, None, None, None, None] * 32 + np.arange(2)[None, None, :, None, None] * 16
+         + (lanes >> 4) * 4 + np.arange(4)[None, None, None, :, None])
+    k = np.arange(nk64 * 4)[None, :, None, None, None] * 16 + (lanes & 15)
+    got = ((bw[..., None] >> lanes.astype(np.uint64)) & np.uint64(1)).astype(bool)
+    ok = (q < Lq) & (k < Lk)
+    qq, kk = np.broadcast_arrays(np.minimum(q, Lq - 1), np.minimum(k, Lk - 1))
+    want = keep[:, qq, kk]
+    assert np.array_equal(got[:, ok], want[:, ok]), "backward layout"
+
+
 def test_attention_packed_layouts(ops):
     """Packed QKV / KV operands (the layouts the model uses) give the same result as separate tensors."""
     B, L, H, nh = 2, 77, 768, 12

@@ -53,7 +53,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     rc = l.bevbert_bev_lift_bin(None, None, None, None, None, 1, 12, 64, 10.0, 21, 0.5, 0.5, None, None, None, None)
     assert rc == -1 and b"out of range" in l.bevbert_last_error()
     strides = (ctypes.c_int64 * 8)(*([768] * 8))
-    rc = l.bevbert_attn_fwd(None, None, None, None, None, None, None, strides, 1, 12, 4, 4, 32, 0.125, 1, 0, 0.0, 0, 0, None, None)
+    rc = l.bevbert_attn_fwd(None, None, None, None, None, None, None, strides, 1, 12, 4, 4, 32, 0.125, 1, 0, 0.0, 0, 0, None, 0, None)
     assert rc == -1 and b"head_dim" in l.bevbert_last_error()
 
 

@@ -9,7 +9,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define TK 64   // keys (or queries, in dKV) per LDS tile
-#define LDT 72  // LDS row stride in bf16 elements
+#define LDT 80  // LDS row stride in bf16 elements: 160 B keeps the 16-byte row reads of 16 consecutive rows AND the
+                // transposing 8-byte reads (rows 4 g ..) conflict-free; 144 B was 2-way on both (scripts/lds_bank_sim.py)
 
 #define DKV_TILE_BYTES (2 * 4 * TK * LDT * 2)                 // dK/dV kernel: two buffers of four bf16 tiles
 #define DKV_SMEM_BYTES (DKV_TILE_BYTES + 2 * 2 * TK * 4)     // + lse / delta rows

@@ -31,6 +31,16 @@ int attn_mfma_fwd(const AttnArgs& a, hipStream_t st);
 int attn_mfma_bwd(const AttnArgs& a, hipStream_t st);
 int attn_mfma_bwd1(const AttnArgs& a, hipStream_t st);
 bool attn_mfma_bwd1_supported(const AttnArgs& a);
+int attn_fwd2(const AttnArgs& a, hipStream_t st);
+bool attn_fwd2_supported(const AttnArgs& a);
+int attn_drop_bits(const AttnArgs& a, uint64_t* bits_f, uint64_t* bits_b, hipStream_t st);
+int attn_bwd2(const AttnArgs& a, hipStream_t st);
+bool attn_bwd2_supported(const AttnArgs& a);
+
+// The keep-bit workspace of a call holds the matrix twice: [forward layout | backward layout], see attn_fwd2.hip
+static int64_t bits_words_one(int B, int nh, int Lq, int Lk) {
+  return (int64_t)B * nh * ((Lq + 127) / 128 * 8) * ((Lk + 63) / 64) * 16;
+}
 
 // impl: 0 = auto (bf16 -> MFMA, f32 -> exact), 1 = force exact kernels, 2 = force MFMA (bf16 only),
 //       3 = MFMA with the two-kernel backward even where the single-pass backward applies (tests, A/B measurements)
@@ -61,15 +71,25 @@ static int fill_common(AttnArgs& a, const void* q, const void* k, const void* v,
 BEVBERT_API int bevbert_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                                  const float* key_mask, const float* bias, const int64_t* strides, int B, int nh,
                                  int Lq, int Lk, int head_dim, float scale, int dtype, int impl, float drop_p,
-                                 uint64_t seed, uint64_t offset, uint64_t* drop_bits, hipStream_t stream) {
+                                 uint64_t seed, uint64_t offset, uint64_t* drop_bits, int bits_ready,
+                                 hipStream_t stream) {
   AttnArgs a;
   int rc = fill_common(a, q, k, v, key_mask, bias, strides, B, nh, Lq, Lk, head_dim, scale, drop_p, seed, offset);
   if (rc != BB_OK) return rc;
   a.o = o; a.lse = lse; a.drop_bits = drop_bits;
+  a.drop_bits_b = drop_bits ? drop_bits + bits_words_one(B, nh, Lq, Lk) : nullptr;
   BB_REQUIRE(dtype == BB_F32 || dtype == BB_BF16, "attn_fwd: dtype %d unsupported", dtype);
   const int im = pick_impl(dtype, impl);
   if (im == 2 || im == 3) {
     BB_REQUIRE(dtype == BB_BF16, "attn_fwd: the MFMA path takes bf16 tensors");
+    if (drop_p > 0.f && drop_bits != nullptr && !bits_ready) {
+      rc = attn_drop_bits(a, a.drop_bits, a.drop_bits_b, stream);
+      if (rc != BB_OK) return rc;
+    }
+    // BEVBERT_ATTN_FWD=1: the round-2 forward (hashes the dropout mask inline) for A/B measurements and as the on-GPU
+    // cross-check of the second-generation kernel
+    static const bool gen1 = [] { const char* v = getenv("BEVBERT_ATTN_FWD"); return v && v[0] == '1'; }();
+    if (!gen1 && attn_fwd2_supported(a)) return attn_fwd2(a, stream);
     return attn_mfma_fwd(a, stream);
   }
   return attn_simple_fwd(a, dtype, stream);
@@ -84,6 +104,7 @@ BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, co
   int rc = fill_common(a, q, k, v, key_mask, bias, strides, B, nh, Lq, Lk, head_dim, scale, drop_p, seed, offset);
   if (rc != BB_OK) return rc;
   a.drop_bits = const_cast<uint64_t*>(drop_bits);
+  a.drop_bits_b = drop_bits ? a.drop_bits + bits_words_one(B, nh, Lq, Lk) : nullptr;
   BB_REQUIRE(dtype == BB_F32 || dtype == BB_BF16, "attn_bwd: dtype %d unsupported", dtype);
   BB_REQUIRE(lse != nullptr && delta_ws != nullptr, "attn_bwd: lse and the (B,nh,Lq) delta workspace are required");
   a.o = const_cast<void*>(o); a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = delta_ws;
@@ -94,6 +115,9 @@ BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, co
     // one pass over the scores when all keys of a (batch, head) fit one workgroup (attn_bwd1.hip); BEVBERT_ATTN_BWD=split
     // forces the two-kernel path (A/B measurements)
     static const bool split = [] { const char* v = getenv("BEVBERT_ATTN_BWD"); return v && v[0] == 's'; }();
+    // BEVBERT_ATTN_BWD=1: the round-2 single-pass kernel where the 7+1-wave kernel (attn_bwd2.hip) would run
+    static const bool gen1 = [] { const char* v = getenv("BEVBERT_ATTN_BWD"); return v && v[0] == '1'; }();
+    if (!split && !gen1 && im == 2 && attn_bwd2_supported(a)) return attn_bwd2(a, stream);
     if (!split && im == 2 && attn_mfma_bwd1_supported(a)) return attn_mfma_bwd1(a, stream);
     return attn_mfma_bwd(a, stream);
   }
@@ -110,7 +134,19 @@ __global__ void keep_mask_kernel(uint8_t* out, size_t n, uint32_t key, uint32_t 
 }
 // Size of the keep-bit matrix of an attention call (64-bit words), see attn_common.h.
 BEVBERT_API int64_t bevbert_attn_drop_bits_words(int B, int nh, int Lq, int Lk) {
-  return (int64_t)B * nh * ((Lq + 127) / 128 * 8) * ((Lk + 63) / 64) * 16;
+  return 2 * bits_words_one(B, nh, Lq, Lk);
+}
+
+// Fill the keep-bit workspace of one attention call ahead of its forward (any stream: the mask is a pure function of
+// (seed, offset, step salt, element index)); pass bits_ready = 1 to bevbert_attn_fwd afterwards.
+BEVBERT_API int bevbert_attn_drop_bits(uint64_t* drop_bits, int B, int nh, int Lq, int Lk, float drop_p, uint64_t seed,
+                                       uint64_t offset, hipStream_t stream) {
+  BB_REQUIRE(drop_bits != nullptr && drop_p > 0.f && drop_p < 1.f, "attn_drop_bits: workspace and 0 < p < 1 required");
+  AttnArgs a;
+  const int64_t st[8] = {64, 64, 64, 64, 64, 64, 64, 64};
+  int rc = fill_common(a, nullptr, nullptr, nullptr, nullptr, nullptr, st, B, nh, Lq, Lk, ATTN_D, 1.f, drop_p, seed, offset);
+  if (rc != BB_OK) return rc;
+  return attn_drop_bits(a, drop_bits, drop_bits + bits_words_one(B, nh, Lq, Lk), stream);
 }
 
 BEVBERT_API int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p, uint64_t seed, uint64_t offset,

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbevbert_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "attn_bwd1.hip", "sap_loss.hip", "gemm.hip", "capi.hip"]
+SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "attn_bwd1.hip", "attn_fwd2.hip", "attn_bwd2.hip", "sap_loss.hip", "gemm.hip", "capi.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bevbert_hip.h")
 
 F32, BF16, F16 = 0, 1, 2
@@ -59,7 +59,8 @@ _PROTOS = {
     "bevbert_bev_lift_bin": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _F, _P, _P, _P, _P],
     "bevbert_bev_bin_points": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     "bevbert_bev_splat_mean": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P],
-    "bevbert_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _F, _U64, _U64, _P, _P],
+    "bevbert_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _F, _U64, _U64, _P, _I, _P],
+    "bevbert_attn_drop_bits": [_P, _I, _I, _I, _I, _F, _U64, _U64, _P],
     "bevbert_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _F,
                          _U64, _U64, _P, _P],
     "bevbert_bias_dropout_residual_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _F, _U64,

@@ -1186,13 +1186,14 @@ class _Attention(torch.autograd.Function):
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.shape == (B, Lq, Lk) and bias.is_contiguous()
         bits = None
-        if drop_p > 0 and need_grad and q.dtype == torch.bfloat16 and impl != 1:
-            # keep-bit matrix of the dropout mask: the MFMA forward stores the compare masks it has anyway, the
-            # backward reads one bit per score element instead of hashing again (1 bit / element: 19 MB at 64x12x441x441)
+        if drop_p > 0 and q.dtype == torch.bfloat16 and impl != 1:
+            # keep-bit workspace of the dropout mask (1 bit / element in the forward's and in the backward's lane
+            # layout: 2 x 19 MB at 64x12x441x441), filled by the library ahead of the forward kernel; both directions
+            # read bits through the scalar cache instead of hashing per element
             bits = torch.empty(_drop_bits_words(B, nh, Lq, Lk), dtype=torch.int64, device=q.device)
         call("bevbert_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(key_mask), ptr(bias),
              _strides(q, k, v, o), B, nh, Lq, Lk, HEAD_DIM, scale, dtype_code(q), impl, float(drop_p), RT.seed, off,
-             ptr(bits), stream())
+             ptr(bits), 0, stream())
         ctx.save_for_backward(a, b_, c_, key_mask, bias, o, lse, bits)
         ctx.cfg = (mode, nh, float(drop_p), RT.seed, off, impl, scale)
         return o
@@ -1465,3 +1466,11 @@ def dropout_keep_mask(n, drop_p, seed, offset, device):
     out = torch.empty(n, dtype=torch.uint8, device=device)
     call("bevbert_dropout_keep_mask", ptr(out), n, float(drop_p), int(seed), int(offset), stream())
     return out.bool()
+
+
+def attn_drop_bits(B, nh, Lq, Lk, drop_p, seed, offset, device):
+    """Keep-bit workspace of one attention call ([forward layout | backward layout], int64 words); see
+    include/bevbert_hip.h bevbert_attn_drop_bits."""
+    bits = torch.empty(_drop_bits_words(B, nh, Lq, Lk), dtype=torch.int64, device=device)
+    call("bevbert_attn_drop_bits", ptr(bits), B, nh, Lq, Lk, float(drop_p), int(seed), int(offset), stream())
+    return bits
