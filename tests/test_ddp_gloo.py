@@ -136,3 +136,86 @@ def test_trainer_broadcasts_rank0_state_to_all_replicas():
         assert p.exitcode == 0
     assert all(r[0] == "ok" and r[2] for r in res)
     assert min(r[1] for r in res) > 1e-3                 # the replicas really started apart
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# torch-API bridge of the arena (arena.py) + train.ArenaDataParallel on two gloo ranks: a toy module whose backward
+# writes its weight gradient straight into ``main_grad`` (as every Linear of the product does), trained with the
+# reference's loop body (loss.backward(); clip_grad_norm_; torch optimiser; zero_grad) on rank-specific halves of a
+# batch, must follow the single-process run on the whole batch.
+class _ArenaLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        ctx.w = w
+        return x @ w.detach().t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w = ctx.w
+        w.arena.touch(w)
+        w.main_grad.add_(dy.t() @ x)                 # gradient written behind autograd's back
+        return dy @ w.detach(), None
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.a = torch.nn.Parameter(torch.randn(6, 4, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(3, 6, generator=g))
+        self.unused = torch.nn.Parameter(torch.ones(2))
+
+    def finalize(self, device, dtype=torch.float32):
+        from vln_bevbert_amd.arena import ParamArena
+        self.arena = ParamArena(self, device, dtype)
+        return self.arena
+
+    def forward(self, x):
+        from vln_bevbert_amd.vilmodel import ensure_arena
+        ensure_arena(self)
+        return _ArenaLinearFn.apply(torch.tanh(_ArenaLinearFn.apply(x, self.a)), self.b)
+
+
+def _toy_run(rank, world, port, out):
+    import torch.distributed as dist
+    from vln_bevbert_amd.train import ArenaDataParallel
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                     # replicas start different: the wrap-time broadcast aligns them
+    model = _Toy()
+    if world > 1 and rank > 0:
+        with torch.no_grad():
+            model.a.add_(1.0)
+    model.finalize("cpu")
+    net = ArenaDataParallel(model) if world > 1 else model
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    g = torch.Generator().manual_seed(9)
+    xs, ys = torch.randn(5, 8, 4, generator=g), torch.randn(5, 8, 3, generator=g)
+    for step in range(5):
+        x, y = xs[step], ys[step]
+        if world > 1:                                  # each rank its half of the batch
+            x, y = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+        loss = ((net(x) - y) ** 2).mean()
+        loss.backward()
+        assert model.a.grad is not None and model.unused.grad is None
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        opt.zero_grad()                                # set_to_none=True: the next forward zeroes the arena
+    if rank == 0:
+        torch.save({"a": model.a.detach().clone(), "b": model.b.detach().clone()}, out)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_arena_data_parallel_follows_the_single_process_run_through_a_torch_optimizer(tmp_path):
+    import torch.multiprocessing as mp
+    single, double = str(tmp_path / "single.pt"), str(tmp_path / "double.pt")
+    _toy_run(0, 1, 0, single)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_toy_run, args=(2, port, double), nprocs=2, join=True)
+    a, b = torch.load(single), torch.load(double)
+    for k in ("a", "b"):
+        assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-6), (k, (a[k] - b[k]).abs().max())

@@ -88,6 +88,14 @@ class ParamArena:
         self.chunk_steps = torch.zeros(off // CHUNK, dtype=torch.int32, device=dev)   # per-parameter state["step"]
         self._touched = set()
         self._flags_dirty = False
+        # torch-API bridge (see publish_grads below)
+        self.publish_grads = True
+        self.allreduce_group = None        # set by train.ArenaDataParallel: gradients are averaged over it when published
+        self.defer_allreduce = False       # ArenaDataParallel.no_sync()
+        self._cb_queued = False
+        self._fresh = []                   # parameters written during the running backward pass
+        self._published = []               # parameters whose .grad currently aliases the arena
+        self._param_versions = None
         self.step_count = 0
         self._scalars = torch.zeros(4, dtype=torch.float32, device=dev)       # [grad norm, clip multiplier, lr, -]
         self._partials = torch.zeros(1024, dtype=torch.float32, device=dev)
@@ -125,6 +133,65 @@ class ParamArena:
             a, b = self._seg_of[n]
             self._flags_host[a:b] |= 2
             self._flags_dirty = True
+        if self.publish_grads:
+            self._note_backward_write(param)
+
+    # ---- torch-API bridge: the reference's loops run unchanged ---------------------------------
+    # train_r2r.py:263-313 and map_nav_src/r2r/agent_base.py:174-217 do
+    #     loss.backward(); [scaler.unscale_(opt)]; clip_grad_norm_(model.parameters(), 5.0); optimizer.step(); optimizer.zero_grad()
+    # on ``p.grad`` with a torch optimiser.  Backward kernels here write into ``grads`` (``p.main_grad``) behind autograd's
+    # back, so with ``publish_grads`` (default; PretrainTrainer turns it off and drives the arena itself):
+    #   * the first gradient write of a backward pass queues an autograd-engine callback; at the end of that pass it issues
+    #     the deferred weight-gradient work, joins the side streams (``sync``), averages over ``allreduce_group`` if one is
+    #     set, and points ``p.grad`` of every parameter written so far at its arena view -- parameters that never received
+    #     a gradient keep ``.grad is None`` exactly as under the reference (its AdamW skips them, optim/adamw.py:66);
+    #   * ``optimizer.zero_grad()`` (set_to_none, torch's default) leaves stale sums in the arena: the next forward sees
+    #     ``.grad is None`` on a published parameter and zeroes the arena first (``maybe_lazy_zero``, called from the model's
+    #     forward entry); with set_to_none=False torch zeroes the views in place and nothing is needed;
+    #   * a torch optimiser updates the fp32 masters through ``p``: the bf16 compute copy is refreshed at the next
+    #     forward when any parameter's version counter moved (``maybe_refresh_shadow``).
+    def _note_backward_write(self, param):
+        if not self._cb_queued:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._publish)
+            except RuntimeError:           # not inside a backward pass (a test touching parameters by hand)
+                return
+            self._cb_queued = True
+        self._fresh.append(param)
+
+    def _publish(self):
+        self._cb_queued = False
+        self.sync()
+        if self.allreduce_group is not None and not self.defer_allreduce:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, group=self.allreduce_group)
+            self.grads.div_(dist.get_world_size(self.allreduce_group))
+        for p in self._fresh:
+            if p.grad is None:
+                p.grad = p.main_grad
+                self._published.append(p)
+        self._fresh.clear()
+
+    def maybe_lazy_zero(self):
+        """Zero the gradient arena if the caller dropped the published gradients (zero_grad(set_to_none=True))."""
+        if self._published and self._published[0].grad is None:
+            for p in self._published:
+                p.grad = None
+            self._published.clear()
+            self.zero_grad()
+
+    def maybe_refresh_shadow(self):
+        """Rebuild the bf16 compute copy if a torch-API optimiser (or load_state_dict, or a DDP-style broadcast) wrote
+        the fp32 masters through the parameters since the last look."""
+        if self.shadow is None or not self.publish_grads:
+            return
+        v = 0
+        for _, p in self.named:
+            v += p._version
+        if v != self._param_versions:
+            if self._param_versions is not None:
+                self.sync_shadow()
+            self._param_versions = v
 
     def sync_shadow(self):
         if self.shadow is not None:

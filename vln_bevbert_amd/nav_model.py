@@ -7,7 +7,7 @@ from . import ops
 from .config import BevBertConfig
 from .pretrain_cmt import ClsPrediction, fuse_sap_logits, sap_fusion_indices
 from .vilmodel import (BertEmbeddings, GlobalMapEncoder, ImageEmbeddings, LanguageEncoder, LocalBEVEncoder,
-                       _all_ones_to_none, finalize)
+                       _all_ones_to_none, ensure_arena, finalize)
 
 
 class GlocalTextPathNavCMT(nn.Module):
@@ -97,6 +97,7 @@ class GlocalTextPathNavCMT(nn.Module):
                 "fused_logits": fused_logits, "obj_logits": obj_logits}
 
     def forward(self, mode, batch, **kwargs):
+        ensure_arena(self)
         if mode == "language":
             return self.forward_text(batch["txt_ids"], batch["txt_masks"])
         if mode == "panorama":

@@ -15,7 +15,7 @@ from torch import nn
 
 from . import ops
 from .config import BevBertConfig
-from .vilmodel import BertOnlyMLMHead, GlocalTextPathCMT, finalize, gen_seq_masks
+from .vilmodel import BertOnlyMLMHead, GlocalTextPathCMT, ensure_arena, finalize, gen_seq_masks
 
 BEV_DIM = 21      # pretrain_cmt.py:16-17 (the config's bev_dim / bev_res override these defaults)
 BEV_RES = 0.5
@@ -232,6 +232,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         """``compute_loss``: True / False as in the reference; "mean" (internal, see ``loss_mean``) -> scalar."""
         if not any(task.startswith(t) for t in ("mlm", "mrc", "sap", "og", "sem", "masksem")):
             raise ValueError("invalid task")
+        ensure_arena(self)
         batch = dict(batch)     # the reference works on a defaultdict COPY (pretrain_cmt.py:170): the caller's dict is untouched
         self.lift_splat(batch)
         self.drop_feats(batch)

@@ -139,6 +139,7 @@ class PretrainTrainer:
                  betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0, seed=0, rank=0, world_size=1, overlap=True,
                  force_collectives=False):
         self.model, self.arena = model, arena
+        arena.publish_grads = False      # this class drives the arena itself (flat clip + AdamW, in-place all-reduce, graphs)
         self.lr, self.warmup, self.total = learning_rate, warmup_steps, num_train_steps
         self.betas, self.wd, self.grad_norm = betas, weight_decay, grad_norm
         self.seed, self.rank, self.world = seed, rank, world_size
@@ -333,3 +334,62 @@ class PretrainTrainer:
         sb.graph = gs
         graph.replay()                              # the capture recorded the step; this replay executes it
         return loss.clone()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Drop-in for the reference's own loops (pretrain_src/utils/misc.py:64-77 wrap_model, train_r2r.py:247-313,
+# map_nav_src/r2r/agent_base.py:122-123,174-217): a script that replaces
+#     from utils.misc import wrap_model        ->   from vln_bevbert_amd.train import wrap_model
+# keeps everything else -- build_optimizer / torch.optim over model.parameters(), loss.backward(),
+# clip_grad_norm_(model.parameters(), ...), GradScaler, optimizer.step(), optimizer.zero_grad(), model.state_dict()
+# (keys 'module.*' when wrapped, which the reference's saver strips: pretrain_src/utils/save.py:33-35).
+class ArenaDataParallel(torch.nn.Module):
+    """What DistributedDataParallel is to the reference (utils/misc.py:70), for a model whose gradients live in a
+    ParamArena: wrap-time broadcast of rank 0's parameters and buffers, and one in-place all-reduce of the flat
+    gradient arena (averaged) when a backward pass ends -- torch's DDP cannot do it, its reducer copies ``p.grad`` out
+    of AccumulateGrad hooks that never fire here.  ``find_unused_parameters=True`` semantics come for free (unused
+    parameters contribute zeros and keep ``.grad is None``)."""
+
+    def __init__(self, module, process_group=None, compute_dtype=None):
+        super().__init__()
+        self.module = module
+        arena = getattr(module, "arena", None)
+        if arena is None:
+            dev = next(module.parameters()).device
+            arena = module.finalize(dev, compute_dtype or torch.float32)
+        self.arena = arena
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            arena.allreduce_group = process_group if process_group is not None else dist.group.WORLD
+            dist.broadcast(arena.params, src=0, group=process_group)
+            for b in module.buffers():
+                dist.broadcast(b, src=0, group=process_group)
+            arena.sync_shadow()
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def no_sync(self):
+        """Gradient accumulation without communication (DDP.no_sync): the arena keeps summing locally."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old = self.arena.defer_allreduce
+            self.arena.defer_allreduce = True
+            try:
+                yield
+            finally:
+                self.arena.defer_allreduce = old
+        return ctx()
+
+
+def wrap_model(model, device, local_rank, compute_dtype=None):
+    """pretrain_src/utils/misc.py:64-77 with the same signature: move to the device, place the parameters in the arena
+    (fp32 unless ``compute_dtype`` says bf16; left to the first forward -- which looks at autocast -- when None and
+    single-process), wrap for data parallelism when ``local_rank != -1``."""
+    model.to(device)
+    if local_rank != -1:
+        return ArenaDataParallel(model, compute_dtype=compute_dtype)
+    if compute_dtype is not None and getattr(model, "arena", None) is None:
+        model.finalize(device, compute_dtype)
+    return model

@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import ops
+from . import lib, ops
 from .arena import ParamArena
 from .config import BevBertConfig
 
@@ -789,6 +789,25 @@ def arena_groups(module):
         if isinstance(m, (BertSelfAttention, BertOutAttention)):
             groups.extend(m.arena_groups(name + "." if name else ""))
     return groups
+
+
+def ensure_arena(module):
+    """Forward-entry hook of the model classes: the reference's scripts build the model, ``.to(device)`` it (or let
+    ``wrap_model`` do so) and call it -- they know nothing of ``finalize``.  First call: place the parameters in a flat
+    arena on the device they were moved to (bf16 compute copy when the call runs under ``torch.autocast``, the
+    reference's ``--fp16`` switch: train_r2r.py:256-258, agent_base.py:195; fp32 otherwise).  Every call: honour a
+    ``zero_grad(set_to_none=True)`` and a torch optimiser's parameter update (arena.py, torch-API bridge)."""
+    arena = getattr(module, "arena", None)
+    if arena is None:
+        dev = next(module.parameters()).device
+        if dev.type != "cuda":
+            raise lib.BevBertHipError("the model has not been moved to the GPU: call .to('cuda') (or finalize(device, dtype)) "
+                                      "first -- there is no CPU path")
+        arena = finalize(module, dev, torch.bfloat16 if torch.is_autocast_enabled() else torch.float32)
+    elif arena.publish_grads:
+        arena.maybe_lazy_zero()
+        arena.maybe_refresh_shadow()
+    return arena
 
 
 def finalize(module, device, compute_dtype=torch.float32):
