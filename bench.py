@@ -70,6 +70,20 @@ def parse():
     ap.add_argument("--no-kernel-pass", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--save-gemm-tuning", default="", help="write the hipBLASLt choice table of this run to a file")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the 'side_configs' block (RxR per-rank shape of BASELINE.json configs[3], the CE fork's model, the "
+                         "fine-tune rollout of configs[4]; each runs as a short child process after the main measurement)")
+    ap.add_argument("--no-fwd", action="store_true", help="skip the forward-only timing")
+    ap.add_argument("--no-stream", action="store_true",
+                    help="skip the 'sustained' block (live loader: host-side index building + refills of double-buffered "
+                         "static batches on a copy stream, every step)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="sustained block on ragged batches (T in [1,7], text length in [L/2, L], 36..38 views): many shape "
+                         "buckets, reports buckets / captures / eager steps")
+    ap.add_argument("--ship-grid", action="store_true",
+                    help="sustained block ships the grid features of every batch over PCIe (462 MB fp32 at batch 64) instead "
+                         "of reading rows of the device-resident feature store")
+    ap.add_argument("--stream-steps", type=int, default=33)
     ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
                     help="how the step is issued: eager (~700 launches from Python), graph (hipGraph replay), or auto = time "
                          "both in the untimed preparation and keep the faster one (BEVBERT_GRAPHS=0/1 in the environment "
@@ -268,9 +282,13 @@ def main():
         "final_loss": round(float(losses[-1].item()), 4),
     }
 
+    if world == 1 and not a.no_stream:
+        log("sustained throughput with a live loader")
+        out["sustained"] = sustained(cfg, a, trainer, cycle, tasks, dev, out["ms_per_step"])
+
     # ---- forward ms/batch (the second half of BASELINE.json's metric; reference: train_r2r.py:256-260): the training
     # forward (dropout on, tape recorded) issued eagerly, and the same batch's inference forward replayed from a graph
-    if rank == 0:
+    if rank == 0 and not a.no_fwd:
         log("forward timing")
         fwd = {}
         for t in tasks:
@@ -310,6 +328,8 @@ def main():
                 torch.cuda.synchronize()
             model.train()
         out["fwd_ms_per_batch"] = fwd
+    if rank == 0 and a.no_fwd:
+        pass
     if world > 1 or force:
         # what the exchange moves, and how long it takes alone (all ranks take part; rank 0 reports)
         torch.cuda.synchronize()
@@ -434,6 +454,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline (oracle)")
         out["cpu_baseline"] = cpu_baseline(cfg, a)
+    if rank == 0 and world == 1 and not a.no_side and a.config == "r2r":
+        out["side_configs"] = side_configs(a)
     log("done")
 
     if rank == 0 and a.save_gemm_tuning:
@@ -445,8 +467,139 @@ def main():
         print(json.dumps(out), flush=True)     # after the teardown: the JSON is the last line on stdout
 
 
+def side_configs(a):
+    """The other single-GPU configurations of BASELINE.json, each in a short child process on the same GPU (the parent
+    is idle by now): configs[3]'s per-rank shape (RxR: xlm-roberta vocabulary of 250 002 tokens, 160-token
+    instructions, batch 32), the continuous-environment fork's model, and configs[4] (fine-tune rollout, batch 32,
+    15 navigation steps: scripts/ft_r2r.bash:37 --max_action_len 15).  Side measurements, not the bench metric; skipped
+    one by one once the whole run has used its time budget."""
+    import subprocess
+    budget_s = float(os.environ.get("BEVBERT_BENCH_SIDE_BUDGET_S", "240"))
+    common = ["--steps", "11", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-pass", "--no-stream", "--no-side", "--no-fwd"]
+    jobs = [("rxr_b32_len160", [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "rxr", "--txt-len", "160",
+                                "--batch", "32"] + common),
+            ("ce_b64", [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "ce"] + common),
+            ("finetune_rollout_b32_15steps_infer", [sys.executable, os.path.join(ROOT, "scripts", "bench_nav.py"), "--batch", "32",
+                                                    "--steps", "15", "--iters", "4", "--warmup", "2", "--mode", "infer"])]
+    res = {}
+    for name, cmd in jobs:
+        if time.perf_counter() - T_START > budget_s:
+            res[name] = {"skipped": f"time budget of {budget_s:.0f} s for the whole bench run used up"}
+            continue
+        log(f"side config {name}")
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+            d = json.loads(line[-1])
+            keep = ("value", "unit", "ms_per_step", "step_launch", "config", "final_loss", "ms_per_nav_step", "workload",
+                    "episodes_per_s", "host_map_bookkeeping_ms_per_nav_step", "ms_per_episode_batch")
+            res[name] = {k: d[k] for k in keep if k in d}
+        except Exception as e:      # noqa: BLE001 -- a side figure must not cost the bench line
+            res[name] = {"error": repr(e)[:300]}
+    return res
+
+
+def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
+    """Throughput with the loader's work INSIDE the measured loop (the headline figure replays resident batches).
+
+    A producer thread (loader.StreamingLoader) takes the next host batch of the step's task from a pool of pinned
+    synthetic batches (the pool stands in for dataset reads; random-number generation is not loader work), builds
+    everything the reference computes on the host inside its forward (StaticBatch.plan: masked-token positions, SAP
+    fusion table, global-map aggregation CSR), picks the shape bucket (loader.BucketManager), refills one of the
+    bucket's two buffer sets on a copy stream and hands it to the training thread, which waits for the copy on the
+    compute stream and runs the step (captured graph of that buffer set once it exists, eager before).  Grid features
+    come as row numbers of a device-resident feature_store.GridFeatureStore (--ship-grid: as 462 MB of fp32 per batch
+    over PCIe, the reference's way)."""
+    import numpy as np
+    from vln_bevbert_amd import ops, synthetic
+    from vln_bevbert_amd.feature_store import GridFeatureStore
+    from vln_bevbert_amd.loader import BucketManager, StreamingLoader
+    n_pool = 6 if a.ragged else 4
+    store = None
+    n_rows = 1024
+    if not a.ship_grid:
+        g = torch.Generator(device=dev).manual_seed(5)
+        P = 12 * cfg.grid_hw * cfg.grid_hw
+        rgbs = torch.randn(n_rows, P, 768, device=dev, dtype=torch.float16, generator=g)
+        depths = torch.rand(n_rows, 12, cfg.grid_hw, cfg.grid_hw, device=dev, generator=g) * 0.6
+        depths = depths * (torch.rand(depths.shape, device=dev, generator=g) > 0.05)
+        sems = torch.randint(0, max(1, cfg.sem_classes), (n_rows, P), device=dev, generator=g).to(torch.uint8)
+        store = GridFeatureStore([f"s_{i}" for i in range(n_rows)], rgbs, depths, sems, dev)
+    rng = np.random.default_rng(11)
+    pool = {}
+    for t in tasks:
+        pool[t] = []
+        for j in range(n_pool):
+            b = synthetic.make_batch(cfg, t, a.batch, seed=7000 + 31 * j + len(pool), txt_len=a.txt_len, ragged=a.ragged,
+                                     sems_as="ids")
+            keys = None
+            if store is not None:
+                for k in ("rgbs", "depths", "sems"):
+                    b.pop(k, None)
+                keys = [f"s_{int(i)}" for i in rng.integers(0, n_rows, a.batch)]
+            b = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()}
+            pool[t].append((b, keys))
+    mgr = BucketManager(cfg, dev, depth=2, max_buckets=64, grid_store=store)
+    # warm-up: every (bucket, buffer set) has to be seen GRAPH_WARMUP + 1 times before its step is a replay
+    seen = {t: 0 for t in tasks}
+    per_task_uses = {t: max(1, cycle.count(t)) for t in tasks}
+    n_buckets_guess = {t: (n_pool if a.ragged else 1) for t in tasks}
+    n_warm = max(len(cycle) * -(-(n_buckets_guess[t] * 2 * (trainer.GRAPH_WARMUP + 1)) // per_task_uses[t]) for t in tasks)
+    n_warm = min(n_warm, 40 * len(cycle))
+    n_total = n_warm + a.stream_steps
+
+    def source():
+        for i in range(n_total):
+            t = cycle[i % len(cycle)]
+            b, keys = pool[t][seen[t] % n_pool]
+            seen[t] += 1
+            yield t, b, keys
+
+    loader = StreamingLoader(source(), mgr, prefetch=1)
+    plans0 = ops.gemm_plan_count() if hasattr(ops, "gemm_plan_count") else None
+    it = iter(loader)
+    replayed = eager = 0
+    t0 = None
+    stats0 = None
+    for i in range(n_total):
+        if i == n_warm:
+            torch.cuda.synchronize()
+            stats0 = dict(mgr.stats)
+            replayed = eager = 0
+            t0 = time.perf_counter()
+        task, sb = next(it)
+        was_graph = sb.graph is not None
+        trainer.step(task, sb)
+        loader.release(sb)
+        replayed += was_graph
+        eager += not was_graph
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loader.close()
+    st = {k: mgr.stats[k] - stats0.get(k, 0) for k in mgr.stats}
+    ms = 1000.0 * dt / a.stream_steps
+    res = {"samples_per_s": round(a.stream_steps * a.batch / dt, 2), "ms_per_step": round(ms, 3),
+           "vs_resident": round(resident_ms / ms, 4), "steps": a.stream_steps, "warmup_steps": n_warm,
+           "batches": "ragged (T in [1,7], text in [L/2, L], 36..38 views)" if a.ragged else "fixed shapes (T = 5, L = %d)" % a.txt_len,
+           "grid_features": "462 MB fp32 per batch over PCIe" if a.ship_grid else f"rows of a {store.nbytes() / 2**30:.1f} GiB device-resident store",
+           "pool": f"{n_pool} pinned host batches per task, cycled; host-side index building and refill every step",
+           "buckets": len(mgr.buckets), "buckets_created_in_timed_region": st.get("buckets_created", 0),
+           "captured_graphs": mgr.captured_graphs(), "steps_replayed": replayed, "steps_eager": eager,
+           "loader_ms_per_batch": round(1000.0 * st.get("loader_s", 0.0) / max(1, a.stream_steps), 3),
+           "h2d_MB_per_step": round(st.get("bytes_h2d", 0) / max(1, a.stream_steps) / 1e6, 2)}
+    if plans0 is not None:
+        res["gemm_plans_added"] = ops.gemm_plan_count() - plans0
+    del store
+    return res
+
+
 def cpu_baseline(cfg, a):
-    """The CPU oracle doing the same training step (fwd + bwd + AdamW, fp32, dropout off) on a bounded sample."""
+    """The CPU oracle (oracle/bevbert_ref.py, a restatement pinned to the reference by golden vectors) on the host cores.
+
+    ``forward``: BASELINE.md section 3's protocol -- forward only, SAP and MLM, batch 2 (BASELINE.json configs[0]) and
+    16, one thread and all usable cores, fp32, eval; 2 warm-ups + the median of up to 10 repetitions, cut short by a time
+    budget per cell (the slow cells say how many repetitions they got).  ``value`` (the contract field) stays the
+    training figure: fwd + bwd + AdamW at batch 8 on all cores, the same work the GPU line measures."""
     from oracle import bevbert_ref as R
     from vln_bevbert_amd import synthetic, weights
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
@@ -458,7 +611,7 @@ def cpu_baseline(cfg, a):
     m = [torch.zeros_like(p) for p in params]
     v = [torch.zeros_like(p) for p in params]
     B = 8
-    t_total, n_samples, budget_s = 0.0, 0, 30.0
+    t_total, n_samples, budget_s = 0.0, 0, 20.0
     order = ("sap", "mlm", "sap", "mlm", "masksem", "mlm", "sap", "mlm", "sap")      # first one is the untimed warm-up
     order = tuple(t if t in cfg.pretrain_tasks else "mlm" for t in order)
     for it, task in enumerate(order):
@@ -477,10 +630,49 @@ def cpu_baseline(cfg, a):
         if it > 0:                         # first iteration pages everything in
             t_total += dt
             n_samples += B
-    return {"value": round(n_samples / t_total, 3), "unit": "samples/s", "cores": n, "kind": "port",
-            "sample": f"{n_samples // B} steps ({', '.join(order[1:1 + n_samples // B])}) of batch {B}, same shapes, "
-                      f"fp32, dropout off, fwd+bwd+AdamW, {t_total:.1f} s of torch CPU work with {n} threads after "
-                      "1 untimed warm-up step"}
+    out = {"value": round(n_samples / t_total, 3), "unit": "samples/s", "cores": n, "kind": "port",
+           "sample": f"{n_samples // B} steps ({', '.join(order[1:1 + n_samples // B])}) of batch {B}, same shapes, "
+                     f"fp32, dropout off, fwd+bwd+AdamW, {t_total:.1f} s of torch CPU work with {n} threads after "
+                     "1 untimed warm-up step"}
+    # ---- forward only, BASELINE.md section 3
+    gflop = {"sap": 50.81, "mlm": 32.25}          # per sample, BASELINE.md section 2 (FlopCounterMode on the reference)
+    sdf = {k: t.detach() for k, t in sd.items()}
+    cells, cell_budget = [], 5.0
+    for task in ("sap", "mlm"):
+        if task not in cfg.pretrain_tasks:
+            continue
+        for bsz in (2, 16):
+            batch = synthetic.make_batch(cfg, task, bsz, seed=4100 + bsz, txt_len=a.txt_len)
+            for threads in sorted({1, n}):
+                torch.set_num_threads(threads)
+                times, warm, spent = [], 0, 0.0
+                with torch.no_grad():
+                    while len(times) < 10 and (spent < cell_budget or not times):
+                        t0 = time.perf_counter()
+                        R.pretrain_forward(sdf, cfg, batch, task)
+                        dt = time.perf_counter() - t0
+                        spent += dt
+                        if warm < 2 and spent + 2 * dt < cell_budget:      # warm-ups only while the cell can afford them
+                            warm += 1
+                        else:
+                            times.append(dt)
+                times.sort()
+                med = times[len(times) // 2]
+                cells.append({"task": task, "batch": bsz, "threads": threads, "warmups": warm, "reps": len(times),
+                              "median_s": round(med, 4), "min_s": round(times[0], 4),
+                              "samples_per_s": round(bsz / med, 3), "gflops": round(gflop[task] * bsz / med, 1)})
+                log(f"  cpu forward {task} B={bsz} threads={threads}: median {med:.3f} s over {len(times)} reps")
+    torch.set_num_threads(n)
+    try:
+        with open("/proc/cpuinfo") as f:
+            model_name = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "?")
+    except Exception:       # noqa: BLE001
+        model_name = "?"
+    out["forward"] = {"protocol": "BASELINE.md section 3: forward only, fp32, eval, 2 warm-ups + median of up to 10 "
+                                  f"repetitions, {cell_budget:.0f} s budget per cell", "host_cpu": model_name,
+                      "usable_cores": n, "cells": cells}
+    out["train"] = {"value": out["value"], "unit": "samples/s", "cores": n, "what": "fwd + bwd + AdamW, batch 8"}
+    return out
 
 
 if __name__ == "__main__":

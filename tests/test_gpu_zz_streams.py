@@ -303,3 +303,67 @@ def test_static_batch_refill_keeps_the_captured_graph(env):
         sb.load(b2)
         losses[graphs] = float(tr.step("sap", sb))
     assert abs(losses[True] - losses[False]) <= 1e-5 * max(1.0, abs(losses[False])), losses
+
+
+def test_static_batch_with_object_tokens_runs_eagerly_and_survives_a_refill(env):
+    """REVERIE-style batches (traj_obj_img_fts): the forward uploads host-derived object-token indices, so such a
+    StaticBatch is never captured (a graph would replay the indices of the batch it was captured on); a refill with a
+    batch of different per-sample step / object counts in the same bucket gives that batch's loss."""
+    from vln_bevbert_amd.static_step import StaticBatch
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(image_feat_size=768, obj_feat_size=768, obj_prob_size=50, num_l_layers=1, num_x_layers=1,
+                             vocab_size=400, pretrain_tasks=("mlm", "mrc", "sap", "og"))
+    b1 = synthetic.make_batch(cfg, "sap", 3, seed=71, ragged=True)
+    assert b1.get("traj_obj_img_fts") is not None
+    model, arena = _fresh(cfg, torch.float32)
+    model.set_dropout(0.0)
+    tr = PretrainTrainer(model, arena, learning_rate=0.0, warmup_steps=1, num_train_steps=10)
+    sb = StaticBatch(cfg, "sap", b1, DEV)
+    assert not sb.capturable
+    for _ in range(tr.GRAPH_WARMUP + 2):
+        tr.step("sap", sb)
+    assert sb.graph is None and tr.graph_error is None
+    other = None
+    for seed in range(72, 100):                         # another batch that falls into the same bucket
+        b2 = synthetic.make_batch(cfg, "sap", 3, seed=seed, ragged=True)
+        if StaticBatch(cfg, "sap", b2, "cpu").signature == sb.signature and \
+                not torch.equal(b2["traj_vp_obj_lens"], b1["traj_vp_obj_lens"]):
+            other = b2
+            break
+    if other is None:
+        pytest.skip("no second synthetic batch in the same shape bucket with different object counts")
+    sb.load(other)
+    got = float(tr.step("sap", sb))
+    want = float(model(synthetic.batch_to(other, DEV), "sap").mean())
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
+
+
+def test_streaming_loader_refills_double_buffered_batches_and_trains_like_direct_steps(env):
+    """loader.StreamingLoader + BucketManager (producer thread, copy stream, two buffer sets per shape bucket, graphs
+    captured per buffer set) give the losses of stepping on freshly built StaticBatches of the same host batches."""
+    from vln_bevbert_amd.loader import BucketManager, StreamingLoader
+    from vln_bevbert_amd.static_step import StaticBatch
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    order = ["sap", "mlm"] * 8
+    host = [synthetic.make_batch(cfg, t, 3, seed=300 + i % 3, sems_as="ids") for i, t in enumerate(order)]
+    losses = {}
+    for mode in ("direct", "stream"):
+        model, arena = _fresh(cfg, torch.float32)
+        model.set_dropout(0.0)
+        tr = PretrainTrainer(model, arena, learning_rate=1e-4, warmup_steps=1, num_train_steps=100)
+        out = []
+        if mode == "direct":
+            tr.use_graphs = False
+            for t, b in zip(order, host):
+                out.append(float(tr.step(t, StaticBatch(cfg, t, b, DEV))))
+        else:
+            mgr = BucketManager(cfg, DEV, depth=2, max_buckets=8)
+            loader = StreamingLoader(((t, b) for t, b in zip(order, host)), mgr, prefetch=1)
+            for t, sb in loader:
+                out.append(float(tr.step(t, sb)))
+                loader.release(sb)
+            assert mgr.stats["refills"] > 0 and mgr.captured_graphs() > 0
+            assert len(mgr.buckets) <= 6
+        losses[mode] = np.asarray(out)
+    assert np.allclose(losses["direct"], losses["stream"], rtol=1e-5, atol=1e-6), losses

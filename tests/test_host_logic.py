@@ -500,3 +500,25 @@ def test_graph_map_hop_counts_equal_the_recursive_path_lengths():
             for i, x in enumerate(names):
                 for j, y in enumerate(names):
                     assert L[b, i, j] == len(gm.eps[b].path(x, y)), (t, b, x, y)
+
+
+def test_bucket_manager_keeps_shape_buckets_lru_and_round_robins_buffer_sets():
+    """loader.BucketManager on the CPU (no streams): one bucket per shape signature, ``depth`` buffer sets per bucket
+    allocated on first use and then refilled in turn, least-recently-used bucket evicted beyond ``max_buckets``."""
+    from vln_bevbert_amd.loader import BucketManager
+    from vln_bevbert_amd.static_step import StaticBatch
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    mgr = BucketManager(cfg, "cpu", depth=2, max_buckets=2)
+    b = [synthetic.make_batch(cfg, "sap", 2, seed=40 + i, sems_as="ids") for i in range(3)]
+    s0 = mgr.acquire("sap", b[0])
+    s1 = mgr.acquire("sap", b[0])
+    s2 = mgr.acquire("sap", b[0])
+    assert s0 is not s1 and s2 is s0 and mgr.stats["buffer_sets_allocated"] == 2 and mgr.stats["refills"] == 1
+    assert torch.equal(s2.tensors["txt_ids"], b[0]["txt_ids"])
+    sigs = {StaticBatch.plan(cfg, "sap", x)["signature"] for x in b}
+    ragged = [synthetic.make_batch(cfg, "sap", 2, seed=90 + i, ragged=True, sems_as="ids") for i in range(6)]
+    for x in ragged:
+        mgr.acquire("sap", x)
+    assert len(mgr.buckets) <= 2
+    assert mgr.stats["buckets_created"] - mgr.stats["buckets_evicted"] == len(mgr.buckets)
+    assert len(sigs) >= 1

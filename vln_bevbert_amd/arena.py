@@ -236,6 +236,7 @@ class ParamArena:
         """Learning rate of the next optimiser step, kept in device memory (one 4-byte fill on the stream): the AdamW
         kernel reads it there, so a step captured in a hipGraph follows the schedule without being re-captured."""
         self._scalars[2:3].fill_(float(lr))
+        self._lr_set = True
 
     def upload_flags(self):
         """Host -> device copy of the per-chunk flags when a parameter was touched for the first time (never inside a
@@ -253,6 +254,9 @@ class ParamArena:
             self.exp_avg_sq = torch.zeros_like(self.params)
         if lr is not None:
             self.set_lr(lr)
+        elif not getattr(self, "_lr_set", False):
+            raise RuntimeError("clip_and_step(lr=None) reads the device-resident learning rate: call set_lr() first "
+                               "(the slot starts at 0, which would silently turn AdamW and its weight decay into a no-op)")
         if not torch.cuda.is_current_stream_capturing():
             self.upload_flags()
         self.step_count += 1

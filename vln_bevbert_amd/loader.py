@@ -1,0 +1,157 @@
+"""Feeding the captured step: shape buckets, double-buffered static batches, a copy stream.
+
+The reference overlaps the host->device copy of batch i+1 with the step on batch i through ``PrefetchLoader``
+(pretrain_src/data/loader.py:78-120: ``move_to_cuda(non_blocking=True)`` one batch ahead) and draws the task of every
+step in ``MetaLoader`` (loader.py:18-62).  Everything it then does on the HOST inside the forward -- positions of the
+masked tokens, the SAP fusion table, the global-map aggregation lists (vilmodel.py:632-666, pretrain_cmt.py:339-356) --
+is loader work here (``StaticBatch._host_side``), done by the producer thread of ``StreamingLoader`` next to the copies:
+
+    source iterator (task, host batch)            main thread
+          |  producer thread                           |
+          v                                            v
+    BucketManager.acquire: shape signature -> buffer set of that bucket (round robin over ``depth`` sets; waits for the
+        step that last read the set), ``StaticBatch.load`` on the COPY stream, ``ready`` event
+          |------------------ queue (depth - 1) ------->|  current stream waits ``ready``; trainer.step(task, sb)
+          |<----------------- release(sb): ``done`` event on the compute stream
+
+A bucket is what a hipGraph is captured on: the signature is (task, B, text shape, panorama shape, map width, padded row
+counts); buffer sets of a bucket are separate ``StaticBatch`` objects, each with its own captured step.  Buckets are
+kept LRU up to ``max_buckets``; what the manager did (buckets created / evicted, refills, bytes copied) is counted so
+that ``bench.py --stream`` can report it.
+"""
+import collections
+import queue
+import threading
+import time
+
+import torch
+
+from .static_step import StaticBatch
+
+
+class BucketManager:
+    def __init__(self, cfg, device, depth=2, max_buckets=16, grid_store=None):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.cfg, self.device, self.depth, self.max_buckets = cfg, device, depth, max_buckets
+        self.grid_store = grid_store
+        self.buckets = collections.OrderedDict()        # signature -> {"sets": [StaticBatch], "next": int}
+        self.copy_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self.stats = collections.Counter()
+
+    def _on_copy_stream(self):
+        return torch.cuda.stream(self.copy_stream) if self.copy_stream is not None else _NullCtx()
+
+    def acquire(self, task, batch, grid_keys=None):
+        """Device-resident StaticBatch holding ``batch`` (host tensors, collate schema).  Blocks while the buffer set it
+        is about to overwrite is still being read by an earlier step."""
+        t0 = time.perf_counter()
+        host = StaticBatch.plan(self.cfg, task, batch)
+        sig = host["signature"]
+        b = self.buckets.get(sig)
+        if b is None:
+            b = {"sets": [], "next": 0}
+            self.buckets[sig] = b
+            self.stats["buckets_created"] += 1
+            while len(self.buckets) > self.max_buckets:
+                old_sig, old = self.buckets.popitem(last=False)
+                for sb in old["sets"]:
+                    if getattr(sb, "done", None) is not None:
+                        sb.done.synchronize()
+                self.stats["buckets_evicted"] += 1
+        self.buckets.move_to_end(sig)
+        if len(b["sets"]) < self.depth:                  # first uses of a bucket: allocate another buffer set
+            with self._on_copy_stream():
+                sb = StaticBatch(self.cfg, task, batch, self.device, grid_store=self.grid_store, grid_keys=grid_keys)
+                sb.ready = self._record()
+            sb.done = None
+            b["sets"].append(sb)
+            self.stats["buffer_sets_allocated"] += 1
+        else:
+            sb = b["sets"][b["next"] % self.depth]
+            b["next"] += 1
+            if sb.done is not None:
+                sb.done.synchronize()                    # the step that last read these buffers has finished
+            with self._on_copy_stream():
+                sb.load(batch, grid_keys=grid_keys, host=host)
+                sb.ready = self._record()
+            self.stats["refills"] += 1
+        self.stats["bytes_h2d"] += sum(v.numel() * v.element_size() for k, v in batch.items()
+                                       if torch.is_tensor(v) and not (self.grid_store is not None and k in ("rgbs", "depths", "sems")))
+        self.stats["loader_s"] += time.perf_counter() - t0
+        return sb
+
+    def _record(self):
+        if self.copy_stream is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.copy_stream)
+        return ev
+
+    def release(self, sb):
+        """Call right after the step on ``sb`` has been enqueued: its buffers may be refilled once that step is done."""
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            sb.done = ev
+
+    def captured_graphs(self):
+        return sum(sb.graph is not None for b in self.buckets.values() for sb in b["sets"])
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class StreamingLoader:
+    """Iterate ``(task, StaticBatch)``: a producer thread stays ``prefetch`` batches ahead of the consumer."""
+
+    def __init__(self, source, manager, prefetch=1):
+        self.source, self.manager = source, manager
+        self.q = queue.Queue(maxsize=max(1, prefetch))
+        self._stop = False
+        self.error = None
+        self.thread = threading.Thread(target=self._produce, daemon=True)
+
+    def _produce(self):
+        try:
+            if self.manager.device.type == "cuda":
+                torch.cuda.set_device(self.manager.device)
+            for item in self.source:
+                if self._stop:
+                    break
+                task, batch = item[0], item[1]
+                keys = item[2] if len(item) > 2 else None
+                self.q.put((task, self.manager.acquire(task, batch, grid_keys=keys)))
+        except Exception as e:          # noqa: BLE001 -- surfaced in the consumer thread
+            self.error = e
+        self.q.put(None)
+
+    def __iter__(self):
+        self.thread.start()
+        while True:
+            item = self.q.get()
+            if item is None:
+                if self.error is not None:
+                    raise self.error
+                return
+            task, sb = item
+            if sb.ready is not None:
+                torch.cuda.current_stream(self.manager.device).wait_event(sb.ready)
+            yield task, sb
+
+    def release(self, sb):
+        self.manager.release(sb)
+
+    def close(self):
+        self._stop = True
+        while self.thread.is_alive():
+            try:
+                self.q.get(timeout=0.1)
+            except queue.Empty:
+                pass

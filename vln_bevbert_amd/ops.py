@@ -1474,3 +1474,8 @@ def attn_drop_bits(B, nh, Lq, Lk, drop_p, seed, offset, device):
     bits = torch.empty(_drop_bits_words(B, nh, Lq, Lk), dtype=torch.int64, device=device)
     call("bevbert_attn_drop_bits", ptr(bits), B, nh, Lq, Lk, float(drop_p), int(seed), int(offset), stream())
     return bits
+
+
+def gemm_plan_count():
+    """Number of hipBLASLt plans the library holds (grows when a new GEMM problem shows up: a new shape bucket)."""
+    return int(lib.load().bevbert_gemm_plan_count())

@@ -27,8 +27,9 @@ from . import ops, synthetic
 from .pretrain_cmt import sap_fusion_indices
 from .vilmodel import gmap_csr_arrays
 
-MLM_ROW_PAD = 64        # masked-token rows are padded to a multiple of this
-SEM_ROW_PAD = 128       # supervised BEV cells (MaskSEM) likewise
+MLM_ROW_PAD = 256       # masked-token rows are padded to a multiple of this (15 % of B x L tokens +- a few dozen: a coarse
+                        # step keeps consecutive batches in ONE shape bucket, i.e. on one captured graph)
+SEM_ROW_PAD = 512       # supervised BEV cells (MaskSEM) likewise
 GMAP_PAD = 4            # global-map width G (batch max of the node counts) is rounded up to a multiple of this
 
 
@@ -47,6 +48,10 @@ class StaticBatch:
         self.graph = None           # set by PretrainTrainer once the step has been captured on these buffers
         self.loss_out = None
         self.eager_runs = 0
+        # Object tokens (REVERIE / SOON: traj_obj_img_fts) are gathered with indices the forward derives on the HOST from
+        # traj_step_lens / traj_vp_obj_lens (vilmodel._obj_tokens) and uploads inside the forward: a captured graph would
+        # either refuse the pageable copy or freeze the indices of the batch it was captured on.  Such batches run eagerly.
+        self.capturable = batch.get("traj_obj_img_fts") is None
         host = self._host_side(batch)
         self.signature = host["signature"]
         t = {}
@@ -65,6 +70,14 @@ class StaticBatch:
             grid_store.attach(t, grid_keys)
         self.tensors = t
         self._refresh_counts()
+
+    @staticmethod
+    def plan(cfg, task, batch):
+        """The host-side part alone (shape signature, padded tensors, index tables) -- what a loader computes to find
+        the bucket of a batch before it touches any device buffer (loader.BucketManager)."""
+        self = object.__new__(StaticBatch)
+        self.cfg, self.task = cfg, task
+        return self._host_side(batch)
 
     # -- host side: everything that is a Python loop over ids or a data-dependent count --------------------------
     def _host_side(self, batch):
@@ -92,6 +105,8 @@ class StaticBatch:
                                                   batch["traj_cand_vpids"], batch["gmap_vpids"], n_views, G)
         static = {}
         sig = [task, B, tuple(batch["txt_ids"].shape), tuple(batch["traj_view_img_fts"].shape), G]
+        if batch.get("traj_obj_img_fts") is not None:      # buffers of a bucket must agree on the object-token layout too
+            sig.append(("obj", tuple(batch["traj_obj_img_fts"].shape), tuple(int(x) for x in batch["traj_step_lens"])))
         if task.startswith("mlm"):
             labels = batch["txt_labels"].reshape(-1)
             pos = torch.nonzero(labels != -1).squeeze(1)
@@ -119,10 +134,12 @@ class StaticBatch:
                 "signature": tuple(sig)}
 
     # -- in-place refill -----------------------------------------------------------------------------------------
-    def load(self, batch, grid_keys=None):
+    def load(self, batch, grid_keys=None, host=None):
         """Write another batch of the same shape bucket into these buffers (what a prefetching loader does with its
-        preallocated device buffers); a captured graph keeps replaying on them.  Raises if the bucket differs."""
-        host = self._host_side(batch)
+        preallocated device buffers); a captured graph keeps replaying on them.  Raises if the bucket differs.
+        ``host``: the result of ``plan`` for this batch if the caller has it already."""
+        if host is None:
+            host = self._host_side(batch)
         if host["signature"] != self.signature:
             raise ValueError(f"batch of shape bucket {host['signature']} does not fit the buffers of {self.signature}")
         t = self.tensors

@@ -244,7 +244,8 @@ class PretrainTrainer:
         return loss.detach()
 
     def optimizer_step(self, lr=None):
-        """clip_grad_norm_ + AdamW + schedule (train_r2r.py:278-313) on the flat arena (lr=None: device-resident)."""
+        """clip_grad_norm_ + AdamW + schedule (train_r2r.py:278-313) on the flat arena.  ``lr=None``: the schedule value
+        of the current global step is computed here and written to the device-resident slot."""
         if lr is None:
             lr = warmup_linear_lr(self.global_step, self.lr, self.warmup, self.total)
         self.arena.clip_and_step(lr, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
@@ -255,7 +256,7 @@ class PretrainTrainer:
         A ``static_step.StaticBatch`` runs eagerly ``GRAPH_WARMUP`` times, is then captured into a hipGraph (forward,
         backward with the weight-gradient stream, clip, AdamW -- and, on several GPUs, the in-place all-reduce on its
         side stream) and replayed from then on: one launch per step instead of ~1 000."""
-        if isinstance(batch, StaticBatch) and self.use_graphs and ops.TRACE is None:
+        if isinstance(batch, StaticBatch) and self.use_graphs and batch.capturable and ops.TRACE is None:
             return self._static_step(task, batch)
         loss = self.forward_backward(task, batch)
         self.optimizer_step()
