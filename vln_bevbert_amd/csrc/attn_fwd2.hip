@@ -258,12 +258,20 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd2_kernel(AttnArgs a) {
 // One wave per (bh, q16, k64): 8 hashes per lane give the 16 F words as wave-wide compare masks; the B words are the
 // same bits transposed inside the wave (4 ds_bpermute of the lane's 16-bit mask + 16 compares), not hashed again.
 // =============================================================================================
-// lane `LANE` of the (lo, hi) register pair <- the 64-bit wave mask m.  v_writelane_b32 has no builtin in this compiler;
-// the leading s_nop covers the "VALU wrote the SGPR (v_cmp) -> v_writelane reads it" wait states, which the compiler does
-// not insert for instructions inside an asm statement.
-template <int LANE> __device__ __forceinline__ void put_word(uint32_t& lo, uint32_t& hi, uint64_t m) {
-  asm volatile("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-               : "+v"(lo), "+v"(hi) : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "n"(LANE));
+// lanes LANE0 .. LANE0 + 3 of the (lo, hi) register pair <- four 64-bit wave masks.  v_writelane_b32 has no builtin in
+// this compiler; the ONE leading s_nop covers the "VALU wrote the SGPR (v_cmp) -> v_writelane reads it" wait states of
+// the most recent compare, which the compiler does not insert for instructions inside an asm statement.
+template <int LANE0> __device__ __forceinline__ void put_words4(uint32_t& lo, uint32_t& hi, uint64_t m0, uint64_t m1,
+                                                              uint64_t m2, uint64_t m3) {
+  asm volatile("s_nop 3\n\t"
+               "v_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %1, %3, %10\n\t"
+               "v_writelane_b32 %0, %4, %11\n\tv_writelane_b32 %1, %5, %11\n\t"
+               "v_writelane_b32 %0, %6, %12\n\tv_writelane_b32 %1, %7, %12\n\t"
+               "v_writelane_b32 %0, %8, %13\n\tv_writelane_b32 %1, %9, %13"
+               : "+v"(lo), "+v"(hi)
+               : "s"((uint32_t)m0), "s"((uint32_t)(m0 >> 32)), "s"((uint32_t)m1), "s"((uint32_t)(m1 >> 32)),
+                 "s"((uint32_t)m2), "s"((uint32_t)(m2 >> 32)), "s"((uint32_t)m3), "s"((uint32_t)(m3 >> 32)),
+                 "n"(LANE0), "n"(LANE0 + 1), "n"(LANE0 + 2), "n"(LANE0 + 3));
 }
 
 template <bool WITH_B>
@@ -285,10 +293,10 @@ __global__ __launch_bounds__(256) void attn_drop_bits_kernel(AttnArgs a, uint64_
       const uint32_t b0 = bb_pair_bits(key, pr), b1 = bb_pair_bits(key, pr + 1);
       const bool k0 = (b0 << 16) >= thr_hi, k1 = b0 >= thr_hi, k2 = (b1 << 16) >= thr_hi, k3 = b1 >= thr_hi;
       const uint64_t m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
-      if (t == 0) { put_word<0>(flo, fhi, m0); put_word<1>(flo, fhi, m1); put_word<2>(flo, fhi, m2); put_word<3>(flo, fhi, m3); }
-      if (t == 1) { put_word<4>(flo, fhi, m0); put_word<5>(flo, fhi, m1); put_word<6>(flo, fhi, m2); put_word<7>(flo, fhi, m3); }
-      if (t == 2) { put_word<8>(flo, fhi, m0); put_word<9>(flo, fhi, m1); put_word<10>(flo, fhi, m2); put_word<11>(flo, fhi, m3); }
-      if (t == 3) { put_word<12>(flo, fhi, m0); put_word<13>(flo, fhi, m1); put_word<14>(flo, fhi, m2); put_word<15>(flo, fhi, m3); }
+      if (t == 0) put_words4<0>(flo, fhi, m0, m1, m2, m3);
+      if (t == 1) put_words4<4>(flo, fhi, m0, m1, m2, m3);
+      if (t == 2) put_words4<8>(flo, fhi, m0, m1, m2, m3);
+      if (t == 3) put_words4<12>(flo, fhi, m0, m1, m2, m3);
       if (WITH_B) {
         const uint32_t nib = (k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u);
         mine |= nib << (4 * t);
@@ -299,15 +307,13 @@ __global__ __launch_bounds__(256) void attn_drop_bits_kernel(AttnArgs a, uint64_
       // destination lane (c' = c, g' = g) of word (t, r') wants keep(q = 16 q16 + 4 g' + r', key = 64 k64 + 16 t + c'):
       // source lane (c' >> 2) * 16 + 4 g' + r', source bit 4 t + (c' & 3)
       uint32_t blo = 0, bhi = 0;         // lane j < 16 ends up holding B word (t = j >> 2, r' = j & 3)
-#define BB_B_WORDS(RP)                                                                                   \
-      {                                                                                                     \
-        const int src = (c >> 2) * 16 + 4 * g + RP;                                                         \
-        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)mine) >> (c & 3);        \
-        put_word<0 + RP>(blo, bhi, __ballot(got & 1u));                                                     \
-        put_word<4 + RP>(blo, bhi, __ballot((got >> 4) & 1u));                                              \
-        put_word<8 + RP>(blo, bhi, __ballot((got >> 8) & 1u));                                              \
-        put_word<12 + RP>(blo, bhi, __ballot((got >> 12) & 1u));                                            \
-      }
+      // word index 4 t + r'; the four words of one r' sit 4 apart: assemble per t after all four r' have been fetched
+      uint32_t got[4];
+#pragma unroll
+      for (int rp = 0; rp < 4; ++rp)
+        got[rp] = (uint32_t)__builtin_amdgcn_ds_bpermute(((c >> 2) * 16 + 4 * g + rp) << 2, (int)mine) >> (c & 3);
+#define BB_B_WORDS(T) put_words4<4 * T>(blo, bhi, __ballot((got[0] >> (4 * T)) & 1u), __ballot((got[1] >> (4 * T)) & 1u), \
+                                        __ballot((got[2] >> (4 * T)) & 1u), __ballot((got[3] >> (4 * T)) & 1u));
       BB_B_WORDS(0) BB_B_WORDS(1) BB_B_WORDS(2) BB_B_WORDS(3)
 #undef BB_B_WORDS
       // word (bh, q32 = q16 >> 1, k16 = 4 k64 + t, tt = q16 & 1, r')

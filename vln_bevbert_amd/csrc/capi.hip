@@ -82,14 +82,21 @@ BEVBERT_API int bevbert_attn_fwd(const void* q, const void* k, const void* v, vo
   const int im = pick_impl(dtype, impl);
   if (im == 2 || im == 3) {
     BB_REQUIRE(dtype == BB_BF16, "attn_fwd: the MFMA path takes bf16 tensors");
-    if (drop_p > 0.f && drop_bits != nullptr && !bits_ready) {
-      rc = attn_drop_bits(a, a.drop_bits, a.drop_bits_b, stream);
-      if (rc != BB_OK) return rc;
-    }
     // BEVBERT_ATTN_FWD=1: the round-2 forward (hashes the dropout mask inline) for A/B measurements and as the on-GPU
     // cross-check of the second-generation kernel
     static const bool gen1 = [] { const char* v = getenv("BEVBERT_ATTN_FWD"); return v && v[0] == '1'; }();
-    if (!gen1 && attn_fwd2_supported(a)) return attn_fwd2(a, stream);
+    // Small score matrices with dropout (text 80 x 80, panoramas 36 x 36, the global map): their kernels are bound by
+    // launch latency, the inline hash of the round-2 forward hides in it, and that forward leaves the keep bits behind
+    // for the backward anyway -- a separate bit-generation launch per site only adds launches (35 of 71 per three steps).
+    const bool small = drop_p > 0.f && (int64_t)Lq * Lk < 32768 && Lk <= 256 && !bits_ready;   // (Lk > 256: the 7+1-wave
+    // backward wants the backward-layout bits, which only bevbert_attn_drop_bits writes)
+    if (!gen1 && !small && attn_fwd2_supported(a)) {
+      if (drop_p > 0.f && !bits_ready) {
+        rc = attn_drop_bits(a, a.drop_bits, a.drop_bits_b, stream);
+        if (rc != BB_OK) return rc;
+      }
+      return attn_fwd2(a, stream);
+    }
     return attn_mfma_fwd(a, stream);
   }
   return attn_simple_fwd(a, dtype, stream);

@@ -67,15 +67,19 @@ class _Runtime:
         v = _hash32(_hash32(step_seed & 0xFFFFFFFF) ^ (step_seed >> 32))
         return v - (1 << 32) if v >= (1 << 31) else v          # as int32 bit pattern
 
-    def new_step(self, step_seed, write_salt=True):
+    def new_step(self, step_seed, write_salt=True, plan_key=None):
         """Start the dropout stream of a step: offsets restart at 0 and the device salt becomes hash(step_seed).
-        ``write_salt=False`` only restarts the offsets (graph replay: the caller has already written the salt)."""
+        ``write_salt=False`` only restarts the offsets (graph replay: the caller has already written the salt).
+        ``plan_key``: identity of the step's shape (task + batch signature) for ``ATTN_BITS`` -- a step whose sequence of
+        attention-dropout sites is known from an earlier step with the same key generates all its keep-bit workspaces
+        up front on a side stream."""
         self.offset = 0
         if write_salt and torch.cuda.is_available():
             if self._salt is None:
                 self._salt = torch.zeros(1, dtype=torch.int32, device="cuda")
                 lib.load().bevbert_set_step_salt(self._salt.data_ptr())
             self._salt.fill_(self.salt_word(step_seed))
+        ATTN_BITS.begin(plan_key)
 
     def workspace(self, device, nfloats):
         # one scratch buffer per (device, stream): branches of the model run concurrently on separate streams
@@ -99,7 +103,79 @@ class _Runtime:
 
 
 _LT_WS_BYTES = 32 << 20
+
+
+class _AttnBitsPlanner:
+    """Keep-bit workspaces of a step's attention-dropout sites, generated ahead of the forward on a side stream.
+
+    The mask of a site is a pure function of (seed, offset, step salt, element index) and the (shape, offset) sequence
+    of a step repeats from step to step for the same task and batch shapes.  The first step with a given ``plan_key``
+    records the sequence (its sites generate their bits inline, in front of their forward kernel); every later step
+    with that key launches ALL its bevbert_attn_drop_bits calls when the step starts, on one side stream, into buffers
+    that belong to the plan -- the hashing (one 32-bit mix per element pair: ~80 us of pure VALU work per 441 x 441
+    site at batch 64) then runs beside the library GEMMs of the text and panorama encoders instead of in front of
+    every attention kernel, and each attention forward only waits for its site's event.  Works eagerly and inside a
+    captured step (the side stream is forked from and joined to the capturing stream).  BEVBERT_ATTN_BITS_AHEAD=0
+    turns it off (A/B measurements)."""
+
+    def __init__(self):
+        self.enabled = _os.environ.get("BEVBERT_ATTN_BITS_AHEAD", "1") == "1"
+        self.plans = {}          # key -> {"sites": [sig], "bufs": [tensor]}
+        self.key = None
+        self.seen = []
+        self.ready = None        # [(sig, bits, event)] of the running step
+        self.idx = 0
+        self.stream = None
+        self.hits = self.misses = 0
+
+    def begin(self, key):
+        if self.key is not None and self.seen and self.key not in self.plans:
+            self.plans[self.key] = {"sites": list(self.seen), "bufs": [None] * len(self.seen)}
+        self.key, self.seen, self.idx, self.ready = key, [], 0, None
+        if not self.enabled or key is None or not torch.cuda.is_available():
+            return
+        plan = self.plans.get(key)
+        if plan is None:
+            return
+        dev = torch.cuda.current_device()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)             # after the salt fill (and, in a capture, part of the captured graph)
+        ready = []
+        with torch.cuda.stream(self.stream):
+            for i, sig in enumerate(plan["sites"]):
+                B, nh, Lq, Lk, p, off = sig
+                if plan["bufs"][i] is None:
+                    plan["bufs"][i] = torch.empty(_drop_bits_words(B, nh, Lq, Lk), dtype=torch.int64, device="cuda")
+                bits = plan["bufs"][i]
+                call("bevbert_attn_drop_bits", ptr(bits), B, nh, Lq, Lk, float(p), self._seed(), int(off), stream())
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                ready.append((sig, bits, ev))
+        self.ready = ready
+
+    @staticmethod
+    def _seed():
+        return RT.seed
+
+    def get(self, B, nh, Lq, Lk, p, off, device):
+        """(workspace, bits_ready) for the next attention-dropout site of the running step."""
+        sig = (B, nh, Lq, Lk, float(p), int(off))
+        i = self.idx
+        self.idx += 1
+        self.seen.append(sig)
+        if self.ready is not None and i < len(self.ready) and self.ready[i][0] == sig:
+            _, bits, ev = self.ready[i]
+            torch.cuda.current_stream().wait_event(ev)
+            self.hits += 1
+            return bits, 1
+        self.misses += 1
+        return torch.empty(_drop_bits_words(B, nh, Lq, Lk), dtype=torch.int64, device=device), 0
+
+
 RT = _Runtime()
+ATTN_BITS = _AttnBitsPlanner()
 
 
 class Branches:
@@ -1185,15 +1261,18 @@ class _Attention(torch.autograd.Function):
             assert key_mask.dtype == torch.float32 and key_mask.shape == (B, Lk) and key_mask.is_contiguous()
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.shape == (B, Lq, Lk) and bias.is_contiguous()
-        bits = None
+        bits, bits_ready = None, 0
         if drop_p > 0 and q.dtype == torch.bfloat16 and impl != 1:
             # keep-bit workspace of the dropout mask (1 bit / element in the forward's and in the backward's lane
             # layout: 2 x 19 MB at 64x12x441x441), filled by the library ahead of the forward kernel; both directions
             # read bits through the scalar cache instead of hashing per element
-            bits = torch.empty(_drop_bits_words(B, nh, Lq, Lk), dtype=torch.int64, device=q.device)
+            if Lq * Lk >= 32768 or Lk > 256:
+                bits, bits_ready = ATTN_BITS.get(B, nh, Lq, Lk, drop_p, off, q.device)
+            else:       # small score matrices: the forward hashes inline and leaves the bits for the backward (capi.hip)
+                bits = torch.empty(_drop_bits_words(B, nh, Lq, Lk), dtype=torch.int64, device=q.device)
         call("bevbert_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(key_mask), ptr(bias),
              _strides(q, k, v, o), B, nh, Lq, Lk, HEAD_DIM, scale, dtype_code(q), impl, float(drop_p), RT.seed, off,
-             ptr(bits), 0, stream())
+             ptr(bits), bits_ready, stream())
         ctx.save_for_backward(a, b_, c_, key_mask, bias, o, lse, bits)
         ctx.cfg = (mode, nh, float(drop_p), RT.seed, off, impl, scale)
         return o

@@ -229,8 +229,14 @@ class PretrainTrainer:
     def forward_backward(self, task, batch):
         """Forward + backward + gradient exchange of one batch; leaves the (summed) gradients in ``arena.grads``."""
         self.global_step += 1
-        ops.RT.new_step(self._step_seed())
+        ops.RT.new_step(self._step_seed(), plan_key=self._plan_key(task, batch))
         return self._forward_backward(task, batch)
+
+    @staticmethod
+    def _plan_key(task, batch):
+        """Identity of a step's kernel sequence for ops.ATTN_BITS: static batches carry their shape signature; batches
+        of the reference API (data-dependent shapes) take the inline path."""
+        return (task, batch.signature) if isinstance(batch, StaticBatch) else None
 
     def _forward_backward(self, task, batch):
         self.arena.zero_grad()
@@ -273,7 +279,8 @@ class PretrainTrainer:
         if a.exp_avg is None:                       # optimiser state exists before anything is captured
             a.exp_avg = torch.zeros_like(a.params)
             a.exp_avg_sq = torch.zeros_like(a.params)
-        ops.RT.new_step(self._step_seed())          # salt -> device word (a 4-byte fill on the stream)
+        ops.RT.new_step(self._step_seed(), plan_key=None if (sb.graph is not None and sb.graph.owner is self)
+                        else self._plan_key(task, sb))          # salt -> device word (a 4-byte fill on the stream)
         a.set_lr(lr)                                # learning rate -> device word
         gs = sb.graph
         if gs is not None and gs.owner is self:
@@ -313,7 +320,9 @@ class PretrainTrainer:
             mode = "thread_local"
         try:
             with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):
-                ops.RT.new_step(0, write_salt=False)    # offsets restart; the salt word is read by the kernels at replay
+                # offsets restart; the salt word is read by the kernels at replay; the keep-bit generation of every
+                # attention site is captured as a side branch of the graph (ops.ATTN_BITS)
+                ops.RT.new_step(0, write_salt=False, plan_key=self._plan_key(task, sb))
                 loss = self._forward_backward(task, sb)
                 a.clip_and_step(None, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
         except Exception as e:      # noqa: BLE001 -- a step that cannot be captured (e.g. a collective library that refuses
@@ -324,7 +333,7 @@ class PretrainTrainer:
             warnings.warn(f"hipGraph capture of the {task} step failed, continuing with eager steps: {self.graph_error}")
             ops.Branches.enabled = branches
             torch.cuda.synchronize()
-            ops.RT.new_step(self._step_seed())
+            ops.RT.new_step(self._step_seed(), plan_key=self._plan_key(task, sb))
             loss = self._forward_backward(task, sb)
             self.optimizer_step(lr=None)
             return loss
