@@ -40,6 +40,10 @@ def main():
     ap.add_argument("--mode", default="infer", choices=["infer", "train"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--nodes", type=int, default=14, help="viewpoints per synthetic scan")
+    ap.add_argument("--check", action="store_true",
+                    help="size-independent properties of the rollout instead of timing (tests/test_gpu_model.py): every step's "
+                         "fused logits are finite or -inf, every live sample has a finite best action, a second rollout "
+                         "with the same step seed reproduces the logits")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -77,6 +81,8 @@ def main():
     pix, polar = ops.pixel_scale(cfg.grid_hw, dev), bevpos_polar(cfg.bev_dim, dev)
     t_book = [0.0]
 
+    trace = []
+
     def episode():
         gm = GraphMapBatch([ob["viewpoint"] for ob in obs_all[0]], cfg.hidden_size, dev, dtype=cdt)
         gm.update_graph(obs_all[0])
@@ -107,6 +113,8 @@ def main():
                 "bev_cand_idxs": bi["bev_cand_idxs"], "bev_cand_vpids": bi["bev_cand_vpids"], "obj_embeds": None,
                 "obj_masks": None})
             out = model("navigation", nav)
+            if a.check:
+                trace.append(out["fused_logits"].float().clone())
             if a.mode == "train":       # teacher action: [stop] is always a valid target of the fused logits
                 live = torch.from_numpy(~ended).to(dev)
                 tgt = torch.zeros(B, dtype=torch.long, device=dev)
@@ -123,6 +131,24 @@ def main():
             (episode() / B).backward()
             arena.clip_and_step(1e-5, max_norm=40.0)
 
+    if a.check:
+        runs = []
+        for _ in range(2):
+            trace.clear()
+            iteration(7)
+            torch.cuda.synchronize()
+            runs.append([t.cpu() for t in trace])
+        assert len(runs[0]) == T
+        for t in range(T):
+            x, y = runs[0][t], runs[1][t]
+            assert not torch.isnan(x).any() and not (x == float("inf")).any(), t
+            live = torch.from_numpy(~ended_all[t])
+            assert bool(torch.isfinite(x.max(1).values[live]).all()), t          # a live sample can always act ([stop])
+            fin = torch.isfinite(x)
+            assert torch.equal(fin, torch.isfinite(y)) and float((x[fin] - y[fin]).abs().max()) <= 1e-6 * max(1.0, float(x[fin].abs().max())), t
+        print(json.dumps({"check": "ok", "batch": B, "steps": T, "dtype": a.dtype,
+                          "map_nodes_last_step": int(runs[0][-1].shape[1])}))
+        return
     for i in range(a.warmup):
         iteration(i)
     torch.cuda.synchronize()

@@ -1,5 +1,7 @@
 """End-to-end parity of the HIP path on the MI355X: the product model (vln_bevbert_amd) against the golden vectors
 captured from the reference (tests/golden/*.npz) and against the CPU oracle, forward and backward, fp32 and bf16."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -424,22 +426,25 @@ def test_rxr_vocabulary_tasks_gpu(env, dtype):
 
 
 # ----------------------------------------------------------------------------- BASELINE configs[1] at full batch
-def test_full_r2r_batch64_properties(env):
-    """configs[1] at its real size (batch 64, full depth, bf16, dropout 0.1) through the whole model.  The oracle cannot
+@pytest.mark.parametrize("which", ["r2r_b64", "rxr_b32_len160"])
+def test_full_size_batch_properties(env, which):
+    """configs[1] (R2R, batch 64, 80 tokens) and the per-rank shape of configs[3] (RxR: xlm-roberta vocabulary of 250 002
+    tokens, 160-token instructions, batch 32 = 256 / 8 GPUs, full depth) at their real size (bf16, dropout 0.1) through the
+    whole model.  The oracle cannot
     finish this size in seconds, so the checks are size-independent: finite losses of the right shape; parameters a task
     does not use keep an exactly-zero gradient (find_unused_parameters semantics); a rerun with the same (seed, step)
     reproduces losses bit for bit and gradients to 1e-6 (fp32 summation order: atomics, split-K library GEMMs)."""
     from vln_bevbert_amd import ops
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
-    cfg = BevBertConfig()
+    cfg, B, L = (BevBertConfig(), 64, 80) if which == "r2r_b64" else (BevBertConfig.rxr(), 32, 160)
     torch.manual_seed(0)
     model = GlocalTextPathCMTPreTraining(cfg)
     arena = model.finalize(DEV, torch.bfloat16)
     model.train()
     model.set_dropout(0.1)
-    B = 64
     for task in ("sap", "mlm", "masksem"):
-        b = synthetic.batch_to(synthetic.make_batch(cfg, task, B, seed=2000, sems_as="ids"), DEV)
+        b = synthetic.batch_to(synthetic.make_batch(cfg, task, B, seed=2000, txt_len=L, sems_as="ids"), DEV)
+        assert b["txt_ids"].shape == (B, L)
         runs = []
         for rep in range(3):                    # rep 0 settles the hipBLASLt plans of this task's shapes
             ops.RT.new_step(77)
@@ -459,7 +464,7 @@ def test_full_r2r_batch64_properties(env):
         # across workgroups (the 30 522-deep MLM decoder dgrad).  Exact equality of everything else is asserted at
         # small sizes, where no split-K algorithm is picked (tests/test_gpu_zz_streams.py).
         rel = float((g1 - g2).norm() / g1.norm())
-        _record("rerun", f"B64 {task}", rel_l2=rel, differing=float((g1 != g2).float().mean()))
+        _record("rerun", f"{which} {task}", rel_l2=rel, differing=float((g1 != g2).float().mean()))
         assert rel < 1e-6, (task, rel)
         unused = {"sap": ("mlm_head.", "local_sem_head."), "mlm": ("global_sap_head.", "local_sap_head.", "local_sem_head.",
                                                                     "sap_fuse_linear."),
@@ -704,6 +709,63 @@ def test_batches_from_resident_grid_feature_store(env):
             want = R.pretrain_forward(sd, cfg, ob, task)
         assert torch.equal(via_store, as_tensors), task
         assert max_abs(via_store.numpy(), want.numpy()) < FP32_TOL, task
+
+
+def test_grid_feature_cache_to_resident_store_to_static_batch(env, tmp_path):
+    """f2 end to end: feature_cache.write_shards (the on-disk format that replaces the reference's three gzip HDF5 files,
+    map_nav_src/utils/data.py:9-29, precompute_features/grid_mp3d_clip.py:168-183) -> load_store (pinned, double
+    buffered upload into the device-resident store) -> StaticBatch(grid_store=...) -> the losses of a training-mode
+    forward equal those of the same batch shipped as tensors, and the oracle's on the fp16-rounded features."""
+    from vln_bevbert_amd import feature_cache, weights
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from vln_bevbert_amd.static_step import StaticBatch
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    model = GlocalTextPathCMTPreTraining(cfg)
+    sd = weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd)
+    model.tie_weights()
+    model.finalize(DEV, torch.float32)
+    model.eval()
+    pool = synthetic.make_batch(cfg, "sap", 7, seed=21, ragged=True, sems_as="ids")
+    keys = [f"scan{i // 3}_vp{i}" for i in range(7)]
+    n = feature_cache.write_shards(((k, pool["rgbs"][i].numpy(), pool["depths"][i, :, 0].numpy(),
+                                     pool["sems"][i].reshape(12, 14, 14).numpy()) for i, k in enumerate(keys)),
+                                   str(tmp_path), shard_size=3)                     # 3 shards: 3 + 3 + 1 viewpoints
+    assert n == 7 and len([f for f in os.listdir(tmp_path) if f.endswith(".safetensors")]) == 3
+    stats = {}
+    store = feature_cache.load_store(str(tmp_path), DEV, stats=stats)
+    assert len(store) == 7 and stats["bytes"] == store.nbytes() and stats["shards"] == 3
+    assert torch.equal(store.rgbs.cpu(), pool["rgbs"].reshape(7, 2352, -1).half())
+    subset = feature_cache.load_store(str(tmp_path), DEV, keys=[keys[5], keys[1]])   # one split of the dataset
+    assert torch.equal(subset.gather(subset.rows([keys[5]]))[0].cpu(), pool["rgbs"][5:6].reshape(1, 2352, -1).half())
+    pick = [6, 2, 0]
+    for task in ("sap", "mlm"):
+        b = synthetic.make_batch(cfg, task, 3, seed=33, ragged=True, sems_as="ids")
+        b["rgbs"] = pool["rgbs"][pick].half().float()
+        b["depths"], b["sems"] = pool["depths"][pick], pool["sems"][pick]
+        with torch.no_grad():
+            shipped = model.loss_mean(StaticBatch(cfg, task, b, DEV).tensors, task)
+            shipped = model.loss_mean(StaticBatch(cfg, task, b, DEV).tensors, task)      # (first call settles GEMM plans)
+            from_cache = model.loss_mean(StaticBatch(cfg, task, b, DEV, grid_store=store,
+                                                     grid_keys=[keys[i] for i in pick]).tensors, task)
+            ob = dict(b)
+            ob["sems"] = torch.from_numpy(np.eye(cfg.sem_classes)[b["sems"].reshape(3, -1).numpy()])
+            want = R.pretrain_forward(sd, cfg, ob, task).mean()
+        assert float(from_cache) == float(shipped), task
+        assert abs(float(from_cache) - float(want)) < FP32_TOL, task
+
+
+def test_finetune_rollout_full_size_properties(env):
+    """BASELINE.json configs[4] at its real size: batch 32, 15 navigation steps (scripts/ft_r2r.bash:37
+    --max_action_len 15), bf16, the whole per-step chain (panorama encoder, map bookkeeping, lift + splat out of the
+    resident store, navigation mode).  Size-independent checks run by scripts/bench_nav.py --check."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "bench_nav.py"), "--batch", "32", "--steps", "15",
+                        "--check"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert '"check": "ok"' in p.stdout, p.stdout[-500:]
 
 
 def test_finetune_bev_from_store_rows_of_visited_neighbours(env):

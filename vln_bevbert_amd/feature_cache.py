@@ -74,9 +74,14 @@ def read_index(cache_dir):
         return json.load(f)
 
 
-def load_store(cache_dir, device, keys=None):
-    """Build a GridFeatureStore from a cache directory (optionally only the viewpoints in `keys`, e.g. one split):
-    one sequential read per shard, then one host->device copy per shard."""
+def load_store(cache_dir, device, keys=None, stats=None):
+    """Build a GridFeatureStore from a cache directory (optionally only the viewpoints in `keys`, e.g. one split).
+
+    Per shard: one sequential read (safetensors, no decompression), one copy into a PINNED staging buffer, one
+    asynchronous host->device copy out of it.  Two staging buffers alternate, so the file read of shard s+1 overlaps
+    the PCIe transfer of shard s.  ``stats`` (a dict) receives bytes, seconds spent reading / staging / waiting and the
+    end-to-end GB/s -- the figure DESIGN.md quotes for filling the 38 GB R2R store."""
+    import time
     idx = read_index(cache_dir)
     want = None if keys is None else set(keys)
     missing = [] if want is None else sorted(want - set(idx["keys"]))
@@ -89,20 +94,64 @@ def load_store(cache_dir, device, keys=None):
     sh = idx["shape"]
     n_total = sum(len(v) for v in by_shard.values())
     P = sh["V"] * sh["hw"] * sh["hw"]
+    device = torch.device(device)
+    cuda = device.type == "cuda"
     # the store is allocated once at its final size (38 GB for R2R) and filled shard by shard: no second copy in HBM
     rgbs = torch.empty(n_total, P, sh["C"], dtype=torch.float16, device=device)
     depths = torch.empty(n_total, sh["V"], sh["hw"], sh["hw"], dtype=torch.float32, device=device)
     sems = torch.empty(n_total, P, dtype=torch.uint8, device=device)
+    dst = {"rgbs": rgbs, "depths": depths, "sems": sems}
+    n_max = max(len(v) for v in by_shard.values())
+    stage = [None, None]
+    events = [None, None]
+    if cuda:
+        stage = [{n: torch.empty((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, pin_memory=True) for n, t in dst.items()}
+                 for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device)
+    t_read = t_stage = t_wait = 0.0
+    nbytes = 0
+    t_all = time.perf_counter()
     out_keys, at = [], 0
-    for s in sorted(by_shard):
+    for j, s in enumerate(sorted(by_shard)):
+        t0 = time.perf_counter()
         t = load_file(os.path.join(cache_dir, f"shard_{s:05d}.safetensors"))
+        t_read += time.perf_counter() - t0
         rows = np.asarray([r for _, r in by_shard[s]], dtype=np.int64)
         out_keys += [k for k, _ in by_shard[s]]
         full = len(rows) == t["rgbs"].shape[0] and np.array_equal(rows, np.arange(len(rows)))
-        for name, dst in (("rgbs", rgbs), ("depths", depths), ("sems", sems)):
+        n = len(rows)
+        if cuda:
+            t0 = time.perf_counter()
+            if events[j & 1] is not None:
+                events[j & 1].synchronize()               # the transfer that last used this staging buffer is done
+            t_wait += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for name in ("rgbs", "depths", "sems"):
             a = t[name] if full else t[name][rows]
-            dst[at:at + len(rows)].copy_(torch.from_numpy(np.ascontiguousarray(a)), non_blocking=True)
-        at += len(rows)
+            src = torch.from_numpy(np.ascontiguousarray(a))
+            nbytes += src.numel() * src.element_size()
+            if cuda:
+                stage[j & 1][name][:n].copy_(src)
+            else:
+                dst[name][at:at + n].copy_(src)
+        t_stage += time.perf_counter() - t0
+        if cuda:
+            with torch.cuda.stream(copy_stream):
+                for name in ("rgbs", "depths", "sems"):
+                    dst[name][at:at + n].copy_(stage[j & 1][name][:n], non_blocking=True)
+                events[j & 1] = torch.cuda.Event()
+                events[j & 1].record(copy_stream)
+        at += n
+    if cuda:
+        t0 = time.perf_counter()
+        copy_stream.synchronize()
+        torch.cuda.current_stream(device).wait_stream(copy_stream)
+        t_wait += time.perf_counter() - t0
+    if stats is not None:
+        dt = time.perf_counter() - t_all
+        stats.update(bytes=nbytes, shards=len(by_shard), viewpoints=n_total, seconds=round(dt, 3),
+                     read_s=round(t_read, 3), stage_s=round(t_stage, 3), wait_s=round(t_wait, 3),
+                     GBps=round(nbytes / dt / 1e9, 2))
     return GridFeatureStore(out_keys, rgbs, depths, sems, device)
 
 
