@@ -143,8 +143,15 @@ def main():
     # BEVBERT_FORCE_COLLECTIVES=1: run the RCCL exchange (side stream, backward hook, in-place all-reduce) on a one-rank
     # group too -- a single-GPU stress of the multi-GPU code path, not a benchmark configuration
     force = os.environ.get("BEVBERT_FORCE_COLLECTIVES") == "1"
+    nccl_log = None
     if world > 1 or force:
         import torch.distributed as dist
+        # what RCCL decides for this topology (rings / trees, channels, protocol) goes into a per-rank file that rank 0
+        # digests into the "rccl" block: the first multi-GPU run of this code must be readable without a second run
+        nccl_log = f"/tmp/bevbert_rccl_{os.getpid()}_r{rank}.log"
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
+        os.environ.setdefault("NCCL_DEBUG_FILE", nccl_log)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -171,11 +178,12 @@ def main():
     launch = a.launch
     if launch == "auto" and os.environ.get("BEVBERT_GRAPHS") in ("0", "1"):
         launch = "graph" if os.environ["BEVBERT_GRAPHS"] == "1" else "eager"
-    if launch == "auto" and world > 1:
-        # captured steps with a real multi-rank RCCL exchange inside have never run on hardware (one-rank RCCL captures and
-        # replays fine: profiles/r02_launch_mode_and_stream_ab.txt); a scaling run takes the plain eager path unless
-        # BEVBERT_GRAPHS=1 / --launch graph asks for the capture explicitly
-        launch = "eager"
+    # Multi-rank runs take the same path as one rank: the step is captured with the in-place RCCL all-reduce of the
+    # gradient arena inside (issued from the backward hooks on the reducer's stream, forked from and joined to the
+    # capturing stream), eager and replayed cycles are timed in the untimed preparation (maximum over ranks, so every
+    # rank takes the same decision) and the faster mechanism runs the timed region.  A capture that fails -- a collective
+    # library that refuses stream capture -- is reported in "graph_error" and the trainer continues eagerly (train.py);
+    # the eager step costs 16-21 ms of host time per step on top of nothing the GPU could not hide at 18 ms/step.
     trainer.use_graphs = launch != "eager"
     # the reference draws the task of each step at random with ratio 5:5:1 (MetaLoader); the bench walks that mix as
     # a fixed 11-step cycle so that every run (and every K that is a multiple of 11) times exactly the same work
@@ -338,7 +346,35 @@ def main():
             dist.all_reduce(arena.grads)
         torch.cuda.synchronize()
         ar_ms = (time.perf_counter() - t0) / 5 * 1e3
+        # one eager step per task with per-region events: when each arena region's all-reduce starts and ends relative to
+        # the start of the step and to the end of backward
+        regions = {}
+        was_graphs = trainer.use_graphs
+        trainer.use_graphs = False
+        for t in tasks:
+            trainer.reducer.timeline = []
+            s_ev, b_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            s_ev.record()
+            trainer.forward_backward(t, batches[t][0])
+            b_ev.record()
+            torch.cuda.synchronize()
+            regions[t] = {"forward_backward_ms": round(s_ev.elapsed_time(b_ev), 3),
+                          "regions": [{"MB": round((hi - lo) * 4 / 1e6, 1), "start_ms": round(s_ev.elapsed_time(e0), 3),
+                                       "end_ms": round(s_ev.elapsed_time(e1), 3)} for lo, hi, e0, e1 in trainer.reducer.timeline]}
+            trainer.reducer.timeline = None
+        trainer.use_graphs = was_graphs
+        digest = []
+        try:
+            with open(os.environ.get("NCCL_DEBUG_FILE", nccl_log or "")) as f:
+                for ln in f:
+                    if any(k in ln for k in ("Channel", "Ring", "Tree", "Algo", "Proto", "nChannels", "threshold", "XGMI", "NVL", "Connected")):
+                        digest.append(ln.strip()[-160:])
+        except Exception as e:      # noqa: BLE001
+            digest = [f"no RCCL debug file: {e!r}"[:160]]
         out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                       "exchange": trainer.reducer.exchange, "region_timeline": regions,
+                       "debug_digest": digest[:40], "debug_lines": len(digest),
                        "allreduce_bytes_per_step": int(arena.numel) * 4,
                        "phase_a_bytes": int(arena.numel - trainer.reducer.split) * 4,
                        "allreduce_alone_ms": round(ar_ms, 3),

@@ -219,3 +219,38 @@ def test_arena_data_parallel_follows_the_single_process_run_through_a_torch_opti
     a, b = torch.load(single), torch.load(double)
     for k in ("a", "b"):
         assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-6), (k, (a[k] - b[k]).abs().max())
+
+
+def _bf16_exchange_run(rank, world, port, out):
+    from vln_bevbert_amd.train import GradReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(50 + rank)
+    n = 10_007                                             # not a multiple of the world size: exercises the padding
+    local = torch.randn(n, generator=g) * torch.logspace(-4, 2, n)          # seven decades of magnitudes
+    want = local.clone()
+    dist.all_reduce(want)                                  # fp32 reference (the default exchange)
+    got = local.clone()
+    red = GradReducer(got, split=4000, exchange="bf16")
+    assert red.active and red.exchange == "bf16"
+    red.phase_a()                                          # [4000, n) first, as the backward hook would
+    red.launch_region(1000, 2500)
+    red.finish()                                           # the rest
+    if rank == 0:
+        torch.save({"got": got, "want": want}, out)
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_exchange_sums_in_fp32_and_stays_within_two_bf16_roundings(tmp_path):
+    """BEVBERT_GRAD_EXCHANGE=bf16: half the bytes per link; against the fp32 all-reduce every element is within the
+    bf16 rounding of each rank's contribution plus that of the result (each 2^-9 relative), in any region order."""
+    out = str(tmp_path / "x.pt")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_bf16_exchange_run, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    got, want = r["got"], r["want"]
+    assert bool(torch.isfinite(got).all())
+    # |error| <= 2^-9 (|a| + |b|) + 2^-9 |a + b|  <=  3 * 2^-9 * (|a| + |b|); bound it by the result's own scale per decade
+    rel = float((got - want).norm() / want.norm())
+    assert rel < 4e-3, rel
+    assert float((got - want).abs().max()) <= 3 * 2 ** -8 * float(want.abs().max())

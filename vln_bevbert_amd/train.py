@@ -67,8 +67,16 @@ class TaskSampler:
 class GradReducer:
     """In-place SUM all-reduce of a flat gradient buffer in [split, end) then [0, split) (see module docstring)."""
 
-    def __init__(self, flat_grads, split, group=None, force=False):
-        """force=True issues the collectives even for a single-rank group (used to exercise the RCCL path on one GPU)."""
+    def __init__(self, flat_grads, split, group=None, force=False, exchange=None):
+        """force=True issues the collectives even for a single-rank group (used to exercise the RCCL path on one GPU).
+        exchange: "fp32" (in-place SUM all-reduce of the fp32 arena: the reference's DDP semantics, 956 MB per step for
+        the R2R model) or "bf16" (BEVBERT_GRAD_EXCHANGE=bf16): gradients travel as bf16 and are summed in fp32 --
+        cast -> all-to-all of the W shards -> fp32 sum of the W received pieces -> all-gather of the bf16 result: half
+        the bytes on every xGMI link, one bf16 rounding on the way out and one on the way back (2^-9 relative each)
+        instead of W - 1 roundings of a bf16 ring sum."""
+        import os
+        self.exchange = exchange or os.environ.get("BEVBERT_GRAD_EXCHANGE", "fp32")
+        assert self.exchange in ("fp32", "bf16"), self.exchange
         self.flat = flat_grads
         self.split = int(split)
         self.group = group
@@ -79,6 +87,7 @@ class GradReducer:
         self._works = []
         self._phase_a_done = False
         self._done = []          # [lo, hi) regions already issued in this step
+        self.timeline = None     # set to [] to collect (lo, hi, start event, end event) per region (bench.py's rccl block)
 
     def launch_region(self, lo, hi):
         """Reduce [lo, hi) now: every gradient in it has been enqueued (caller's guarantee).  Regions may be issued in
@@ -98,6 +107,19 @@ class GradReducer:
             gaps.append((at, self.flat.numel()))
         return gaps
 
+    def _exchange_bf16(self, view):
+        """SUM over ranks of ``view`` (fp32, in place) with bf16 on the wire and fp32 accumulation (see __init__)."""
+        W, n = self.world, view.numel()
+        per = -(-n // W)
+        send = torch.zeros(W * per, dtype=torch.bfloat16, device=view.device)
+        send[:n].copy_(view)                                   # fp32 -> bf16 (round to nearest even)
+        recv = torch.empty_like(send)
+        # transport as raw bytes: every backend moves them, none has to know bf16
+        dist.all_to_all_single(recv.view(torch.uint8), send.view(torch.uint8), group=self.group)
+        mine = recv.view(W, per).float().sum(0).to(torch.bfloat16)          # fp32 sum of the W pieces of MY shard
+        dist.all_gather_into_tensor(send.view(torch.uint8), mine.view(torch.uint8), group=self.group)
+        view.copy_(send[:n])                                   # bf16 -> fp32
+
     def _launch(self, lo, hi):
         if hi <= lo:
             return
@@ -110,7 +132,16 @@ class GradReducer:
                 if ops.Branches.enabled or side not in ops.WgradStream.streams or ops.WgradStream.dirty:   # this step
                     self.stream.wait_stream(side)
             with torch.cuda.stream(self.stream):
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.timeline is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
+                    self.timeline.append((lo, hi, e0, e1))
+                if self.exchange == "bf16":
+                    self._exchange_bf16(view)                  # stream-ordered on the reducer's stream
+                else:
+                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        elif self.exchange == "bf16":
+            self._exchange_bf16(view)
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -128,6 +159,14 @@ class GradReducer:
             for w in self._works:
                 w.wait()
             if self.stream is not None:
+                if self.timeline:
+                    # every region's end event goes out after ALL collectives were issued (they run in order on the
+                    # stream): the events then read "region k finished no later than"; good enough to see the overlap
+                    with torch.cuda.stream(self.stream):
+                        for _, _, _, e1 in self.timeline:
+                            if not getattr(e1, "_rec", False):
+                                e1.record(self.stream)
+                                e1._rec = True
                 torch.cuda.current_stream().wait_stream(self.stream)
         self._works = []
         self._phase_a_done = False
