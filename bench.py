@@ -366,7 +366,9 @@ def main():
         trainer.use_graphs = was_graphs
         digest = []
         try:
-            with open(os.environ.get("NCCL_DEBUG_FILE", nccl_log or "")) as f:
+            import glob
+            cands = sorted(glob.glob(os.environ.get("NCCL_DEBUG_FILE", nccl_log or "") + "*"))
+            with open(cands[0]) as f:
                 for ln in f:
                     if any(k in ln for k in ("Channel", "Ring", "Tree", "Algo", "Proto", "nChannels", "threshold", "XGMI", "NVL", "Connected")):
                         digest.append(ln.strip()[-160:])
@@ -500,7 +502,14 @@ def main():
         dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
     if rank == 0:
-        print(json.dumps(out), flush=True)     # after the teardown: the JSON is the last line on stdout
+        # after the teardown, and after whatever C libraries still hold in their stdio buffers (RCCL's version banner):
+        # the JSON is the last line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
 
 
 def side_configs(a):

@@ -114,10 +114,11 @@ class GradReducer:
         send = torch.zeros(W * per, dtype=torch.bfloat16, device=view.device)
         send[:n].copy_(view)                                   # fp32 -> bf16 (round to nearest even)
         recv = torch.empty_like(send)
-        # transport as raw bytes: every backend moves them, none has to know bf16
-        dist.all_to_all_single(recv.view(torch.uint8), send.view(torch.uint8), group=self.group)
+        # RCCL moves bf16 natively; gloo (the CPU tests) does not know the type: raw bytes there
+        as_wire = (lambda t: t) if view.is_cuda else (lambda t: t.view(torch.uint8))
+        dist.all_to_all_single(as_wire(recv), as_wire(send), group=self.group)
         mine = recv.view(W, per).float().sum(0).to(torch.bfloat16)          # fp32 sum of the W pieces of MY shard
-        dist.all_gather_into_tensor(send.view(torch.uint8), mine.view(torch.uint8), group=self.group)
+        dist.all_gather_into_tensor(as_wire(send), as_wire(mine), group=self.group)
         view.copy_(send[:n])                                   # bf16 -> fp32
 
     def _launch(self, lo, hi):
@@ -199,6 +200,10 @@ class PretrainTrainer:
         # the arena keeps registration order: embeddings, lang_encoder, img_embeddings come before the map encoders
         self.reducer = GradReducer(arena.grads, first_map, force=force_collectives)
         self.overlap = overlap and self.reducer.active
+        # the bf16 exchange is built from all-to-all + all-gather; RCCL 2.26's all-to-all under stream capture takes the
+        # process down (segmentation fault on the MI355X box, one-rank group, gpurun_out r03w) while its all-reduce
+        # captures fine: steps with that exchange are issued eagerly
+        self.capture_ok = not (self.reducer.active and self.reducer.exchange == "bf16")
         if self.reducer.active:
             self.broadcast_state()             # replicas start from rank 0's weights, as under DistributedDataParallel
         if self.overlap:
@@ -301,7 +306,7 @@ class PretrainTrainer:
         A ``static_step.StaticBatch`` runs eagerly ``GRAPH_WARMUP`` times, is then captured into a hipGraph (forward,
         backward with the weight-gradient stream, clip, AdamW -- and, on several GPUs, the in-place all-reduce on its
         side stream) and replayed from then on: one launch per step instead of ~1 000."""
-        if isinstance(batch, StaticBatch) and self.use_graphs and batch.capturable and ops.TRACE is None:
+        if isinstance(batch, StaticBatch) and self.use_graphs and self.capture_ok and batch.capturable and ops.TRACE is None:
             return self._static_step(task, batch)
         loss = self.forward_backward(task, batch)
         self.optimizer_step()
