@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -o pmc -- \
-    python $ROOT/scripts/bench_attn.py one > "$OUT/$C.log" 2>&1
+    python $ROOT/scripts/bench_attn_shape.py 64 441 441 0.1 > "$OUT/$C.log" 2>&1
   find "$OUT/$C" -name '*counter_collection*' -exec cp {} "$OUT/${C}.csv" \;
   rm -rf "$OUT/$C"
 done
@@ -18,7 +18,7 @@ res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     tot, cnt = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(os.path.join(d, c + ".csv"))):
-        if r["Counter_Name"] != c or "attn_mfma" not in r["Kernel_Name"]: continue
+        if r["Counter_Name"] != c or "attn_" not in r["Kernel_Name"]: continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         tot[k] += float(r["Counter_Value"]); cnt[k] += 1
     for k in tot: res[k][c + "_KiB_per_launch"] = tot[k] / cnt[k]

@@ -17,10 +17,11 @@ FP32_TOL = 1e-3          # north_star: "within 1e-3 fp32"
 
 
 BF16_MEAN_TOL = 1e-2     # north_star "1e-2 bf16": mean-abs error relative to the output's abs-max
-BF16_MAX_TOL = 3e-2      # and the worst element.  Achieved over the 61 forward comparisons of this suite (round 2, MI355X):
-#                          worst 2.1e-2 (SAP fused logits), typical 1e-2; the reference's own CPU-autocast forward sits at
-#                          3.4e-2 on MLM scores (tests/golden/ref_autocast_noise.npz).  Every comparison appends its
-#                          achieved error to gpurun_out/bf16_errors.jsonl.
+BF16_MAX_TOL = 2.5e-2    # and the worst element.  Achieved over the forward comparisons of this suite (MI355X): worst 2.1e-2
+#                          (SAP fused logits), typical 1e-2 -- the gate is the achieved worst plus a 20 % margin; the
+#                          reference's own CPU-autocast forward sits at 3.4e-2 on MLM scores
+#                          (tests/golden/ref_autocast_noise.npz).  Every comparison appends its achieved error to
+#                          gpurun_out/bf16_errors.jsonl (a copy of a full run: profiles/r03_bf16_errors_full_suite.jsonl).
 
 
 def _record(kind, what, **vals):
@@ -49,7 +50,11 @@ def bf16_close(got, want, what):
         (what, f"mean {err.mean() / scale:.3e} (tol {BF16_MEAN_TOL}) max {err.max() / scale:.3e} (tol {BF16_MAX_TOL})")
 
 
-BF16_GRAD_TOL = 0.25     # per-tensor relative L2 of bf16 gradients; achieved worst 0.22 (OG task, a 3-row table), median 0.03
+BF16_GRAD_TOL = 0.18     # per-tensor relative L2 of bf16 gradients: achieved worst 0.152 (word embeddings behind the whole text
+#                          encoder, OG task) + 20 % margin, median 0.03 ...
+BF16_GRAD_TOL_TINY_TABLES = 0.25     # ... except tables of 2-3 rows (token / navigation type embeddings): every row is the sum
+#                                      of thousands of cancelling bf16-rounded token gradients; achieved worst 0.22 (OG task)
+TINY_TABLES = ("token_type_embeddings", "nav_type_embedding", "type_embedding")
 
 
 def bf16_grad_close(got, ref, what):
@@ -63,7 +68,8 @@ def bf16_grad_close(got, ref, what):
         return
     l2 = float(np.linalg.norm(got - ref) / max(1e-12, np.linalg.norm(ref)))
     _record("grad", what, rel_l2=l2)
-    assert l2 < BF16_GRAD_TOL, (what, f"relative L2 {l2:.3e} (tol {BF16_GRAD_TOL})")
+    tol = BF16_GRAD_TOL_TINY_TABLES if any(t in str(what) for t in TINY_TABLES) else BF16_GRAD_TOL
+    assert l2 < tol, (what, f"relative L2 {l2:.3e} (tol {tol})")
 
 
 @pytest.fixture(scope="module")

@@ -116,21 +116,48 @@ __global__ __launch_bounds__(256) void bev_bin_sort_kernel(LiftArgs a) {
   __syncthreads();
   for (int c = tid; c <= K; c += 256) a.cell_start[(size_t)b * (K + 1) + c] = s_cnt[c];
 
-  // stable placement: the thread owning cell c walks the points in ascending id (LDS broadcast reads)
+  // Stable placement (point ids ascending inside every cell), in parallel.  Round 2 let the thread that owns a cell
+  // walk all P points (2 352 serial LDS reads per thread: 153 us for 64 workgroups, 1.5x the splat it feeds).  Now each
+  // of the four waves owns a contiguous quarter of the points: (A) per-wave cell counts, (B) per-cell exclusive prefix
+  // over the waves on top of the cell's start, (C) every wave walks its quarter 64 points at a time and ranks the lanes
+  // that share a cell with a compare mask (__ballot) -- lanes in ascending point order, waves in ascending ranges, so the
+  // order is exactly that of the serial walk.
+  __shared__ int s_wbase[4][MAX_CELLS + 1];
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int c = tid; c < 4 * (MAX_CELLS + 1); c += 256) (&s_wbase[0][0])[c] = 0;
+  __syncthreads();
+  const int per_wave = ((a.P + 255) / 256) * 64;              // points per wave, a multiple of 64
+  const int pw0 = wv * per_wave;
+  for (int p = pw0 + lane; p < pw0 + per_wave && p < a.P; p += 64) {
+    const int cid = s_cell[p];
+    if (cid >= 0) atomicAdd(&s_wbase[wv][cid], 1);
+  }
+  __syncthreads();
   for (int c = tid; c < K; c += 256) {
-    int w = s_cnt[c];
-    int* dst = a.order + (size_t)b * a.P;
-    const short cs = (short)c;
-    const int P4 = a.P & ~3;
-    for (int p = 0; p < P4; p += 4) {
-      const short4 v = *reinterpret_cast<const short4*>(&s_cell[p]);
-      if (v.x == cs) dst[w++] = p;
-      if (v.y == cs) dst[w++] = p + 1;
-      if (v.z == cs) dst[w++] = p + 2;
-      if (v.w == cs) dst[w++] = p + 3;
+    int base = s_cnt[c];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int n = s_wbase[w][c];
+      s_wbase[w][c] = base;
+      base += n;
     }
-    for (int p = P4; p < a.P; ++p)
-      if (s_cell[p] == cs) dst[w++] = p;
+  }
+  __syncthreads();
+  int* dst = a.order + (size_t)b * a.P;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));     // lanes below this one
+  for (int p0 = pw0; p0 < pw0 + per_wave && p0 < a.P; p0 += 64) {
+    const int p = p0 + lane;
+    const int cid = p < a.P ? (int)s_cell[p] : -1;
+    unsigned long long todo = __ballot(cid >= 0);
+    while (todo) {                                              // one round per distinct cell among the 64 points
+      const int leader = __builtin_ctzll(todo);
+      const int c0 = __shfl(cid, leader, 64);
+      const unsigned long long same = __ballot(cid == c0);
+      const int base = s_wbase[wv][c0];                         // (broadcast read)
+      if (cid == c0) dst[base + __builtin_popcountll(same & lt)] = p;
+      if (lane == leader) s_wbase[wv][c0] = base + __builtin_popcountll(same);
+      todo &= ~same;
+    }
   }
 }
 
