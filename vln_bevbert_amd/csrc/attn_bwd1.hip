@@ -436,7 +436,9 @@ int attn_mfma_bwd1(const AttnArgs& a, hipStream_t st) {
   // LDS time than the second wave hides, so one wave per SIMD is the default.
   static const bool eight = [] { const char* v = getenv("BEVBERT_BWD1_WAVES"); return v && v[0] == '8'; }();
   if (a.Lk <= 64) return dispatch_bwd1<1, 4, 1>(a, st);
-  if (a.Lk <= 128) return dispatch_bwd1<2, 4, 2>(a, st);
+  // 65..128 keys (the 80 text tokens): BEVBERT_BWD1_KEYS128=8 -> eight waves of 16 keys instead of four of 32
+  static const bool k128_8 = [] { const char* v = getenv("BEVBERT_BWD1_KEYS128"); return v && v[0] == '8'; }();
+  if (a.Lk <= 128) return k128_8 ? dispatch_bwd1<1, 8, 2>(a, st) : dispatch_bwd1<2, 4, 2>(a, st);
   if (a.Lk <= 256) return dispatch_bwd1<4, 4, 4>(a, st);
   if (eight) return dispatch_bwd1<4, 8, 7>(a, st);
   return dispatch_bwd1<7, 4, 7>(a, st);
