@@ -7,7 +7,7 @@ from . import ops
 from .config import BevBertConfig
 from .pretrain_cmt import ClsPrediction, fuse_sap_logits, sap_fusion_indices
 from .vilmodel import (BertEmbeddings, GlobalMapEncoder, ImageEmbeddings, LanguageEncoder, LocalBEVEncoder,
-                       _all_ones_to_none, ensure_arena, finalize)
+                       _all_ones_to_none, ensure_arena, finalize, from_pretrained)
 
 
 class GlocalTextPathNavCMT(nn.Module):
@@ -49,6 +49,11 @@ class GlocalTextPathNavCMT(nn.Module):
             elif isinstance(m, nn.LayerNorm):
                 m.weight.data.fill_(1.0)
                 m.bias.data.zero_()
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, config=None, state_dict=None, **kwargs):
+        """The call map_nav_src/models/vlnbert_init.py:78-81 makes; see vilmodel.from_pretrained."""
+        return from_pretrained(cls, pretrained_model_name_or_path, config, state_dict)
 
     def finalize(self, device, compute_dtype=torch.float32):
         return finalize(self, device, compute_dtype)
@@ -120,7 +125,9 @@ class VLNBert(nn.Module):
     def __init__(self, config, feat_dropout=0.4):
         super().__init__()
         self.vln_bert = GlocalTextPathNavCMT(config)
-        self.feat_dropout = feat_dropout
+        self.drop_env = nn.Dropout(feat_dropout)                  # model.py:19
+
+    feat_dropout = property(lambda self: self.drop_env.p, lambda self, v: setattr(self.drop_env, "p", v))
 
     def forward(self, mode, batch):
         batch = dict(batch)

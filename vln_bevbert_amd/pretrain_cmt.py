@@ -15,7 +15,7 @@ from torch import nn
 
 from . import ops
 from .config import BevBertConfig
-from .vilmodel import BertOnlyMLMHead, GlocalTextPathCMT, ensure_arena, finalize, gen_seq_masks
+from .vilmodel import BertOnlyMLMHead, GlocalTextPathCMT, ensure_arena, finalize, from_pretrained, gen_seq_masks
 
 BEV_DIM = 21      # pretrain_cmt.py:16-17 (the config's bev_dim / bev_res override these defaults)
 BEV_RES = 0.5
@@ -114,7 +114,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         config = BevBertConfig.adopt(config)     # a PretrainedConfig built from configs/*_model.json drops in (train_r2r.py:102-113)
         self.config = config
         self.bert = GlocalTextPathCMT(config)
-        self.feat_dropout = config.feat_dropout
+        self.drop_env = nn.Dropout(config.feat_dropout)          # pretrain_cmt.py:79; read through ``feat_dropout``
         if "mlm" in config.pretrain_tasks:
             self.mlm_head = BertOnlyMLMHead(config)
         if "mrc" in config.pretrain_tasks:
@@ -149,17 +149,27 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         if "mlm" in self.config.pretrain_tasks:     # pretrain_cmt.py:109-112
             self.mlm_head.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, config=None, state_dict=None, **kwargs):
+        """The call train_r2r.py:153-155 makes; see vilmodel.from_pretrained."""
+        return from_pretrained(cls, pretrained_model_name_or_path, config, state_dict)
+
     def finalize(self, device, compute_dtype=torch.float32):
         """Place parameters in the flat arena on ``device`` (fp32 masters + optional bf16 compute copy)."""
         return finalize(self, device, compute_dtype)
 
+    feat_dropout = property(lambda self: self.drop_env.p, lambda self, v: setattr(self.drop_env, "p", v))
+
     def set_dropout(self, p):
-        """utils/misc.py:19-25 set_dropout: the reference rewrites EVERY dropout probability (incl. feat_dropout)."""
-        self.feat_dropout = p
+        """Every dropout probability of the model, attention-probability dropout of the panorama encoder included
+        (tests use it to switch dropout off).  The reference's own ``set_dropout(model, p)`` (utils/misc.py:19-25)
+        works on this model unchanged as well: each site keeps its p in an ``nn.Dropout`` child (vilmodel._p_of), and
+        like there it leaves the float ``dropout`` of the panorama encoder's attention alone."""
         for m in self.modules():
-            for attr in ("drop_p", "dropout_p"):
-                if hasattr(m, attr):
-                    setattr(m, attr, p)
+            if isinstance(m, nn.Dropout):
+                m.p = p
+            if hasattr(m, "attn_drop_p"):
+                m.attn_drop_p = p
 
     # -- lift + splat -------------------------------------------------------------------------------
     def _projector(self, device):

@@ -44,14 +44,46 @@ class _Finalizable(nn.Module):
         pass
 
 
+def from_pretrained(cls, pretrained_model_name_or_path, config, state_dict):
+    """transformers' ``PreTrainedModel.from_pretrained(None, config=..., state_dict=...)`` as both entry scripts call it
+    (pretrain_src/train_r2r.py:153-155, map_nav_src/models/vlnbert_init.py:78-81): build from ``config`` (BERT
+    initialisation), overlay ``state_dict`` non-strictly, tie weights, eval mode.  A shape mismatch raises (as there);
+    keys the checkpoint lacks / has in excess are kept on ``model.load_report`` (transformers logs them)."""
+    if pretrained_model_name_or_path is not None:
+        raise NotImplementedError("checkpoints are passed as state_dict= (the entry scripts remap them first)")
+    model = cls(config)
+    missing, unexpected = [], []
+    if state_dict:
+        own = model.state_dict()
+        bad = [k for k, v in state_dict.items() if k in own and tuple(v.shape) != tuple(own[k].shape)]
+        if bad:
+            raise RuntimeError("size mismatch for " + ", ".join(bad[:8]))
+        res = model.load_state_dict(state_dict, strict=False)
+        missing, unexpected = list(res.missing_keys), list(res.unexpected_keys)
+    if hasattr(model, "tie_weights"):
+        model.tie_weights()
+    model.load_report = {"missing_keys": missing, "unexpected_keys": unexpected}
+    model.eval()
+    return model
+
+
+def _p_of(child):
+    """The probability of a dropout site is held by an ``nn.Dropout`` child (never called: the mask is drawn inside the
+    fused HIP kernels) so that the reference's ``set_dropout(model, p)`` (pretrain_src/utils/misc.py:19-25), which
+    rewrites ``module.p`` of every ``nn.Dropout`` it finds, reaches the kernels without a change to the loop."""
+    return property(lambda self: getattr(self, child).p, lambda self, v: setattr(getattr(self, child), "p", v))
+
+
 class BertEmbeddings(nn.Module):
+    dropout_p = _p_of("dropout")
+
     def __init__(self, config):
         super().__init__()
         self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=0)
         self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
         self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
         self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
-        self.dropout_p = config.hidden_dropout_prob
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
         self.eps = config.layer_norm_eps
 
     def forward(self, input_ids, token_type_ids=None, position_ids=None):
@@ -62,6 +94,8 @@ class BertEmbeddings(nn.Module):
 
 
 class BertSelfAttention(_Finalizable):
+    drop_p = _p_of("dropout")
+
     def __init__(self, config):
         super().__init__()
         if config.hidden_size % config.num_attention_heads != 0:
@@ -70,7 +104,7 @@ class BertSelfAttention(_Finalizable):
         self.num_attention_heads = config.num_attention_heads
         H = config.hidden_size
         self.query, self.key, self.value = nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, H)
-        self.drop_p = config.attention_probs_dropout_prob
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
 
     def _after_arena(self, arena, prefix):
         H = self.query.weight.shape[0]
@@ -94,11 +128,13 @@ class BertSelfAttention(_Finalizable):
 
 
 class BertSelfOutput(nn.Module):
+    drop_p = _p_of("dropout")
+
     def __init__(self, config):
         super().__init__()
         self.dense = nn.Linear(config.hidden_size, config.hidden_size)
         self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
-        self.drop_p = config.hidden_dropout_prob
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
         self.eps = config.layer_norm_eps
 
     def forward(self, hidden_states, input_tensor):
@@ -131,11 +167,13 @@ class BertIntermediate(nn.Module):
 
 
 class BertOutput(nn.Module):
+    drop_p = _p_of("dropout")
+
     def __init__(self, config):
         super().__init__()
         self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
         self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
-        self.drop_p = config.hidden_dropout_prob
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
         self.eps = config.layer_norm_eps
 
     def forward(self, hidden_states, input_tensor):
@@ -190,6 +228,8 @@ class BertOnlyMLMHead(nn.Module):
 
 
 class BertOutAttention(_Finalizable):
+    drop_p = _p_of("dropout")
+
     def __init__(self, config, ctx_dim=None):
         super().__init__()
         self.num_attention_heads = config.num_attention_heads
@@ -198,7 +238,7 @@ class BertOutAttention(_Finalizable):
         self.query = nn.Linear(H, H)
         self.key = nn.Linear(ctx_dim, H)
         self.value = nn.Linear(ctx_dim, H)
-        self.drop_p = config.attention_probs_dropout_prob
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
 
     def _after_arena(self, arena, prefix):
         H, C = self.key.weight.shape
@@ -304,6 +344,7 @@ class _MHAParams(nn.Module):
 
 class TransformerEncoderLayer(nn.Module):
     """transformer.py:133-182 with normalize_before=True (the only mode create_transformer_encoder uses)."""
+    drop_p = _p_of("dropout")
 
     def __init__(self, d_model, nhead, dim_feedforward, dropout):
         super().__init__()
@@ -312,13 +353,15 @@ class TransformerEncoderLayer(nn.Module):
         self.linear2 = nn.Linear(dim_feedforward, d_model)
         self.norm1 = nn.LayerNorm(d_model)      # eps 1e-5 (nn.LayerNorm default), transformer.py:144-145
         self.norm2 = nn.LayerNorm(d_model)
-        self.nhead, self.drop_p = nhead, dropout
+        self.nhead = nhead
+        self.attn_drop_p = dropout              # nn.MultiheadAttention keeps a float: set_dropout does not reach it
+        self.dropout = nn.Dropout(dropout)      # transformer.py:142,146-147 dropout / dropout1 / dropout2 share p
 
     def forward(self, src, key_mask):
         tr, p = self.training, self.drop_p
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias, 1e-5)
         qkv = ops.linear(h, self.self_attn.in_proj_weight, self.self_attn.in_proj_bias)
-        a = ops.attention_self(qkv, key_mask, None, self.nhead, p, tr)
+        a = ops.attention_self(qkv, key_mask, None, self.nhead, self.attn_drop_p, tr)
         o = ops.linear(a, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias)
         src = ops.dropout(o, p, tr, residual=src)
         h = ops.layernorm(src, self.norm2.weight, self.norm2.bias, 1e-5)
@@ -353,6 +396,8 @@ def _small_k_linear(x, lin, out_dtype):
 
 
 class ImageEmbeddings(nn.Module):
+    drop_p = _p_of("dropout")
+
     def __init__(self, config):
         super().__init__()
         H = config.hidden_size
@@ -372,7 +417,7 @@ class ImageEmbeddings(nn.Module):
             self.obj_linear = self.obj_layer_norm = None
         self.nav_type_embedding = nn.Embedding(getattr(config, "nav_type_vocab", 3), H)
         self.layer_norm = nn.LayerNorm(H, eps=1e-12)
-        self.drop_p = config.hidden_dropout_prob
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
         self.pano_encoder = TransformerEncoder(config, config.num_pano_layers) if config.num_pano_layers > 0 else None
 
     def embed(self, view_img_fts, loc_fts, nav_types, view_lens, type_embed_layer, obj_img_fts=None, obj_lens=None,
