@@ -434,7 +434,7 @@ def main():
         dom_entry = max(by_entry, key=by_entry.get)
         dom_key, dom = max(((k, r) for k, r in rows.items() if k.split("[")[0] == dom_entry), key=lambda kv: kv[1]["ms"])
         traffic = traffic_source = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f).get(dom_key)

@@ -421,6 +421,32 @@ def test_attention_fwd_bwd(ops, case, impl, dtype):
         assert rel_err(bi.grad, br.grad) < gt, "dbias"
 
 
+@pytest.mark.parametrize("Lq,Lk,mk", [(80, 80, "neg"), (441, 80, "neg"), (17, 80, "inf"), (80, 17, "neg"), (36, 36, "inf"),
+                                       (100, 96, None), (33, 5, None), (70, 49, "neg")])
+def test_attention_short_key_kernels_with_dropout(ops, Lq, Lk, mk, monkeypatch):
+    """attn_small.hip (Lk <= 96, no graph bias): forward (inline hash, one tile set) and the one-wave backward, which
+    reads the keep bits the forward left, against the fp32 reference under the exported mask -- every key-tile count
+    the launcher instantiates (2, 3, 5, 6) and query counts with partial tiles / partial 32-query chunks.  The kernels
+    are opt-in (they measured no faster than the tiled ones, capi.hip); the library reads the switch per call."""
+    monkeypatch.setenv("BEVBERT_ATTN_SMALL", "1")
+    B, p, dtype = 3, 0.1, torch.bfloat16
+    q, k, v, km, _, nh = _make_attn_inputs(B, Lq, Lk, mk, False, dtype, seed=Lq + Lk)
+    ops.RT.new_step(1234 + Lk)
+    qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o = ops._Attention.apply("sep", qi, ki, vi, km, None, nh, p, 2)
+    Lk2 = (Lk + 1) // 2 * 2
+    keep = ops.dropout_keep_mask(B * nh * Lq * Lk2, p, ops.RT.seed, 0, DEV).view(B, nh, Lq, Lk2)[..., :Lk]
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    orf = _attn_ref(qr, kr, vr, km, None, nh, keep, p)
+    assert float((o.float() - orf).abs().max()) < 1.5e-2 * max(1.0, float(orf.abs().max()))
+    do = torch.randn_like(orf).to(dtype)
+    o.backward(do)
+    orf.backward(do.float())
+    for name, a, b_ in (("dq", qi.grad, qr.grad), ("dk", ki.grad, kr.grad), ("dv", vi.grad, vr.grad)):
+        assert bool(torch.isfinite(a).all()), name
+        assert rel_err(a, b_) < 3e-2, (name, rel_err(a, b_))
+
+
 @pytest.mark.parametrize("Lk", [140, 441, 36])
 @pytest.mark.parametrize("impl,dtype", [(1, torch.float32), (2, torch.bfloat16), (3, torch.bfloat16)])
 def test_attention_dropout_matches_exported_mask(ops, impl, dtype, Lk):

@@ -36,10 +36,19 @@ bool attn_fwd2_supported(const AttnArgs& a);
 int attn_drop_bits(const AttnArgs& a, uint64_t* bits_f, uint64_t* bits_b, hipStream_t st);
 int attn_bwd2(const AttnArgs& a, hipStream_t st);
 bool attn_bwd2_supported(const AttnArgs& a);
+int attn_small_fwd(const AttnArgs& a, hipStream_t st);
+bool attn_small_fwd_supported(const AttnArgs& a);
+int attn_small_bwd(const AttnArgs& a, hipStream_t st);
+bool attn_small_bwd_supported(const AttnArgs& a);
 
 // The keep-bit workspace of a call holds the matrix twice: [forward layout | backward layout], see attn_fwd2.hip
 static int64_t bits_words_one(int B, int nh, int Lq, int Lk) {
   return (int64_t)B * nh * ((Lq + 127) / 128 * 8) * ((Lk + 63) / 64) * 16;
+}
+
+static bool small_kernels_on() {
+  const char* v = getenv("BEVBERT_ATTN_SMALL");
+  return v && v[0] == '1';
 }
 
 // impl: 0 = auto (bf16 -> MFMA, f32 -> exact), 1 = force exact kernels, 2 = force MFMA (bf16 only),
@@ -85,6 +94,10 @@ BEVBERT_API int bevbert_attn_fwd(const void* q, const void* k, const void* v, vo
     // BEVBERT_ATTN_FWD=1: the round-2 forward (hashes the dropout mask inline) for A/B measurements and as the on-GPU
     // cross-check of the second-generation kernel
     static const bool gen1 = [] { const char* v = getenv("BEVBERT_ATTN_FWD"); return v && v[0] == '1'; }();
+    // BEVBERT_ATTN_SMALL=1 (read per call): short key sequences without a graph bias go to the one-tile-set kernels of
+    // attn_small.hip.  Measured (r03y, B = 64, 80 x 80, p = 0.1): 17.6 us against 12.3 + 5.9 us (tiled forward + bit
+    // generation), backward 30.6 against 27.7 us -- no gain, so the tiled kernels stay the default.
+    if (!gen1 && small_kernels_on() && attn_small_fwd_supported(a)) return attn_small_fwd(a, stream);
     // Small score matrices with dropout (text 80 x 80, panoramas 36 x 36, the global map): their kernels are bound by
     // launch latency, the inline hash of the round-2 forward hides in it, and that forward leaves the keep bits behind
     // for the backward anyway -- a separate bit-generation launch per site only adds launches (35 of 71 per three steps).
@@ -124,6 +137,7 @@ BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, co
     static const bool split = [] { const char* v = getenv("BEVBERT_ATTN_BWD"); return v && v[0] == 's'; }();
     // BEVBERT_ATTN_BWD=1: the round-2 single-pass kernel where the 7+1-wave kernel (attn_bwd2.hip) would run
     static const bool gen1 = [] { const char* v = getenv("BEVBERT_ATTN_BWD"); return v && v[0] == '1'; }();
+    if (!split && !gen1 && small_kernels_on() && im == 2 && attn_small_bwd_supported(a)) return attn_small_bwd(a, stream);
     if (!split && !gen1 && im == 2 && attn_bwd2_supported(a)) return attn_bwd2(a, stream);
     if (!split && im == 2 && attn_mfma_bwd1_supported(a)) return attn_mfma_bwd1(a, stream);
     return attn_mfma_bwd(a, stream);

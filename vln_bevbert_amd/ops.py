@@ -1266,7 +1266,9 @@ class _Attention(torch.autograd.Function):
             # keep-bit workspace of the dropout mask (1 bit / element in the forward's and in the backward's lane
             # layout: 2 x 19 MB at 64x12x441x441), filled by the library ahead of the forward kernel; both directions
             # read bits through the scalar cache instead of hashing per element
-            if Lq * Lk >= 32768 or Lk > 256:
+            # attn_small.hip (opt-in, BEVBERT_ATTN_SMALL=1) hashes inline whatever the query count
+            short_keys = Lk <= 96 and bias is None and _os.environ.get("BEVBERT_ATTN_SMALL") == "1"
+            if (Lq * Lk >= 32768 or Lk > 256) and not short_keys:
                 bits, bits_ready = ATTN_BITS.get(B, nh, Lq, Lk, drop_p, off, q.device)
             else:       # small score matrices: the forward hashes inline and leaves the bits for the backward (capi.hip)
                 bits = torch.empty(_drop_bits_words(B, nh, Lq, Lk), dtype=torch.int64, device=q.device)
