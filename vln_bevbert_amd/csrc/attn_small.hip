@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512) void attn_small_fwd_kernel(AttnArgs a, int qpw
         p[1] = k1 ? p[1] : 0.f;
         p[2] = k2 ? p[2] : 0.f;
         p[3] = k3 ? p[3] : 0.f;
-        if (a.drop_bits != nullptr) {
+        if (a.drop_bits != nullptr && t * 16 < a.Lk) {   // (a tile wholly beyond Lk has no words: NKT rounds the tile count up)
           const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), m2b = __ballot(k2), m3 = __ballot(k3);
           if (lane == 0) {
             uint64_t* wp = a.drop_bits + attn_bits_word(a, b * a.nh + h, qt, t >> 2, t & 3, 0);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64, 1) void attn_small_bwd_kernel(AttnArgs a) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
-          r.bits[j * NKT + t] = a.drop_bits[attn_bits_word(a, bh, (q0 >> 4) + j, t >> 2, t & 3, c & 3)];
+          r.bits[j * NKT + t] = (t * 16 < a.Lk) ? a.drop_bits[attn_bits_word(a, bh, (q0 >> 4) + j, t >> 2, t & 3, c & 3)] : 0ull;
     }
   };
   auto chunk_commit = [&](const ChunkRegs& r, int q0) __attribute__((always_inline)) {

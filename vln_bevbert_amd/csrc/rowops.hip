@@ -241,21 +241,71 @@ __global__ __launch_bounds__(1024) void multi_finalize_kernel(const FinalizeTask
 // =============================================================================================
 // bias + erf-GELU forward / backward, and a plain column sum (QKV bias grads)
 // =============================================================================================
+// Same decomposition as the backward below: grid (row groups, 1024-column slices), a thread owns 4 columns (its bias is
+// loaded once) and walks CONTIGUOUS rows with 8 independent loads in flight.  The first version -- a flat grid-stride
+// loop, one chunk per thread and iteration, the column recomputed as (i * 4) % C on a 64-bit index (~60 instructions
+// per chunk) -- ran at 3.2 TB/s.
 template <typename T>
 __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
-                                                            T* __restrict__ y, size_t n4, int C) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const int col = (int)((i * 4) % C);
-    float4 a = ld4<T>(x + i * 4);
-    const float4 b = *reinterpret_cast<const float4*>(bias + col);
-    a.x = gelu_erf(a.x + b.x); a.y = gelu_erf(a.y + b.y); a.z = gelu_erf(a.z + b.z); a.w = gelu_erf(a.w + b.w);
-    st4<T>(y + i * 4, a);
+                                                            T* __restrict__ y, int rows, int C) {
+  const int c0 = blockIdx.y * 1024 + threadIdx.x * 4;
+  if (c0 >= C) return;
+  const float4 b = *reinterpret_cast<const float4*>(bias + c0);
+  const int rpb = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+  int r = blockIdx.x * rpb;
+  rows = (r + rpb < rows) ? r + rpb : rows;
+  constexpr int R = 8;
+  for (; r + R - 1 < rows; r += R) {
+    float4 a[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) a[k] = ld4<T>(x + (size_t)(r + k) * C + c0);
+#pragma unroll
+    for (int k = 0; k < R; ++k) st4<T>(y + (size_t)(r + k) * C + c0, gelu4_of<T>(a[k], b));
+  }
+  for (; r < rows; ++r) st4<T>(y + (size_t)r * C + c0, gelu4_of<T>(ld4<T>(x + (size_t)r * C + c0), b));
+}
+
+// bf16, 16-byte accesses: a thread owns 8 columns (128 threads per 1024-column slice)
+__device__ __forceinline__ void bf16x8_to_f32(const uint4& u, float4& lo, float4& hi) {
+  lo = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                   __uint_as_float(u.y & 0xffff0000u));
+  hi = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                   __uint_as_float(u.w & 0xffff0000u));
+}
+__device__ __forceinline__ uint4 f32_to_bf16x8(const float4& lo, const float4& hi) {
+  return make_uint4(pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y), pack_bf16x2(hi.z, hi.w));
+}
+__global__ __launch_bounds__(128) void bias_gelu_fwd8_kernel(const bf16_raw* __restrict__ x, const float* __restrict__ bias,
+                                                             bf16_raw* __restrict__ y, int rows, int C) {
+  const int c0 = blockIdx.y * 1024 + threadIdx.x * 8;
+  if (c0 >= C) return;
+  const float4 b0 = *reinterpret_cast<const float4*>(bias + c0), b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+  const int rpb = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+  int r = blockIdx.x * rpb;
+  rows = (r + rpb < rows) ? r + rpb : rows;
+  constexpr int R = 8;
+  for (; r + R - 1 < rows; r += R) {
+    uint4 a[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) a[k] = *reinterpret_cast<const uint4*>(x + (size_t)(r + k) * C + c0);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      float4 lo, hi;
+      bf16x8_to_f32(a[k], lo, hi);
+      *reinterpret_cast<uint4*>(y + (size_t)(r + k) * C + c0) =
+          f32_to_bf16x8(gelu4_of<bf16_raw>(lo, b0), gelu4_of<bf16_raw>(hi, b1));
+    }
+  }
+  for (; r < rows; ++r) {
+    float4 lo, hi;
+    bf16x8_to_f32(*reinterpret_cast<const uint4*>(x + (size_t)r * C + c0), lo, hi);
+    *reinterpret_cast<uint4*>(y + (size_t)r * C + c0) = f32_to_bf16x8(gelu4_of<bf16_raw>(lo, b0), gelu4_of<bf16_raw>(hi, b1));
   }
 }
 
 // MODE 0: dx = dy * gelu'(x + bias) ; partial column sums of dx.   MODE 1: plain column sums of dy (no dx).
 // Grid (row groups, column slices of 1024): thread t owns 4 columns and walks its row group 4 rows at a time
-// (4 independent loads in flight); partials[blockIdx.x][C].
+// (8 independent loads per tensor in flight); partials[blockIdx.x][C].
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colwise_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ bias, T* __restrict__ dx,
@@ -265,20 +315,23 @@ __global__ __launch_bounds__(256) void colwise_bwd_kernel(const T* __restrict__ 
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE == 0) b = *reinterpret_cast<const float4*>(bias + c0);
-  const int stride = gridDim.x;
-  int r = blockIdx.x;
-  for (; r + 3 * stride < rows; r += 4 * stride) {
-    float4 d[4], a[4];
+  // block b owns the CONTIGUOUS rows [b * rpb, (b + 1) * rpb): the eight rows a thread has in flight are neighbours
+  const int rpb = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int stride = 1;
+  int r = blockIdx.x * rpb;
+  rows = (r + rpb < rows) ? r + rpb : rows;
+  constexpr int R = 8;                   // rows in flight per thread
+  for (; r + (R - 1) * stride < rows; r += R * stride) {
+    float4 d[R], a[R];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < R; ++k) {
       d[k] = ld4<T>(dy + (size_t)(r + k * stride) * C + c0);
       if (MODE == 0) a[k] = ld4<T>(x + (size_t)(r + k * stride) * C + c0);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < R; ++k) {
       if (MODE == 0) {
-        d[k].x *= gelu_erf_grad(a[k].x + b.x); d[k].y *= gelu_erf_grad(a[k].y + b.y);
-        d[k].z *= gelu_erf_grad(a[k].z + b.z); d[k].w *= gelu_erf_grad(a[k].w + b.w);
+        d[k] = gelu_grad4_of<T>(d[k], a[k], b);
         st4<T>(dx + (size_t)(r + k * stride) * C + c0, d[k]);
       }
       acc.x += d[k].x; acc.y += d[k].y; acc.z += d[k].z; acc.w += d[k].w;
@@ -288,8 +341,7 @@ __global__ __launch_bounds__(256) void colwise_bwd_kernel(const T* __restrict__ 
     float4 d = ld4<T>(dy + (size_t)r * C + c0);
     if (MODE == 0) {
       const float4 a = ld4<T>(x + (size_t)r * C + c0);
-      d.x *= gelu_erf_grad(a.x + b.x); d.y *= gelu_erf_grad(a.y + b.y);
-      d.z *= gelu_erf_grad(a.z + b.z); d.w *= gelu_erf_grad(a.w + b.w);
+      d = gelu_grad4_of<T>(d, a, b);
       st4<T>(dx + (size_t)r * C + c0, d);
     }
     acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
@@ -605,6 +657,13 @@ static int colwise_blocks(int rows) {
   return nb < 1 ? 1 : nb;
 }
 
+// row groups of a purely elementwise row kernel (no partial rows to bound): 8 rows each, at most 4096 groups
+static int elementwise_row_groups(int rows) {
+  int nb = (rows + 7) / 8;
+  if (nb > 4096) nb = 4096;
+  return nb < 1 ? 1 : nb;
+}
+
 // workspace: >= bevbert_colsum_workspace_floats(3*H) floats
 BEVBERT_API int64_t bevbert_colsum_workspace_floats(int total_cols) { return (int64_t)512 * total_cols; }
 
@@ -656,13 +715,13 @@ BEVBERT_API int bevbert_bias_gelu_fwd(const void* x, const float* bias, void* y,
                                       hipStream_t stream) {
   BB_REQUIRE(C % 4 == 0, "bias_gelu_fwd: C=%d must be a multiple of 4", C);
   if (rows <= 0) return BB_OK;
-  const size_t n4 = (size_t)rows * C / 4;
-  size_t nb = (n4 + 255) / 256;
-  if (nb > 4096) nb = 4096;
+  const dim3 grid(elementwise_row_groups(rows), (C + 1023) / 1024);
   if (dtype == BB_F32)
-    hipLaunchKernelGGL(bias_gelu_fwd_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)x, bias, (float*)y, n4, C);
+    hipLaunchKernelGGL(bias_gelu_fwd_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, bias, (float*)y, rows, C);
+  else if (dtype == BB_BF16 && C % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0)   // 71 vs 76 us at 28224 x 3072
+    hipLaunchKernelGGL(bias_gelu_fwd8_kernel, grid, dim3(128), 0, stream, (const bf16_raw*)x, bias, (bf16_raw*)y, rows, C);
   else if (dtype == BB_BF16)
-    hipLaunchKernelGGL(bias_gelu_fwd_kernel<bf16_raw>, dim3(nb), dim3(256), 0, stream, (const bf16_raw*)x, bias, (bf16_raw*)y, n4, C);
+    hipLaunchKernelGGL(bias_gelu_fwd_kernel<bf16_raw>, grid, dim3(256), 0, stream, (const bf16_raw*)x, bias, (bf16_raw*)y, rows, C);
   else {
     bb_set_error("bias_gelu_fwd: dtype %d unsupported", dtype);
     return BB_EUNSUPPORTED;
