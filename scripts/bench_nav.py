@@ -28,6 +28,7 @@ from vln_bevbert_amd.config import BevBertConfig  # noqa: E402
 from vln_bevbert_amd.feature_store import GridFeatureStore  # noqa: E402
 from vln_bevbert_amd.graph_map import GraphMapBatch  # noqa: E402
 from vln_bevbert_amd.nav_model import VLNBert  # noqa: E402
+from vln_bevbert_amd.nav_static import NavGraphRunner  # noqa: E402
 from vln_bevbert_amd.pretrain_cmt import bevpos_polar  # noqa: E402
 
 
@@ -40,6 +41,9 @@ def main():
     ap.add_argument("--mode", default="infer", choices=["infer", "train"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--nodes", type=int, default=14, help="viewpoints per synthetic scan")
+    ap.add_argument("--no-graphs", action="store_true",
+                    help="infer mode: issue the panorama / navigation forwards eagerly instead of replaying the captured "
+                         "steps of nav_static.NavGraphRunner")
     ap.add_argument("--check", action="store_true",
                     help="size-independent properties of the rollout instead of timing (tests/test_gpu_model.py): every step's "
                          "fused logits are finite or -inf, every live sample has a finite best action, a second rollout "
@@ -80,6 +84,8 @@ def main():
                      "view_lens": torch.full((B,), 36, dtype=torch.long, device=dev), "obj_lens": None})
     pix, polar = ops.pixel_scale(cfg.grid_hw, dev), bevpos_polar(cfg.bev_dim, dev)
     t_book = [0.0]
+    runner = NavGraphRunner(model) if a.mode == "infer" else None
+    use_graphs = [runner is not None and not a.no_graphs]
 
     trace = []
 
@@ -95,7 +101,7 @@ def main():
                 gm.update_graph(obs, ended_all[t - 1])
             gm.set_step_ids(obs, t, ended)
             t_book[0] += time.perf_counter() - h0
-            pe, pm = model("panorama", pano[t])
+            pe, pm = runner.panorama(pano[t]) if use_graphs[0] else model("panorama", pano[t])
             avg = (pe * pm[..., None]).sum(1) / pm.sum(1, keepdim=True)                       # agent.py:478-479
             h0 = time.perf_counter()
             gm.update_node_embeds(obs, [[c["viewpointId"] for c in ob["candidate"]] for ob in obs], avg, pe, ended)
@@ -112,7 +118,7 @@ def main():
                 "bev_masks": torch.ones(B, K, dtype=torch.bool, device=dev), "bev_nav_masks": bi["bev_nav_masks"],
                 "bev_cand_idxs": bi["bev_cand_idxs"], "bev_cand_vpids": bi["bev_cand_vpids"], "obj_embeds": None,
                 "obj_masks": None})
-            out = model("navigation", nav)
+            out = runner.navigation(nav) if use_graphs[0] else model("navigation", nav)
             if a.check:
                 trace.append(out["fused_logits"].float().clone())
             if a.mode == "train":       # teacher action: [stop] is always a valid target of the fused logits
@@ -146,8 +152,41 @@ def main():
             assert bool(torch.isfinite(x.max(1).values[live]).all()), t          # a live sample can always act ([stop])
             fin = torch.isfinite(x)
             assert torch.equal(fin, torch.isfinite(y)) and float((x[fin] - y[fin]).abs().max()) <= 1e-6 * max(1.0, float(x[fin].abs().max())), t
-        print(json.dumps({"check": "ok", "batch": B, "steps": T, "dtype": a.dtype,
-                          "map_nodes_last_step": int(runs[0][-1].shape[1])}))
+        rec = {"check": "ok", "batch": B, "steps": T, "dtype": a.dtype, "map_nodes_last_step": int(runs[0][-1].shape[1])}
+        if use_graphs[0]:
+            # the captured steps against the eager forwards on the same inputs: node / candidate padding and the static
+            # buffers must not change which actions are possible, nor the logits beyond the rounding of differently
+            # shaped GEMMs.  Four rollouts, so that every bucket has passed its eager uses and is replayed.
+            for k in range(3):
+                trace.clear()
+                iteration(7)
+            torch.cuda.synchronize()
+            graphed = [t.cpu() for t in trace]
+            assert runner.graph_error is None, runner.graph_error
+            assert runner.captured_graphs() >= 2 and runner.stats["replays"] > 0, runner.stats
+            use_graphs[0] = False
+            trace.clear()
+            iteration(7)
+            torch.cuda.synchronize()
+            eager = [t.cpu() for t in trace]
+            tol = 3e-2 if a.dtype == "bf16" else 1e-4
+            worst = 0.0
+            for t in range(T):
+                x, y = graphed[t], eager[t]
+                assert x.shape == y.shape, (t, x.shape, y.shape)
+                fin = torch.isfinite(y)
+                assert torch.equal(torch.isfinite(x), fin), t
+                worst = max(worst, float((x[fin] - y[fin]).abs().max()) / max(1.0, float(y[fin].abs().max())))
+                live = torch.from_numpy(~ended_all[t])
+                same = (x.argmax(1) == y.argmax(1)) | ~live
+                # an argmax may flip only between logits that are closer than the tolerance
+                flip = (~same).nonzero().flatten().tolist()
+                for i in flip:
+                    assert abs(float(y[i].max() - y[i, x[i].argmax()])) <= tol * max(1.0, float(y[i][fin[i]].abs().max())), (t, i)
+            assert worst <= tol, worst
+            rec.update({"graphs_vs_eager_max_rel_diff": round(worst, 5), "captured_graphs": runner.captured_graphs(),
+                        "runner": runner.stats})
+        print(json.dumps(rec))
         return
     for i in range(a.warmup):
         iteration(i)
@@ -162,7 +201,11 @@ def main():
                                   f"GraphMapBatch + resident grid-feature store ({store.nbytes() / 2 ** 30:.1f} GiB)",
                       "ms_per_episode_batch": round(dt * 1e3, 2), "ms_per_nav_step": round(dt * 1e3 / T, 2),
                       "episodes_per_s": round(B / dt, 1), "nav_steps_per_s": round(B * T / dt, 1),
-                      "host_map_bookkeeping_ms_per_nav_step": round(t_book[0] / a.iters / T * 1e3, 2)}))
+                      "host_map_bookkeeping_ms_per_nav_step": round(t_book[0] / a.iters / T * 1e3, 2),
+                      "step_launch": ("hipGraph replay per mode and shape bucket (%d graphs, %d replays, %d eager calls)"
+                                      % (runner.captured_graphs(), runner.stats["replays"], runner.stats["eager"]))
+                      if use_graphs[0] else "eager",
+                      "graph_error": runner.graph_error if runner is not None else None}))
 
 
 if __name__ == "__main__":

@@ -764,7 +764,10 @@ def test_grid_feature_cache_to_resident_store_to_static_batch(env, tmp_path):
 def test_finetune_rollout_full_size_properties(env):
     """BASELINE.json configs[4] at its real size: batch 32, 15 navigation steps (scripts/ft_r2r.bash:37
     --max_action_len 15), bf16, the whole per-step chain (panorama encoder, map bookkeeping, lift + splat out of the
-    resident store, navigation mode).  Size-independent checks run by scripts/bench_nav.py --check."""
+    resident store, navigation mode).  Size-independent checks run by scripts/bench_nav.py --check, which also
+    compares the captured navigation steps (nav_static.NavGraphRunner: node / candidate axes padded to shape buckets,
+    static buffers, hipGraph replay) with the eager forwards on the same observations."""
+    import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -772,6 +775,28 @@ def test_finetune_rollout_full_size_properties(env):
                         "--check"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     assert '"check": "ok"' in p.stdout, p.stdout[-500:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["captured_graphs"] >= 2 and rec["runner"]["replays"] > 0, rec
+    assert rec["graphs_vs_eager_max_rel_diff"] <= 3e-2, rec
+
+
+def test_host_feed_ships_a_step_of_host_arrays_in_one_copy(env):
+    """graph_map.HostFeed: arrays of mixed dtype / shape (empty ones included) packed into a pinned ring slot, one
+    non-blocking copy, typed device views -- equal to the per-array copies, also when the ring wraps around."""
+    from vln_bevbert_amd.graph_map import HostFeed
+    feed = HostFeed(DEV, slots=3)
+    rng = np.random.default_rng(0)
+    for it in range(8):
+        n = 3 + it
+        arrays = {"i64": rng.integers(-5, 5, (n, 7)), "f32": rng.standard_normal((n, 3, 5)).astype(np.float32),
+                  "b": rng.random((n, 9)) < 0.5, "i32": rng.integers(0, 9, (n,)).astype(np.int32),
+                  "empty": np.zeros((0,), dtype=np.int64), "f64": rng.standard_normal((2, 4, 4)),
+                  "strided": np.arange(40, dtype=np.float32).reshape(5, 8)[:, ::2]}
+        out = feed(arrays)
+        for k, v in arrays.items():
+            want = torch.from_numpy(np.ascontiguousarray(v))
+            assert out[k].dtype == want.dtype and tuple(out[k].shape) == tuple(v.shape), k
+            assert torch.equal(out[k].cpu(), want), (it, k)
 
 
 def test_finetune_bev_from_store_rows_of_visited_neighbours(env):

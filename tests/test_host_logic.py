@@ -561,3 +561,16 @@ def test_bucket_manager_keeps_shape_buckets_lru_and_round_robins_buffer_sets():
     assert len(mgr.buckets) <= 2
     assert mgr.stats["buckets_created"] - mgr.stats["buckets_evicted"] == len(mgr.buckets)
     assert len(sigs) >= 1
+
+
+def test_host_feed_cpu_fallback_and_bucket_padding():
+    """graph_map.HostFeed on a CPU device is the plain per-array conversion (the packed pinned ring is for the GPU);
+    nav_static pads the node / candidate axes to multiples of the bucket step."""
+    from vln_bevbert_amd.graph_map import HostFeed
+    from vln_bevbert_amd.nav_static import _pad_to
+    arrays = {"a": np.arange(6, dtype=np.int64).reshape(2, 3)[:, ::2], "m": np.array([True, False]), "e": np.zeros((0, 4), np.float32)}
+    out = HostFeed("cpu")(arrays)
+    for k, v in arrays.items():
+        assert torch.equal(out[k], torch.from_numpy(np.ascontiguousarray(v))), k
+    assert HostFeed.shared("cpu") is HostFeed.shared("cpu")
+    assert [_pad_to(n, 8) for n in (1, 2, 8, 9, 16, 17)] == [8, 8, 8, 16, 16, 24]

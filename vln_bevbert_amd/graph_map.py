@@ -53,6 +53,64 @@ def angle_fts(headings, elevations, angle_feat_size=4):
     return np.concatenate([f] * (angle_feat_size // 4), 1) if angle_feat_size // 4 > 1 else f
 
 
+class HostFeed:
+    """One host -> device copy per call instead of one per array.
+
+    ``torch.from_numpy(a).to(device)`` from pageable memory is a blocking copy ordered behind everything already queued
+    on the stream: with ~20 small arrays per navigation step the host ends up waiting for the GPU twenty times a step.
+    Here the arrays of a call are packed (16-byte aligned) into a slot of a small ring of PINNED buffers and shipped
+    with a single non-blocking copy; the results are typed views of one device buffer.  A slot is reused only after the
+    copy that read it has completed (event), i.e. the host can run ``slots`` calls ahead of the GPU."""
+
+    def __init__(self, device, slots=8):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.ring = [{"buf": None, "ev": None} for _ in range(slots)]
+        self.i = 0
+
+    _shared = {}
+
+    @classmethod
+    def shared(cls, device):
+        """One ring per device for the whole process: a GraphMapBatch lives for one episode batch, and pinning memory
+        costs ~10 ms per buffer."""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        f = cls._shared.get(device)
+        if f is None:
+            f = cls._shared[device] = cls(device)
+        return f
+
+    def __call__(self, arrays):
+        if not self.cuda:
+            return {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in arrays.items()}
+        arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+        offs, total = {}, 0
+        for k, v in arrays.items():
+            offs[k] = total
+            total += (v.nbytes + 15) // 16 * 16
+        total = max(total, 16)
+        slot = self.ring[self.i]
+        self.i = (self.i + 1) % len(self.ring)
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        if slot["buf"] is None or slot["buf"].numel() < total:
+            slot["buf"] = torch.empty(max(2 * total, 1 << 20), dtype=torch.uint8).pin_memory()
+        host = slot["buf"].numpy()
+        for k, v in arrays.items():
+            host[offs[k]:offs[k] + v.nbytes] = v.reshape(-1).view(np.uint8)
+        devbuf = torch.empty(total, dtype=torch.uint8, device=self.device)
+        devbuf.copy_(slot["buf"][:total], non_blocking=True)
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record(torch.cuda.current_stream(self.device))
+        out = {}
+        for k, v in arrays.items():
+            tdt = torch.from_numpy(np.empty(0, dtype=v.dtype)).dtype
+            out[k] = devbuf[offs[k]:offs[k] + v.nbytes].view(tdt).view(v.shape)
+        return out
+
+
 class FloydGraph:
     """graph_utils.py:44-94 on dense matrices.  Nodes are registered on their first edge (like the reference's
     defaultdict keys) and keep their insertion order."""
@@ -185,6 +243,10 @@ class GraphMapBatch:
         self._alloc(node_capacity)
         self._hops = None               # hop counts of the current graphs (rebuilt after update_graph)
 
+    @property
+    def feed(self):
+        return HostFeed.shared(self.device)
+
     def _alloc(self, ncap):
         B, old = self.B, self.ncap
         pos = np.zeros((B, ncap, 3))
@@ -298,12 +360,14 @@ class GraphMapBatch:
         if not rb:
             return
         dev = self.device
-        t = lambda v: torch.tensor(v, dtype=torch.long, device=dev)
-        rb_t, rs_t = t(rb), t(rs)
+        ix = self.feed({"rb": np.asarray(rb, dtype=np.int64), "rs": np.asarray(rs, dtype=np.int64),
+                        "ab": np.asarray(ab, dtype=np.int64), "as": np.asarray(as_, dtype=np.int64),
+                        "aj": np.asarray(aj, dtype=np.int64)})
+        rb_t, rs_t = ix["rb"], ix["rs"]
         self.embed_sum = self.embed_sum.index_put((rb_t, rs_t), avg_pano_embeds[rb_t].to(self.dtype))
         self.embed_cnt = self.embed_cnt.index_put((rb_t, rs_t), torch.ones(len(rb), device=dev))
         if ab:
-            ab_t, as_t, aj_t = t(ab), t(as_), t(aj)
+            ab_t, as_t, aj_t = ix["ab"], ix["as"], ix["aj"]
             self.embed_sum = self.embed_sum.index_put((ab_t, as_t), pano_embeds[ab_t, aj_t].to(self.dtype),
                                                       accumulate=True)
             self.embed_cnt = self.embed_cnt.index_put((ab_t, as_t), torch.ones(len(ab), device=dev), accumulate=True)
@@ -408,7 +472,9 @@ class GraphMapBatch:
             names = self.eps[b].names
             vpids.append([None] + [names[k] for k in node[b, :cnt[b]]])
         dev = self.device
-        slot_t = torch.from_numpy(slot_np).to(dev)
+        up = self.feed({"slot": slot_np, "step_ids": step_ids, "pos": pos, "visited": visited, "pair": pair_np,
+                        "masks": masks})
+        slot_t = up["slot"]
         ok = slot_t >= 0
         bt = torch.arange(B, device=dev)[:, None].expand(-1, G)
         si = slot_t.clamp(min=0)
@@ -416,12 +482,12 @@ class GraphMapBatch:
         embeds = (self.embed_sum[bt, si] / c[..., None]) * ok[..., None].to(self.dtype)    # [stop] / padding = 0
         return {
             "gmap_vpids": vpids, "gmap_img_embeds": embeds,
-            "gmap_step_ids": torch.from_numpy(step_ids).to(dev),
-            "gmap_pos_fts": torch.from_numpy(pos).to(dev),
-            "gmap_visited_masks": torch.from_numpy(visited).to(dev),
+            "gmap_step_ids": up["step_ids"],
+            "gmap_pos_fts": up["pos"],
+            "gmap_visited_masks": up["visited"],
             "gmap_visited_masks_cpu": torch.from_numpy(visited),
-            "gmap_pair_dists": torch.from_numpy(pair_np).to(dev),
-            "gmap_masks": torch.from_numpy(masks).to(dev),
+            "gmap_pair_dists": up["pair"],
+            "gmap_masks": up["masks"],
             "no_vp_left": [bool(x) for x in (n - nvis) == 0],
         }
 
@@ -469,10 +535,6 @@ class GraphMapBatch:
                 rows[i, r], T_c2w[i, r] = pc[vp]
             live[i, :len(ns)] = True
             rows[i, len(ns):] = rows[i, 0]
-        dev = self.device
-        rows_t = torch.from_numpy(rows).to(dev)
-        depths = store.depths.index_select(0, rows_t.reshape(-1).long()).reshape(B, R * V, store.hw, store.hw)
-        depths = depths * torch.from_numpy(live).to(dev).repeat_interleave(V, 1)[..., None, None]   # padding: no depth
         P = np.asarray([ob["position"] for ob in obs], dtype=np.float32)
         S = np.stack([P[:, 0], P[:, 2], -P[:, 1]], 1)
         xyzhe = np.zeros((B, 5))
@@ -492,11 +554,16 @@ class GraphMapBatch:
         start = np.asarray([self.eps[b].index[self.eps[b].start_vp] for b in range(B)])
         gpos = self._pos_fts_rows(ar, cur, start, np.asarray([ob["heading"] for ob in obs], dtype=np.float64),
                                   np.asarray([ob["elevation"] for ob in obs], dtype=np.float64), 4)
+        up = self.feed({"rows": rows, "live": live, "T_c2w": T_c2w.reshape(B, R * V, 4, 4), "T_w2c": pose_matrix(xyzhe),
+                        "S": S, "nav_masks": nav_masks, "cand": cand_np, "gpos": gpos})
+        rows_t = up["rows"]
+        depths = store.depths.index_select(0, rows_t.reshape(-1).long()).reshape(B, R * V, store.hw, store.hw)
+        depths = depths * up["live"].repeat_interleave(V, 1)[..., None, None]                        # padding: no depth
         return {
-            "grid_rows": rows_t, "depths": depths, "T_c2w": torch.from_numpy(T_c2w.reshape(B, R * V, 4, 4)).to(dev),
-            "T_w2c": torch.from_numpy(pose_matrix(xyzhe)).to(dev)[:, None], "S_w2c": torch.from_numpy(S).to(dev)[:, None],
-            "bev_nav_masks": torch.from_numpy(nav_masks).to(dev), "bev_cand_idxs": torch.from_numpy(cand_np).to(dev),
-            "bev_cand_vpids": cand_vpids, "bev_gpos_fts": torch.from_numpy(gpos).to(dev)[:, None],
+            "grid_rows": rows_t, "depths": depths, "T_c2w": up["T_c2w"],
+            "T_w2c": up["T_w2c"][:, None], "S_w2c": up["S"][:, None],
+            "bev_nav_masks": up["nav_masks"], "bev_cand_idxs": up["cand"],
+            "bev_cand_vpids": cand_vpids, "bev_gpos_fts": up["gpos"][:, None],
         }
 
     @staticmethod
