@@ -423,12 +423,14 @@ def test_attention_fwd_bwd(ops, case, impl, dtype):
 
 @pytest.mark.parametrize("Lq,Lk,mk", [(80, 80, "neg"), (441, 80, "neg"), (17, 80, "inf"), (80, 17, "neg"), (36, 36, "inf"),
                                        (100, 96, None), (33, 5, None), (70, 49, "neg")])
-def test_attention_short_key_kernels_with_dropout(ops, Lq, Lk, mk, monkeypatch):
+@pytest.mark.parametrize("small_fwd", ["1", "0"])
+def test_attention_short_key_kernels_with_dropout(ops, Lq, Lk, mk, small_fwd, monkeypatch):
     """attn_small.hip (Lk <= 96, no graph bias): forward (inline hash, one tile set) and the one-wave backward, which
     reads the keep bits the forward left, against the fp32 reference under the exported mask -- every key-tile count
-    the launcher instantiates (2, 3, 5, 6) and query counts with partial tiles / partial 32-query chunks.  The kernels
-    are opt-in (they measured no faster than the tiled ones, capi.hip); the library reads the switch per call."""
-    monkeypatch.setenv("BEVBERT_ATTN_SMALL", "1")
+    the launcher instantiates (2, 3, 5, 6) and query counts with partial tiles / partial 32-query chunks.  The forward
+    and the one-wave backward are opt-in (they measured no faster than the tiled ones, capi.hip; the library reads the
+    switch per call); with queries AND keys up to 96 the backward is the independent-waves kernel either way."""
+    monkeypatch.setenv("BEVBERT_ATTN_SMALL", small_fwd)     # "0": tiled forward (keep bits from either) + new backward
     B, p, dtype = 3, 0.1, torch.bfloat16
     q, k, v, km, _, nh = _make_attn_inputs(B, Lq, Lk, mk, False, dtype, seed=Lq + Lk)
     ops.RT.new_step(1234 + Lk)

@@ -375,6 +375,194 @@ __global__ __launch_bounds__(64, 1) void attn_small_bwd_kernel(AttnArgs a) {
 }
 
 // =============================================================================================
+// Backward for SHORT query AND key sequences (Lq, Lk <= 96): waves that never talk to each other.
+//
+// One workgroup per (batch, head); K, Q, dO (row-major), lse and delta = rowsum(dO * O) are staged in LDS once, ONE
+// barrier, and from there on every wave works alone on data nobody writes:
+//   * query-owner waves (one per 16-query tile): S^T = K Q^T and dP^T = V dO^T (lane <-> query, registers <-> keys, the
+//     forward's orientation) -> dS^T, which IS the B operand of dQ^T = K^T dS^T (K^T by transposing reads) -> store dQ;
+//   * key-owner waves (one per 16-key tile): S = Q K^T and dP = dO V^T (lane <-> key, registers <-> queries) -> P and dS,
+//     which ARE the B operands of dV^T += dO^T P and dK^T += Q^T dS (Q^T / dO^T by transposing reads) -> store dK, dV.
+// The scores are computed twice (7 tile products instead of 5) -- the price of 10 independent waves per (batch, head)
+// for an 80 x 80 problem where the single-pass kernel has 4 waves and 4 barriers per 64-query tile.
+// =============================================================================================
+typedef const __attribute__((address_space(4))) uint64_t* sm_cu64p;   // uniform loads through the scalar cache
+
+#define SM2_ROWS 96
+
+template <int NKT, bool DROP, bool KMASK>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(5))) void attn_small_bwd2_kernel(AttnArgs a) {
+  constexpr int NC = (NKT + 1) / 2;
+  __shared__ __attribute__((aligned(16))) bf16_raw s_k[SM2_ROWS * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_q[SM2_ROWS * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_do[SM2_ROWS * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_v[16 * NKT * LDT];
+  __shared__ __attribute__((aligned(16))) float s_lse2[SM2_ROWS];
+  __shared__ __attribute__((aligned(16))) float s_dlt[SM2_ROWS];
+  __shared__ __attribute__((aligned(16))) float s_mk[SM2_ROWS];      // additive key mask, log2 domain; -inf beyond Lk
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqt = (a.Lq + 15) >> 4;                  // query-owner waves 0 .. nqt-1, key-owner waves nqt ..
+  int blk, h, b;
+  attn_decode_block(a, blk, h, b);
+  const int bh = b * a.nh + h;
+  const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
+  const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
+  const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
+  const bf16_raw* op = (const bf16_raw*)a.o + (size_t)b * a.bso + h * ATTN_D;
+  const bf16_raw* dop = (const bf16_raw*)a.dout + (size_t)b * a.bso + h * ATTN_D;
+  const float sc2 = a.scale * LOG2E;
+  const float ks = DROP ? a.keep_scale : 1.0f;
+
+  // ---- staging (all waves): rows beyond Lq / Lk are zero, their lse is +inf (P = 0), their delta 0
+  for (int ci = tid; ci < SM2_ROWS * 8; ci += blockDim.x) {
+    const int row = ci >> 3, ch = ci & 7;
+    uint4 kv = make_uint4(0, 0, 0, 0), qv = kv, dv = kv, ov = kv, vv = kv;
+    if (row < a.Lk) {
+      kv = ld_frag_global(kp, a.ldk, row, ch * 8);
+      vv = ld_frag_global(vp, a.ldv, row, ch * 8);
+    }
+    if (row < 16 * NKT) *reinterpret_cast<uint4*>(s_v + row * LDT + ch * 8) = vv;
+    if (row < a.Lq) {
+      qv = ld_frag_global(qp, a.ldq, row, ch * 8);
+      dv = ld_frag_global(dop, a.ldo, row, ch * 8);
+      ov = ld_frag_global(op, a.ldo, row, ch * 8);
+    }
+    *reinterpret_cast<uint4*>(s_k + row * LDT + ch * 8) = kv;
+    *reinterpret_cast<uint4*>(s_q + row * LDT + ch * 8) = qv;
+    *reinterpret_cast<uint4*>(s_do + row * LDT + ch * 8) = dv;
+    const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+    float dsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      dsum += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16) +
+              __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+    dsum = sm_sum8(dsum);
+    if ((lane & 7) == 0) s_dlt[row] = dsum;
+  }
+  if (tid < SM2_ROWS) {
+    s_lse2[tid] = tid < a.Lq ? a.lse[(size_t)bh * a.Lq + tid] * LOG2E : INFINITY;
+    float m = -INFINITY;
+    if (tid < a.Lk) m = KMASK ? a.key_mask[(size_t)b * a.Lk + tid] * LOG2E : 0.f;
+    s_mk[tid] = m;
+  }
+
+  if (w < nqt) {
+    // =================================================================== query-owner wave: tile qt = w -> dQ
+    const int qt = w;
+    sm_cu64p wq = nullptr;
+    if (DROP) wq = (sm_cu64p)(uintptr_t)(a.drop_bits + attn_bits_word(a, bh, qt, 0, 0, 0));
+    __syncthreads();
+    const bf16x8 qb0 = lds_frag_rows(s_q, qt, 0, lane), qb1 = lds_frag_rows(s_q, qt, 1, lane);
+    const bf16x8 db0 = lds_frag_rows(s_do, qt, 0, lane), db1 = lds_frag_rows(s_do, qt, 1, lane);
+    const float lse2 = s_lse2[qt * 16 + c], dlt = s_dlt[qt * 16 + c];
+    f32x4 ds[NKT];
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      f32x4 s = mfma16(lds_frag_rows(s_k, t, 0, lane), qb0, zero);
+      s = mfma16(lds_frag_rows(s_k, t, 1, lane), qb1, s);
+      f32x4 dp = mfma16(lds_frag_rows(s_v, t, 0, lane), db0, zero);
+      dp = mfma16(lds_frag_rows(s_v, t, 1, lane), db1, dp);
+      const float4 m4 = *reinterpret_cast<const float4*>(s_mk + 16 * t + 4 * g);
+      const float mk[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = fast_exp2(fmaf(s[r], sc2, mk[r] - lse2));
+        float dpd = dp[r] * ks;
+        if (DROP) {
+          const uint64_t word = (t * 16 < a.Lk) ? wq[(t >> 2) * 16 + (t & 3) * 4 + r] : 0ull;
+          dpd = __builtin_amdgcn_inverse_ballot_w64(word) ? dpd : 0.f;
+        }
+        ds[t][r] = p * (dpd - dlt);
+      }
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = zero;
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+      const bf16x8 dsb = pack_pair(ds[2 * m], (2 * m + 1 < NKT) ? ds[(2 * m + 1 < NKT) ? 2 * m + 1 : 0] : zero);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        dq[dt] = mfma16(lds_frag_tr(s_k, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane), dsb, dq[dt]);
+    }
+    const int qrow = qt * 16 + c;
+    if (qrow < a.Lq) {
+      bf16_raw* dqp = (bf16_raw*)a.dq + (size_t)b * a.bsq + (size_t)qrow * a.ldq + h * ATTN_D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        st4<bf16_raw>(dqp + dt * 16 + g * 4, make_float4(dq[dt][0] * a.scale, dq[dt][1] * a.scale,
+                                                          dq[dt][2] * a.scale, dq[dt][3] * a.scale));
+    }
+  } else {
+    // =================================================================== key-owner wave: tile t = w - nqt -> dK, dV
+    const int t = w - nqt;
+    const int key = t * 16 + c;
+    uint64_t bw[DROP ? 6 : 1];                         // keep bits of (query tile, this key tile): one word per lane and tile
+    if (DROP) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        bw[j] = (j < nqt) ? a.drop_bits[attn_bits_word(a, bh, j, t >> 2, t & 3, c & 3)] : 0ull;
+    }
+    __syncthreads();
+    const bf16x8 kb0 = lds_frag_rows(s_k, t, 0, lane), kb1 = lds_frag_rows(s_k, t, 1, lane);
+    const bf16x8 vb0 = lds_frag_rows(s_v, t, 0, lane), vb1 = lds_frag_rows(s_v, t, 1, lane);
+    const float mk2 = s_mk[key];
+    f32x4 dk[4], dv[4];
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = zero;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {                      // 32-query chunks
+      if (m * 32 < a.Lq) {
+        uint2 pp[2], pds[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int qt = 2 * m + j;
+          f32x4 s = mfma16(lds_frag_rows(s_q, qt, 0, lane), kb0, zero);
+          s = mfma16(lds_frag_rows(s_q, qt, 1, lane), kb1, s);
+          f32x4 dp = mfma16(lds_frag_rows(s_do, qt, 0, lane), vb0, zero);
+          dp = mfma16(lds_frag_rows(s_do, qt, 1, lane), vb1, dp);
+          const float4 l4 = *reinterpret_cast<const float4*>(s_lse2 + 16 * qt + 4 * g);
+          const float4 d4 = *reinterpret_cast<const float4*>(s_dlt + 16 * qt + 4 * g);
+          const float lrow[4] = {l4.x, l4.y, l4.z, l4.w}, drow[4] = {d4.x, d4.y, d4.z, d4.w};
+          uint32_t kbits = 0xfu;
+          if (DROP) kbits = (uint32_t)(bw[qt] >> (16 * (c >> 2) + 4 * g));
+          f32x4 pd, dsv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fast_exp2(fmaf(s[r], sc2, mk2 - lrow[r]));
+            const bool keep = !DROP || ((kbits >> r) & 1u);
+            pd[r] = keep ? p * ks : 0.f;
+            const float dpd = keep ? dp[r] * ks : 0.f;
+            dsv[r] = p * (dpd - drow[r]);
+          }
+          pp[j] = pack4(pd);
+          pds[j] = pack4(dsv);
+        }
+        const bf16x8 pb = join_pair(pp[0], pp[1]), dsb = join_pair(pds[0], pds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = mfma16(lds_frag_tr(s_do, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane), pb, dv[dt]);
+          dk[dt] = mfma16(lds_frag_tr(s_q, LDT, 32 * m + 4 * g, 32 * m + 16 + 4 * g, dt * 16, lane), dsb, dk[dt]);
+        }
+      }
+    }
+    if (key < a.Lk) {
+      bf16_raw* dkp = (bf16_raw*)a.dk + (size_t)b * a.bsk + (size_t)key * a.ldk + h * ATTN_D;
+      bf16_raw* dvp = (bf16_raw*)a.dv + (size_t)b * a.bsv + (size_t)key * a.ldv + h * ATTN_D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        st4<bf16_raw>(dkp + dt * 16 + g * 4, make_float4(dk[dt][0] * a.scale, dk[dt][1] * a.scale, dk[dt][2] * a.scale,
+                                                          dk[dt][3] * a.scale));
+        st4<bf16_raw>(dvp + dt * 16 + g * 4, make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]));
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // Host side
 // =============================================================================================
 static bool sm_aligned(const AttnArgs& a) {
@@ -431,6 +619,31 @@ int attn_small_fwd(const AttnArgs& a_in, hipStream_t st) {
   else if (nkt <= 5) launch_fwd<5>(a, grid, block, qpw, st);
   else launch_fwd<6>(a, grid, block, qpw, st);
   BB_CHECK_LAUNCH("attn_fwd(small)");
+  return BB_OK;
+}
+
+template <int NKT>
+static void launch_bwd2(const AttnArgs& a, dim3 grid, dim3 block, hipStream_t st) {
+  const bool hd = a.drop_p > 0.f, hm = a.key_mask != nullptr;
+  if (hd && hm) hipLaunchKernelGGL((attn_small_bwd2_kernel<NKT, true, true>), grid, block, 0, st, a);
+  else if (hd) hipLaunchKernelGGL((attn_small_bwd2_kernel<NKT, true, false>), grid, block, 0, st, a);
+  else if (hm) hipLaunchKernelGGL((attn_small_bwd2_kernel<NKT, false, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((attn_small_bwd2_kernel<NKT, false, false>), grid, block, 0, st, a);
+}
+
+// query AND key sequences up to 96: independent query-owner and key-owner waves (attn_small_bwd2_kernel)
+bool attn_small_bwd2_supported(const AttnArgs& a) { return attn_small_bwd_supported(a) && a.Lq <= SM2_ROWS; }
+
+int attn_small_bwd2(const AttnArgs& a_in, hipStream_t st) {
+  AttnArgs a = a_in;
+  const int nkt = (a.Lk + 15) / 16, nqt = (a.Lq + 15) / 16;
+  a.nblk = 1;
+  const dim3 grid((unsigned)a.nh * a.B), block(64 * (nqt + nkt));
+  if (nkt <= 2) launch_bwd2<2>(a, grid, block, st);
+  else if (nkt <= 3) launch_bwd2<3>(a, grid, block, st);
+  else if (nkt <= 5) launch_bwd2<5>(a, grid, block, st);
+  else launch_bwd2<6>(a, grid, block, st);
+  BB_CHECK_LAUNCH("attn_bwd(small, independent waves)");
   return BB_OK;
 }
 

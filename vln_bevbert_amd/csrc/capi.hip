@@ -40,6 +40,8 @@ int attn_small_fwd(const AttnArgs& a, hipStream_t st);
 bool attn_small_fwd_supported(const AttnArgs& a);
 int attn_small_bwd(const AttnArgs& a, hipStream_t st);
 bool attn_small_bwd_supported(const AttnArgs& a);
+int attn_small_bwd2(const AttnArgs& a, hipStream_t st);
+bool attn_small_bwd2_supported(const AttnArgs& a);
 
 // The keep-bit workspace of a call holds the matrix twice: [forward layout | backward layout], see attn_fwd2.hip
 static int64_t bits_words_one(int B, int nh, int Lq, int Lk) {
@@ -49,6 +51,11 @@ static int64_t bits_words_one(int B, int nh, int Lq, int Lk) {
 static bool small_kernels_on() {
   const char* v = getenv("BEVBERT_ATTN_SMALL");
   return v && v[0] == '1';
+}
+
+static bool small_bwd2_on() {
+  const char* v = getenv("BEVBERT_ATTN_SMALL_BWD");
+  return !(v && v[0] == '0');
 }
 
 // impl: 0 = auto (bf16 -> MFMA, f32 -> exact), 1 = force exact kernels, 2 = force MFMA (bf16 only),
@@ -137,6 +144,9 @@ BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, co
     static const bool split = [] { const char* v = getenv("BEVBERT_ATTN_BWD"); return v && v[0] == 's'; }();
     // BEVBERT_ATTN_BWD=1: the round-2 single-pass kernel where the 7+1-wave kernel (attn_bwd2.hip) would run
     static const bool gen1 = [] { const char* v = getenv("BEVBERT_ATTN_BWD"); return v && v[0] == '1'; }();
+    // query and key sequences up to 96 (80 x 80 text, 36 x 36 panoramas, 17 x 80 / 80 x 17 map <-> text): independent
+    // query-owner / key-owner waves, attn_small.hip.  BEVBERT_ATTN_SMALL_BWD=0 keeps the single-pass kernel (A/B).
+    if (!split && !gen1 && im == 2 && small_bwd2_on() && attn_small_bwd2_supported(a)) return attn_small_bwd2(a, stream);
     if (!split && !gen1 && small_kernels_on() && im == 2 && attn_small_bwd_supported(a)) return attn_small_bwd(a, stream);
     if (!split && !gen1 && im == 2 && attn_bwd2_supported(a)) return attn_bwd2(a, stream);
     if (!split && im == 2 && attn_mfma_bwd1_supported(a)) return attn_mfma_bwd1(a, stream);
