@@ -313,9 +313,10 @@ class WgradStream:
             cls._next_event += 1
             ev.record(producer)
             target.wait_event(ev)
-        if final:        # the batched reductions read what every weight-gradient stream produced
-            for st in cls.streams[1:]:
+        if final:        # the batched reductions read what every weight-gradient stream produced, and the first
+            for st in cls.streams[1:]:      # stages of the queued column reductions, wherever those were launched
                 target.wait_stream(st)
+            ReduceQueue.wait_producers(target)
         lib.set_stream_override(target.cuda_stream)
         cls._target = target
         cls.dirty = True
@@ -345,12 +346,20 @@ class WgradStream:
                         cls._flush(other)
                 cls._flush(mine, final=True)
                 return
+            ReduceQueue.wait_producers(torch.cuda.current_stream(dev))
             ReduceQueue.flush(dev)
         for slot in cls._pending.values():
             cls._flush(slot)
 
     @classmethod
     def release(cls):
+        cls._keep.clear()
+
+    @classmethod
+    def drop_pending(cls):
+        """Forget deferred closures of an aborted step (failed graph capture) instead of running them later."""
+        for _, fns in cls._pending.values():
+            fns.clear()
         cls._keep.clear()
 
 
@@ -360,24 +369,43 @@ class ScratchRing:
     allocations), which is what lets ReduceQueue keep its task tables -- they hold raw pointers -- in device memory
     instead of rebuilding and re-uploading them every step.  Wraps around when full (capacity >> one step's needs)."""
 
+    INITIAL = 256 << 20
+
     def __init__(self, nbytes=1 << 30):
-        self.nbytes = nbytes
+        self.nbytes = nbytes            # cap (BEVBERT_SCRATCH_MB)
+        self.size = 0                   # bytes allocated so far: the ring GROWS to what a step needs, up to the cap
         self.buf = None
         self.base = 0
         self.off = 0
+        self._old = []                  # outgrown buffers are NEVER freed: queued records of the running step and steps
+        #                                 captured before the growth (another task's hipGraph) keep pointing into them
 
     def reset(self):
         self.off = 0
 
     def alloc(self, nbytes, device):
-        if self.buf is None:
-            self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
-            self.base = self.buf.data_ptr()
         n = (int(nbytes) + 255) & ~255
         if n > self.nbytes:
             raise lib.BevBertHipError(f"scratch ring: {n} bytes requested, capacity {self.nbytes}")
-        if self.off + n > self.nbytes:
-            self.off = 0
+        if self.off + n > self.size:
+            if self.size < self.nbytes:
+                # grow (warm-up steps): a new, larger buffer; from the next reset on every allocation of the step lives
+                # in it, so the addresses repeat again -- which the cached task tables and captured steps rely on
+                if torch.cuda.is_current_stream_capturing():
+                    raise lib.BevBertHipError("scratch ring would have to grow during graph capture: run one more "
+                                              "eager step first, or start larger (BEVBERT_SCRATCH_INITIAL_MB)")
+                new = min(self.nbytes, max(2 * self.size, self.off + n, self.INITIAL))
+                if self.buf is not None:
+                    self._old.append(self.buf)
+                self.buf = torch.empty(new, dtype=torch.uint8, device=device)
+                self.base, self.size, self.off = self.buf.data_ptr(), new, 0
+            else:
+                # at the cap: wrap around -- only legal when nothing queued still points into the ring
+                if ReduceQueue.jobs or ReduceQueue.accum_jobs:
+                    raise lib.BevBertHipError(
+                        f"scratch ring ({self.nbytes >> 20} MB) is full while reductions of this step are still queued: "
+                        "their partial sums would be overwritten -- raise BEVBERT_SCRATCH_MB")
+                self.off = 0
         p = self.base + self.off
         self.off += n
         return p
@@ -391,6 +419,7 @@ class ScratchRing:
 
 
 SCRATCH = ScratchRing(int(_os.environ.get("BEVBERT_SCRATCH_MB", "6144")) << 20)      # ~2.5 GB / step at batch 64
+ScratchRing.INITIAL = int(_os.environ.get("BEVBERT_SCRATCH_INITIAL_MB", "256")) << 20
 
 
 class ReduceQueue:
@@ -403,15 +432,43 @@ class ReduceQueue:
 
     jobs = []
     accum_jobs = []
+    producers = {}       # raw stream handle -> torch stream on which first stages of pending records were launched
     _tables = {}
     _accum_tables = {}
     _dtype = None
     _adtype = None
 
     @classmethod
+    def _note_producer(cls):
+        """The first stage of the record being added was launched on the stream C-ABI launches go to right now (the
+        autograd stream, a branch stream, or the weight-gradient stream a deferred closure runs on).  The second
+        stage must wait for every such stream, whatever else happens to order them (a side-stream producer
+        whose deferred-work slot is empty would otherwise leave no dependency edge)."""
+        st = WgradStream._target
+        if st is None:
+            if not torch.cuda.is_available():
+                return
+            st = torch.cuda.current_stream()
+        cls.producers[st.cuda_stream] = st
+
+    @classmethod
+    def wait_producers(cls, consumer):
+        """Make ``consumer`` (a torch stream) wait for everything enqueued so far on the producing streams."""
+        for h, st in cls.producers.items():
+            if h != consumer.cuda_stream:
+                consumer.wait_stream(st)
+        cls.producers = {}
+
+    @classmethod
+    def drop_pending(cls):
+        """Forget the records of an aborted step (failed graph capture): they reference memory of a dead capture."""
+        cls.jobs, cls.accum_jobs, cls.producers = [], [], {}
+
+    @classmethod
     def add_accum(cls, partials_ptr, sink_ptr, S, n, dtype):
         """sink[0:n] += sum of the S partial slices at partials_ptr (split-K weight-gradient products)."""
         cls.accum_jobs.append((partials_ptr, sink_ptr, S, n, dtype))
+        cls._note_producer()
 
     @classmethod
     def _build_accum(cls, jobs, device):
@@ -438,6 +495,7 @@ class ReduceQueue:
     @classmethod
     def add(cls, partials_ptr, nblocks, nwhich, C, outs, accumulate=1):
         cls.jobs.append((partials_ptr, nblocks, nwhich, C, outs[0] or 0, outs[1] or 0, outs[2] or 0, accumulate))
+        cls._note_producer()
 
     @classmethod
     def _build(cls, jobs, device):

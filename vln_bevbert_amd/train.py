@@ -89,6 +89,10 @@ class GradReducer:
         self._done = []          # [lo, hi) regions already issued in this step
         self.timeline = None     # set to [] to collect (lo, hi, start event, end event) per region (bench.py's rccl block)
 
+    def drop_pending(self):
+        """Forget the collectives of an aborted step (failed graph capture): the step is issued again eagerly."""
+        self._works, self._done, self._phase_a_done = [], [], False
+
     def launch_region(self, lo, hi):
         """Reduce [lo, hi) now: every gradient in it has been enqueued (caller's guarantee).  Regions may be issued in
         any order; finish() covers whatever is left."""
@@ -377,6 +381,11 @@ class PretrainTrainer:
             warnings.warn(f"hipGraph capture of the {task} step failed, continuing with eager steps: {self.graph_error}")
             ops.Branches.enabled = branches
             torch.cuda.synchronize()
+            # host state the aborted capture left behind points into its dead memory pool: deferred weight-gradient
+            # closures, queued reduction records, collective work handles -- forget them, the step is redone eagerly
+            ops.WgradStream.drop_pending()
+            ops.ReduceQueue.drop_pending()
+            self.reducer.drop_pending()
             ops.RT.new_step(self._step_seed(), plan_key=self._plan_key(task, sb))
             loss = self._forward_backward(task, sb)
             self.optimizer_step(lr=None)
