@@ -6,8 +6,11 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless marked "host"; the caller owns all memory, nothing is allocated,
- *     retained or freed here; the only global state is bevbert_gemm's mutex-guarded plan cache (library handle +
- *     per-shape descriptors) => re-entrant, thread-safe per stream;
+ *     retained or freed here.  Process-wide state, all of it: (1) bevbert_gemm's mutex-guarded plan cache (library
+ *     handle + per-shape descriptors), (2) the step-salt POINTER registered by bevbert_set_step_salt (one per process:
+ *     two training loops in one process share the salt word -- their masks still differ through their seeds), (3) the
+ *     environment switches read by capi.hip (A/B knobs).  Entries may be called concurrently from several threads on
+ *     different streams; bevbert_set_step_salt must not race with launches;
  *   - `stream` is a hipStream_t (PyTorch-ROCm: torch.cuda.current_stream().cuda_stream); launches are asynchronous;
  *   - return value 0 = ok, <0 = error (-1 invalid argument, -2 launch failure, -3 unsupported); the message is
  *     available from bevbert_last_error() (thread-local);
