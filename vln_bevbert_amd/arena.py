@@ -162,6 +162,11 @@ class ParamArena:
     def _publish(self):
         self._cb_queued = False
         self.sync()
+        # end of a backward pass in a caller-owned loop (nobody calls arena.zero_grad there): every queued reduction has
+        # been issued and the current stream waits for the side streams, so the scratch ring may start over
+        if self.device.type == "cuda":
+            from . import ops
+            ops.SCRATCH.reset()
         if self.allreduce_group is not None and not self.defer_allreduce:
             import torch.distributed as dist
             dist.all_reduce(self.grads, group=self.allreduce_group)
