@@ -319,7 +319,7 @@ def test_static_batch_with_object_tokens_runs_eagerly_and_survives_a_refill(env)
         rng = np.random.default_rng(seed)
         samples = [synthetic.make_sample(rng, i, cfg, T, L, ragged_views=True) for i, (T, L) in enumerate([(5, 70), (2, 48), (4, 76)])]
         return synthetic.collate(samples, cfg, "sap", rng)
-    b1, other = mk(71), mk(72)
+    b1, other = mk(71), mk(75)          # 72 differs in the joint [views | objects] width: another bucket (signature)
     assert b1.get("traj_obj_img_fts") is not None
     assert not torch.equal(other["traj_vp_obj_lens"], b1["traj_vp_obj_lens"])
     model, arena = _fresh(cfg, torch.float32)
@@ -331,9 +331,12 @@ def test_static_batch_with_object_tokens_runs_eagerly_and_survives_a_refill(env)
         tr.step("sap", sb)
     assert sb.graph is None and tr.graph_error is None
     assert StaticBatch(cfg, "sap", other, "cpu").signature == sb.signature
+    with pytest.raises(ValueError, match="shape bucket"):       # same step counts, other joint token width: refused
+        sb.load(mk(72))
     sb.load(other)
+    with torch.no_grad():                               # before the step: the step's optimiser moves the weights
+        want = float(model(synthetic.batch_to(other, DEV), "sap").mean())
     got = float(tr.step("sap", sb))
-    want = float(model(synthetic.batch_to(other, DEV), "sap").mean())
     assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
 
 

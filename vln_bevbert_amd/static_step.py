@@ -106,7 +106,9 @@ class StaticBatch:
         static = {}
         sig = [task, B, tuple(batch["txt_ids"].shape), tuple(batch["traj_view_img_fts"].shape), G]
         if batch.get("traj_obj_img_fts") is not None:      # buffers of a bucket must agree on the object-token layout too
-            sig.append(("obj", tuple(batch["traj_obj_img_fts"].shape), tuple(int(x) for x in batch["traj_step_lens"])))
+            # (incl. the width of the joint [views | objects] token axis: the maximum of views + objects over the panoramas)
+            sig.append(("obj", tuple(batch["traj_obj_img_fts"].shape), tuple(int(x) for x in batch["traj_step_lens"]),
+                        int(n_views)))
         if task.startswith("mlm"):
             labels = batch["txt_labels"].reshape(-1)
             pos = torch.nonzero(labels != -1).squeeze(1)
