@@ -111,6 +111,13 @@ int bevbert_bias_dropout_residual_layernorm_fwd(const void* x, const float* bias
                                                 const float* gamma, const float* beta, void* y, void* z_out,
                                                 float* mean, float* rstd, int rows, int H, float eps, int dtype,
                                                 float drop_p, uint64_t seed, uint64_t offset, hipStream_t stream);
+/* y = LayerNorm(x + bias) + post1 + post2 (post terms optional, same dtype / shape as y, added in that order after the
+ * affine): the sums that follow a LayerNorm in the embedding compositions -- ImageEmbeddings (vilmodel.py:494-532:
+ * LN(img) + LN(loc) + nav_type ...) and bev_input_embedding (:589-593) -- ride on its store instead of being separate
+ * element-wise launches.  Backward: bevbert_layernorm_bwd with dy (the post terms receive dy unchanged). */
+int bevbert_layernorm_post_fwd(const void* x, const float* bias, const float* gamma, const float* beta,
+                               const void* post1, const void* post2, void* y, void* z_out, float* mean, float* rstd,
+                               int rows, int H, float eps, int dtype, hipStream_t stream);
 int bevbert_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                           void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, float* workspace, int rows,
                           int H, int dtype, float drop_p, uint64_t seed, uint64_t offset, int accumulate,

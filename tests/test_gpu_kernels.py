@@ -176,6 +176,39 @@ def test_layernorm_fwd_bwd(ops, dtype, with_res, p):
     assert rel_err(bias.grad, bias_r.grad) < gt
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("two", [True, False])
+def test_layernorm_with_post_terms_equals_the_separate_adds(ops, dtype, two):
+    """bevbert_layernorm_post_fwd: (LN(x + bias) + post1) + post2 in the LayerNorm's launch -- the embedding
+    compositions of vilmodel.py:494-532 / 589-593.  fp32: bit-equal to the separate element-wise adds (same order);
+    bf16: one rounding instead of three.  Gradients: the post terms receive dy, the rest is the plain LayerNorm's."""
+    rows, H = 333, 768
+    g0 = torch.Generator(device="cpu").manual_seed(3)
+    mk = lambda *s: torch.randn(*s, generator=g0).to(DEV)
+    x, p1, p2 = (mk(rows, H).to(dtype) for _ in range(3))
+    bias, gamma, beta = mk(H), mk(H), mk(H)
+    leaves = lambda: [t.clone().requires_grad_(True) for t in (x, bias, gamma, beta, p1, p2)]
+    a = leaves()
+    y = ops.bias_layernorm_plus(a[0].clone(), a[1], a[2], a[3], 1e-12, a[4], a[5] if two else None)
+    b = leaves()
+    ref = ops.bias_dropout_residual_layernorm(b[0].clone(), b[1], None, b[2], b[3], 1e-12) + b[4]
+    if two:
+        ref = ref + b[5]
+    if dtype == torch.float32:
+        assert torch.equal(y, ref)
+    else:
+        assert float((y.float() - ref.float()).abs().max()) <= 2 ** -6 * float(ref.float().abs().max())
+    dy = mk(rows, H).to(dtype)
+    y.backward(dy)
+    ref.backward(dy)
+    for i, name in enumerate(("x", "bias", "gamma", "beta", "post1", "post2")):
+        if name == "post2" and not two:
+            assert a[i].grad is None
+            continue
+        assert rel_err(a[i].grad, b[i].grad.float()) < (1e-6 if dtype == torch.float32 else 2e-2), name
+    assert torch.equal(a[4].grad, dy)
+
+
 @pytest.mark.parametrize("eps", [1e-12, 1e-5])
 def test_plain_layernorm_matches_torch(ops, eps):
     torch.manual_seed(1)

@@ -93,6 +93,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     o.y = (v[i].y - mean) * rstd * g.y + b.y;
     o.z = (v[i].z - mean) * rstd * g.z + b.z;
     o.w = (v[i].w - mean) * rstd * g.w + b.w;
+    if (!GATHER) {   // post-normalisation terms (bevbert_layernorm_post_fwd): y = LN(..) + post1 + post2, in that order --
+      // the GATHER-only pointers carry them, so the plain variant costs two null tests
+      if (word != nullptr) {
+        const float4 r = ld4<T>(word + (size_t)row * H + col);
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+      if (pos != nullptr) {
+        const float4 r = ld4<T>(pos + (size_t)row * H + col);
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+    }
     st4<T>(y + (size_t)row * H + col, o);
   }
 }
@@ -617,6 +628,30 @@ BEVBERT_API int bevbert_bias_dropout_residual_layernorm_fwd(const void* x, const
   }
   if (rc != BB_OK) return rc;
   BB_CHECK_LAUNCH("layernorm_fwd");
+  return BB_OK;
+}
+
+// y = LayerNorm(x + bias) + post1 + post2 (either may be NULL): the element-wise sums that follow a LayerNorm in the
+// embedding compositions (vilmodel.py:494-532 image embeddings, :589-593 BEV input embedding) ride on its store.
+BEVBERT_API int bevbert_layernorm_post_fwd(const void* x, const float* bias, const float* gamma, const float* beta,
+                                           const void* post1, const void* post2, void* y, void* z_out, float* mean,
+                                           float* rstd, int rows, int H, float eps, int dtype, hipStream_t stream) {
+  BB_REQUIRE(rows >= 0 && H % 256 == 0, "layernorm_post_fwd: H=%d must be a multiple of 256", H);
+  if (rows == 0) return BB_OK;
+  const dim3 grid((rows + 3) / 4);
+  int rc;
+  if (dtype == BB_F32)
+    rc = ln_fwd_dispatch<float, false>(H / 256, grid, stream, x, bias, nullptr, gamma, beta, y, z_out, mean, rstd, rows,
+                                       eps, 0.f, 0, 0, nullptr, post1, post2, nullptr, 1);
+  else if (dtype == BB_BF16)
+    rc = ln_fwd_dispatch<bf16_raw, false>(H / 256, grid, stream, x, bias, nullptr, gamma, beta, y, z_out, mean, rstd,
+                                          rows, eps, 0.f, 0, 0, nullptr, post1, post2, nullptr, 1);
+  else {
+    bb_set_error("layernorm_post_fwd: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  if (rc != BB_OK) return rc;
+  BB_CHECK_LAUNCH("layernorm_post_fwd");
   return BB_OK;
 }
 

@@ -911,7 +911,7 @@ def use_param(p):
 # ----------------------------------------------------------------------------- K3 LayerNorm family
 class _BiasDropResLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bias, residual, gamma, beta, eps, drop_p, inplace_z):
+    def forward(ctx, x, bias, residual, gamma, beta, eps, drop_p, inplace_z, post1=None, post2=None):
         assert x.is_contiguous() and x.dim() >= 2
         H = x.shape[-1]
         rows = x.numel() // H
@@ -924,12 +924,22 @@ class _BiasDropResLN(torch.autograd.Function):
         off = RT.next_offset(x.numel()) if drop_p > 0 else 0
         if residual is not None:
             assert residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype
-        call("bevbert_bias_dropout_residual_layernorm_fwd", ptr(x), ptr(_f32(bias)) if bias is not None else None,
-             ptr(residual), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(y), None if plain else ptr(z), ptr(mean), ptr(rstd),
-             rows, H, float(eps), dtype_code(x), float(drop_p), RT.seed, off, stream())
+        if post1 is not None or post2 is not None:
+            # y = LN(x + bias) + post1 + post2: the sums that follow the LayerNorm ride on its store (rowops.hip)
+            assert residual is None and drop_p == 0, "post terms: plain bias + LayerNorm only"
+            for t in (post1, post2):
+                assert t is None or (t.is_contiguous() and t.shape == x.shape and t.dtype == x.dtype)
+            call("bevbert_layernorm_post_fwd", ptr(x), ptr(_f32(bias)) if bias is not None else None, ptr(_f32(gamma)),
+                 ptr(_f32(beta)), ptr(post1), ptr(post2), ptr(y), None if plain else ptr(z), ptr(mean), ptr(rstd), rows,
+                 H, float(eps), dtype_code(x), stream())
+        else:
+            call("bevbert_bias_dropout_residual_layernorm_fwd", ptr(x), ptr(_f32(bias)) if bias is not None else None,
+                 ptr(residual), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(y), None if plain else ptr(z), ptr(mean),
+                 ptr(rstd), rows, H, float(eps), dtype_code(x), float(drop_p), RT.seed, off, stream())
         ctx.save_for_backward(z, mean, rstd)
         ctx.params = (bias, gamma, beta)
         ctx.cfg = (rows, H, float(drop_p), RT.seed, off, residual is not None)
+        ctx.posts = (post1 is not None, post2 is not None)
         return y
 
     @staticmethod
@@ -973,18 +983,27 @@ class _BiasDropResLN(torch.autograd.Function):
         gx = dx if dx is not None else dz
         gres = dz if has_res else None
         cast = lambda r, p: None if r is None else r.to(p.dtype)
-        return gx, cast(rbi, bias) if bias is not None else None, gres, cast(rg, gamma), cast(rb, beta), None, None, None
+        g1, g2 = (dy if has else None for has in ctx.posts)      # the post terms were added after the affine
+        return (gx, cast(rbi, bias) if bias is not None else None, gres, cast(rg, gamma), cast(rb, beta), None, None, None,
+                g1, g2)
 
 
 def bias_dropout_residual_layernorm(x, bias, residual, gamma, beta, eps, drop_p=0.0, training=False,
                                     inplace_z=True):
     """LayerNorm(dropout(x + bias) + residual)  -- vilmodel.py:150-154,189-193."""
     p = float(drop_p) if training else 0.0
-    return _BiasDropResLN.apply(x, bias, residual, gamma, beta, eps, p, inplace_z)
+    return _BiasDropResLN.apply(x, bias, residual, gamma, beta, eps, p, inplace_z, None, None)
+
+
+def bias_layernorm_plus(x, bias, gamma, beta, eps, post1, post2=None):
+    """(LayerNorm(x + bias) + post1) + post2 in one launch -- the sums of the embedding compositions
+    (vilmodel.py:494-532, 589-593); fp32 results equal the separate adds bit for bit (same order of additions)."""
+    return _BiasDropResLN.apply(x, bias, None, gamma, beta, eps, 0.0, True, post1.contiguous(),
+                                None if post2 is None else post2.contiguous())
 
 
 def layernorm(x, gamma, beta, eps):
-    return _BiasDropResLN.apply(x.contiguous(), None, None, gamma, beta, eps, 0.0, False)
+    return _BiasDropResLN.apply(x.contiguous(), None, None, gamma, beta, eps, 0.0, False, None, None)
 
 
 # ----------------------------------------------------------------------------- dropout (+ residual, + cast)

@@ -450,9 +450,9 @@ class ImageEmbeddings(nn.Module):
             pool = torch.cat([e, eo, e.new_zeros(e.shape[0], 1, e.shape[2])], 1)
             e = torch.gather(pool, 1, idx[..., None].expand(-1, -1, e.shape[2]))
         loc = _small_k_linear(loc_fts, self.loc_linear, cd)
-        e = e + ops.bias_dropout_residual_layernorm(loc, self.loc_linear.bias, None, self.loc_layer_norm.weight,
-                                                    self.loc_layer_norm.bias, 1e-12)
-        e = e + embedding_lookup(self.nav_type_embedding, nav_types) \
+        # ((e + LN(loc)) + nav_type) + token_type: the first two sums ride on the store of LN(loc)
+        e = ops.bias_layernorm_plus(loc, self.loc_linear.bias, self.loc_layer_norm.weight, self.loc_layer_norm.bias, 1e-12,
+                                    e, embedding_lookup(self.nav_type_embedding, nav_types)) \
             + embedding_lookup(type_embed_layer, torch.ones(1, 1, dtype=torch.long, device=e.device))
         e = ops.layernorm(e, self.layer_norm.weight, self.layer_norm.bias, 1e-12)
         e = ops.dropout(e, self.drop_p, self.training)
@@ -525,8 +525,9 @@ class LocalBEVEncoder(nn.Module):
         e = ops.bias_dropout_residual_layernorm(x, lin.bias, None, ln.weight, ln.bias, 1e-12)
         lin, ln = self.bev_pos_embeddings[0], self.bev_pos_embeddings[1]
         pos = _small_k_linear(bev_pos_fts, lin, cd)
-        e = e + ops.bias_dropout_residual_layernorm(pos, lin.bias, None, ln.weight, ln.bias, 1e-12)
-        return e + embedding_lookup(self.nav_type_embedding, bev_nav_masks.long())
+        # (e + LN(pos)) + nav_type in the LayerNorm's own launch
+        return ops.bias_layernorm_plus(pos, lin.bias, ln.weight, ln.bias, 1e-12, e,
+                                       embedding_lookup(self.nav_type_embedding, bev_nav_masks.long()))
 
     def with_objects(self, bev_embeds, bev_masks, obj_embeds, obj_masks):
         """vilmodel.py:601-606: object tokens are appended to the BEV cells (an all-ones BEV mask may come as None)."""
