@@ -23,6 +23,8 @@ Here:
     the per-view poses -- exactly what ``ops.bev_lift_bin`` + ``ops.bev_splat_mean(rows=...)`` consume.
 Host logic is plain numpy / torch indexing (device agnostic); the kernels it feeds are the C-ABI ones.
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -67,6 +69,7 @@ class HostFeed:
         self.cuda = self.device.type == "cuda"
         self.ring = [{"buf": None, "ev": None} for _ in range(slots)]
         self.i = 0
+        self._lock = threading.Lock()       # the per-device instance is shared: slot selection + fill are one critical section
 
     _shared = {}
 
@@ -85,7 +88,10 @@ class HostFeed:
     def __call__(self, arrays):
         if not self.cuda:
             return {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in arrays.items()}
-        arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+        with self._lock:
+            return self._ship({k: np.ascontiguousarray(v) for k, v in arrays.items()})
+
+    def _ship(self, arrays):
         offs, total = {}, 0
         for k, v in arrays.items():
             offs[k] = total
