@@ -1,3 +1,7 @@
+"""graph_map.HostFeed against per-array torch.from_numpy(a).to(device) copies: host time per call with an idle GPU and
+behind a queued 7 ms matmul per iteration.  In the second case BOTH block for the matmul (the loop is GPU-bound and
+the ring is 8 slots deep) -- what the packed feed buys shows in the idle case (one copy instead of five) and in the
+rollout bench, where the GPU is not saturated.  usage: python scripts/probes/hostfeed_probe.py"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
