@@ -79,7 +79,9 @@ int bevbert_bev_splat_mean(const void* feat, int feat_dtype, const int* order, c
  *   strides[8] (host) = {ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso}; dq/dk/dv use the q/k/v strides, dout the o strides.
  * key_mask (B,Lk) and bias (B,Lq,Lk) are additive fp32 (NULL = none; -inf allowed); lse (B,nh,Lq) fp32.
  * impl: 0 = auto (bf16 -> MFMA kernels, f32 -> exact fp32 kernels), 1 = exact kernels, 2 = MFMA kernels.
- * bwd: delta_ws is a (B,nh,Lq) fp32 scratch; dbias (B,Lq,Lk) fp32 is ACCUMULATED (sum over heads), NULL to skip. */
+ * bwd: delta_ws is a (B,nh,Lq) fp32 scratch; dbias (B,nh,Lq,Lk) fp32 receives the PER-HEAD bias gradients (written,
+ * not accumulated: the bias is shared by the heads and the caller sums dim 1 in a fixed order -- no atomics), NULL to
+ * skip. */
 int bevbert_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* key_mask,
                      const float* bias, const int64_t* strides, int B, int nh, int Lq, int Lk, int head_dim,
                      float scale, int dtype, int impl, float drop_p, uint64_t seed, uint64_t offset,
@@ -147,9 +149,12 @@ int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const 
                                     float* rstd, int rows, int L, int H, float eps, int dtype, float drop_p,
                                     uint64_t seed, uint64_t offset, hipStream_t stream);
 
-/* backward of the word-embedding gather of BertEmbeddings: table_grad[ids[r], :] += d[r, :] (fp32 atomics). */
-int bevbert_embedding_grad(const int64_t* ids, const void* d, float* table_grad, int rows, int H, int dtype,
-                           hipStream_t stream);
+/* backward of the word-embedding gather of BertEmbeddings (vilmodel.py:50,67): table_grad[t, :] += sum of d[r, :] over
+ * the rows with ids[r] == t, rows with ids[r] == padding_idx skipped (nn.Embedding(padding_idx=0); -1: none).  No
+ * atomics: the first row of every id sums its id's rows in ascending row order (four contiguous quarters, folded
+ * pairwise), so the result is a pure function of the inputs.  H % 4 == 0, H <= 1024. */
+int bevbert_embedding_grad(const int64_t* ids, const void* d, float* table_grad, int rows, int H, int padding_idx,
+                           int dtype, hipStream_t stream);
 
 /* backward of nn.Embedding lookups on SMALL tables (vilmodel.py:452 nav_type_embedding, :567 gmap_step_embedding, the
  * token-type row): partials[s][t][:] = sum of d[r, :] over the rows r of slice s (rows_per_slice rows each) with

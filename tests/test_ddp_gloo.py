@@ -221,6 +221,54 @@ def test_arena_data_parallel_follows_the_single_process_run_through_a_torch_opti
         assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-6), (k, (a[k] - b[k]).abs().max())
 
 
+class _ToyBranch(_Toy):
+    """``extra`` is used by rank 0 only (a task head another rank's batch does not reach)."""
+
+    def __init__(self):
+        super().__init__()
+        self.extra = torch.nn.Parameter(torch.full((3, 3), 0.5))
+        self.use_extra = False
+
+    def forward(self, x):
+        y = super().forward(x)
+        return _ArenaLinearFn.apply(y, self.extra) if self.use_extra else y
+
+
+def _union_run(rank, world, port, out):
+    import torch.distributed as dist
+    from vln_bevbert_amd.train import ArenaDataParallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _ToyBranch()
+    model.use_extra = rank == 0
+    model.finalize("cpu")
+    net = ArenaDataParallel(model)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(9)
+    xs, ys = torch.randn(3, 8, 4, generator=g), torch.randn(3, 8, 3, generator=g)
+    for step in range(3):
+        x, y = xs[step][rank * 4:(rank + 1) * 4], ys[step][rank * 4:(rank + 1) * 4]
+        ((net(x) - y) ** 2).mean().backward()
+        # used on rank 0 only: BOTH ranks receive the averaged gradient (DDP find_unused_parameters=True semantics)
+        assert model.extra.grad is not None, rank
+        assert model.unused.grad is None
+        opt.step()
+        opt.zero_grad()
+    torch.save({"extra": model.extra.detach().clone(), "a": model.a.detach().clone()}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_a_parameter_used_on_one_rank_only_is_updated_on_every_rank(tmp_path):
+    """arena._publish exchanges the set of touched parameters, so a parameter only rank 0's batch reaches gets
+    ``.grad`` (the averaged gradient) on rank 1 as well and the replicas stay identical."""
+    out = str(tmp_path / "u.pt")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_union_run, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["extra"], r1["extra"]) and torch.equal(r0["a"], r1["a"])
+    assert not torch.equal(r0["extra"], torch.full((3, 3), 0.5))
+
+
 def _bf16_exchange_run(rank, world, port, out):
     from vln_bevbert_amd.train import GradReducer
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -288,6 +288,52 @@ def test_small_table_embedding_grad_sliced(ops, table_rows, rows, dtype):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("rows,V,H,dtype", [(5120, 30522, 768, torch.bfloat16), (5120, 9, 768, torch.bfloat16),
+                                            (3000, 40, 64, torch.float32), (51, 500, 768, torch.float32),
+                                            (1, 3, 128, torch.float32)])
+def test_word_embedding_grad_is_deterministic_and_honours_padding_idx(ops, rows, V, H, dtype):
+    """bevbert_embedding_grad (backward of BertEmbeddings' word lookup, vilmodel.py:50,67): equals index_add_ with the
+    padding row left alone, accumulates into the sink, and gives the SAME BITS on every run -- no atomics.  (5120, 9):
+    ~570 rows per id, (3000, 40) with a 1 700-row run of one id: list batches beyond 1 024 entries are drained in turn."""
+    from vln_bevbert_amd.lib import call, dtype_code, ptr, stream
+    torch.manual_seed(11)
+    ids = torch.randint(0, V, (rows,), device=DEV)
+    if rows == 3000:
+        ids[torch.randperm(rows, device=DEV)[:1700]] = 5
+    d = torch.randn(rows, H, device=DEV).to(dtype)
+    for pad in (-1, 0):
+        keep = ids != pad
+        want = torch.zeros(V, H, device=DEV, dtype=torch.float64).index_add_(0, ids[keep], d[keep].double()) + 1.0
+        outs = []
+        for _ in range(3):
+            sink = torch.ones(V, H, device=DEV)
+            call("bevbert_embedding_grad", ptr(ids), ptr(d), ptr(sink), rows, H, pad, dtype_code(d), stream())
+            torch.cuda.synchronize()
+            outs.append(sink)
+        err = float((outs[0].double() - want).abs().max() / want.abs().max())
+        assert err < 1e-5, (pad, err)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        if pad == 0:
+            assert torch.equal(outs[0][0], torch.ones(H, device=DEV))
+
+
+def test_graph_bias_gradient_is_deterministic(ops):
+    """The additive graph bias (B, G, G) is shared by the 12 heads: the backward kernels store per-head gradients and the
+    host folds the heads -- the same bits on every run, for the exact and the MFMA kernels."""
+    for dtype, impl in ((torch.float32, 1), (torch.bfloat16, 2)):
+        q, k, v, km, bias, nh = _make_attn_inputs(5, 23, 23, "neg", True, dtype, seed=4)
+        outs = []
+        for _ in range(3):
+            bi = bias.clone().requires_grad_(True)
+            qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
+            o = ops.attention(qi, ki, vi, km, bi, nh, impl=impl)
+            o.backward(torch.ones_like(o) * 0.01 + o.detach() * 0.1)
+            torch.cuda.synchronize()
+            outs.append(bi.grad.clone())
+        assert float(outs[0].abs().sum()) > 0
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("dtype,fuse", [(torch.float32, True), (torch.float32, False), (torch.bfloat16, True)])
 def test_fused_sap_loss_tail_matches_the_torch_composition(ops, dtype, fuse):
     """ops.sap_loss == pretrain_cmt.forward_sap's tail written with torch ops (masked fills, fuse_sap_logits, three

@@ -19,12 +19,6 @@ from vln_bevbert_amd.config import BevBertConfig
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-# parameters whose gradients are accumulated with fp32 atomics (order-dependent in the last bits): the word-embedding
-# table (scatter of token gradients) and the Linear(1,1) behind the graph bias (atomic (B,G,G) bias gradient)
-ATOMIC = ("bert.embeddings.word_embeddings.weight", "bert.global_encoder.sprel_linear.weight",
-          "bert.global_encoder.sprel_linear.bias")
-
-
 @pytest.fixture(scope="module")
 def env():
     if not torch.cuda.is_available():
@@ -59,9 +53,8 @@ def one_rank_group(env):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_rccl_reducer_leaves_the_gradients_of_a_run_without_collectives(one_rank_group, dtype):
     """One backward per task with the collectives forced / not forced, same (seed, step): ``arena.grads`` before
-    clip + AdamW.  A one-rank all-reduce is the identity, so the two must agree: exactly wherever no fp32 atomics
-    contribute, and to 1e-6 relative L2 overall (pretrain_src/utils/misc.py:64-77 semantics: the wrapper changes
-    where gradients are summed, never their value)."""
+    clip + AdamW.  A one-rank all-reduce is the identity, so the two must agree bit for bit (no atomics on the path;
+    pretrain_src/utils/misc.py:64-77 semantics: the wrapper changes where gradients are summed, never their value)."""
     from vln_bevbert_amd.train import PretrainTrainer
     cfg = BevBertConfig.tiny(num_l_layers=2, num_x_layers=2, vocab_size=400)
     grads = {}
@@ -74,22 +67,15 @@ def test_rccl_reducer_leaves_the_gradients_of_a_run_without_collectives(one_rank
             loss = tr.forward_backward(task, b)
             torch.cuda.synchronize()
             grads[(force, task)] = (float(loss), arena.grads.clone())
-    exact = torch.ones(arena.numel, dtype=torch.bool, device=DEV)
-    for n in ATOMIC:
-        o, k = arena.slices[n]
-        exact[o:o + k] = False
     for task in ("sap", "mlm", "masksem"):
         (l0, g0), (l1, g1) = grads[(False, task)], grads[(True, task)]
         assert l0 == l1, task
         assert float(g0.norm()) > 0
-        rel = float((g0 - g1).norm() / g0.norm())
-        assert rel < 1e-6, (task, rel)
-        bad = (g0[exact] != g1[exact]).nonzero()
+        bad = (g0 != g1).nonzero()
         if bad.numel():
-            off = int(exact.nonzero()[int(bad[0])])
+            off = int(bad[0])
             name = [n for n, (o, k) in arena.slices.items() if o <= off < o + k]
-            raise AssertionError(f"{task}: {bad.shape[0]} gradient elements outside the atomic regions differ "
-                                 f"with the collectives on, first in {name}")
+            raise AssertionError(f"{task}: {bad.shape[0]} gradient elements differ with the collectives on, first in {name}")
 
 
 def test_four_steps_with_forced_collectives_track_a_run_without(one_rank_group):
@@ -340,32 +326,85 @@ def test_static_batch_with_object_tokens_runs_eagerly_and_survives_a_refill(env)
     assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
 
 
-def test_streaming_loader_refills_double_buffered_batches_and_trains_like_direct_steps(env):
-    """loader.StreamingLoader + BucketManager (producer thread, copy stream, two buffer sets per shape bucket, graphs
-    captured per buffer set) give the losses of stepping on freshly built StaticBatches of the same host batches."""
-    from vln_bevbert_amd.loader import BucketManager, StreamingLoader
+def _run_direct(cfg, order, host, lr, dtype=torch.float32, dropout=0.0):
     from vln_bevbert_amd.static_step import StaticBatch
     from vln_bevbert_amd.train import PretrainTrainer
+    model, arena = _fresh(cfg, dtype)
+    model.set_dropout(dropout)
+    tr = PretrainTrainer(model, arena, learning_rate=lr, warmup_steps=1, num_train_steps=100)
+    tr.use_graphs = False
+    out = [float(tr.step(t, StaticBatch(cfg, t, b, DEV))) for t, b in zip(order, host)]
+    torch.cuda.synchronize()
+    return np.asarray(out), arena.params.clone()
+
+
+def _run_stream(cfg, order, host, lr, depth=2, prefetch=1, dtype=torch.float32, dropout=0.0, graphs=True):
+    from vln_bevbert_amd.loader import BucketManager, StreamingLoader
+    from vln_bevbert_amd.train import PretrainTrainer
+    model, arena = _fresh(cfg, dtype)
+    model.set_dropout(dropout)
+    tr = PretrainTrainer(model, arena, learning_rate=lr, warmup_steps=1, num_train_steps=100)
+    tr.use_graphs = graphs
+    mgr = BucketManager(cfg, DEV, depth=depth, max_buckets=8)
+    loader = StreamingLoader(((t, b) for t, b in zip(order, host)), mgr, prefetch=prefetch)
+    out = []
+    for t, sb in loader:
+        out.append(float(tr.step(t, sb)))
+        loader.release(sb)
+    torch.cuda.synchronize()
+    return np.asarray(out), arena.params.clone(), mgr
+
+
+def test_training_is_bit_reproducible_run_to_run(env):
+    """The direct-vs-direct control VERDICT r3 asked for: two runs of the same 12 eager training steps (dropout ON, bf16
+    compute copies, AdamW) from the same seed give the same losses and the same parameters BIT FOR BIT -- there is no
+    atomic accumulation left on the path (word-embedding gradients: first-row leaders summing in row order; graph-bias
+    gradients: per-head stores folded on the host; everything else was already a fixed-order reduction)."""
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    order = ["sap", "mlm", "masksem"] * 4
+    host = [synthetic.make_batch(cfg, t, 3, seed=500 + i % 5, ragged=True, sems_as="ids") for i, t in enumerate(order)]
+    for dtype in (torch.float32, torch.bfloat16):
+        a, pa = _run_direct(cfg, order, host, 1e-4, dtype=dtype, dropout=0.1)
+        b, pb = _run_direct(cfg, order, host, 1e-4, dtype=dtype, dropout=0.1)
+        assert np.array_equal(a, b), (dtype, a, b)
+        assert torch.equal(pa, pb), dtype
+
+
+def test_streaming_loader_refills_double_buffered_batches_and_trains_like_direct_steps(env):
+    """loader.StreamingLoader + BucketManager (producer thread, copy stream, two buffer sets per shape bucket, graphs
+    captured per buffer set) against stepping on freshly built StaticBatches of the same host batches.
+    (1) identical weights (learning rate 0, as test_static_batch_refill_keeps_the_captured_graph): every step's loss is
+    a function of the batch in the buffers alone -> 1e-5; a stale or half-refilled buffer set shows here.
+    (2) a real training curve (AdamW, lr 1e-4): the gate of test_captured_step_replays_the_eager_step (5e-4) -- eager
+    and replayed steps run the same kernels; since round 4 they are free of atomics, so the observed difference is 0."""
     cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
     order = ["sap", "mlm"] * 8
     host = [synthetic.make_batch(cfg, t, 3, seed=300 + i % 3, sems_as="ids") for i, t in enumerate(order)]
-    losses = {}
-    for mode in ("direct", "stream"):
-        model, arena = _fresh(cfg, torch.float32)
-        model.set_dropout(0.0)
-        tr = PretrainTrainer(model, arena, learning_rate=1e-4, warmup_steps=1, num_train_steps=100)
-        out = []
-        if mode == "direct":
-            tr.use_graphs = False
-            for t, b in zip(order, host):
-                out.append(float(tr.step(t, StaticBatch(cfg, t, b, DEV))))
-        else:
-            mgr = BucketManager(cfg, DEV, depth=2, max_buckets=8)
-            loader = StreamingLoader(((t, b) for t, b in zip(order, host)), mgr, prefetch=1)
-            for t, sb in loader:
-                out.append(float(tr.step(t, sb)))
-                loader.release(sb)
-            assert mgr.stats["refills"] > 0 and mgr.captured_graphs() > 0
-            assert len(mgr.buckets) <= 6
-        losses[mode] = np.asarray(out)
-    assert np.allclose(losses["direct"], losses["stream"], rtol=1e-5, atol=1e-6), losses
+    d0, _ = _run_direct(cfg, order, host, 0.0)
+    s0, _, mgr = _run_stream(cfg, order, host, 0.0)
+    assert mgr.stats["refills"] > 0 and mgr.captured_graphs() > 0 and len(mgr.buckets) <= 6
+    assert np.allclose(d0, s0, rtol=1e-5, atol=1e-6), (d0, s0)
+    d1, pd = _run_direct(cfg, order, host, 1e-4)
+    s1, ps, _ = _run_stream(cfg, order, host, 1e-4)
+    dev = np.max(np.abs(d1 - s1) / np.maximum(1.0, np.abs(d1)))
+    assert dev < 5e-4, (dev, d1, s1)
+    assert float((pd - ps).norm() / pd.norm()) < 1e-4
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_streaming_loader_single_task_stream_reuses_one_bucket_safely(env, graphs):
+    """consecutive batches of ONE task land in one shape bucket, so with two buffer sets and one queued
+    batch the producer wants to refill the set of batch k while step k is still being enqueued.  The ownership flag of
+    loader.BucketManager makes it wait: every step's loss (identical weights, lr 0) is its own batch's loss."""
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    order = ["mlm"] * 12
+    base = synthetic.make_batch(cfg, "mlm", 3, seed=410, sems_as="ids")
+    host = []
+    for i in range(len(order)):      # same shapes (one bucket), different tokens / labels -> different losses
+        b = synthetic.make_batch(cfg, "mlm", 3, seed=410 + i, sems_as="ids")
+        host.append(b)
+    d0, _ = _run_direct(cfg, order, host, 0.0)
+    s0, _, mgr = _run_stream(cfg, order, host, 0.0, graphs=graphs)
+    assert len(set(np.round(d0, 5))) > 6, d0                      # the batches are distinguishable by their loss
+    assert np.allclose(d0, s0, rtol=1e-5, atol=1e-6), (d0, s0)
+    assert max(len(b["sets"]) for b in mgr.buckets.values()) == 2 and mgr.stats["refills"] >= 4

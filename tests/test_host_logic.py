@@ -551,16 +551,55 @@ def test_bucket_manager_keeps_shape_buckets_lru_and_round_robins_buffer_sets():
     b = [synthetic.make_batch(cfg, "sap", 2, seed=40 + i, sems_as="ids") for i in range(3)]
     s0 = mgr.acquire("sap", b[0])
     s1 = mgr.acquire("sap", b[0])
+    assert s0.in_use and s1.in_use
+    mgr.release(s0)
     s2 = mgr.acquire("sap", b[0])
     assert s0 is not s1 and s2 is s0 and mgr.stats["buffer_sets_allocated"] == 2 and mgr.stats["refills"] == 1
     assert torch.equal(s2.tensors["txt_ids"], b[0]["txt_ids"])
+    mgr.release(s1)
+    mgr.release(s2)
     sigs = {StaticBatch.plan(cfg, "sap", x)["signature"] for x in b}
     ragged = [synthetic.make_batch(cfg, "sap", 2, seed=90 + i, ragged=True, sems_as="ids") for i in range(6)]
     for x in ragged:
-        mgr.acquire("sap", x)
+        mgr.release(mgr.acquire("sap", x))
     assert len(mgr.buckets) <= 2
     assert mgr.stats["buckets_created"] - mgr.stats["buckets_evicted"] == len(mgr.buckets)
     assert len(sigs) >= 1
+
+
+def test_bucket_manager_never_refills_a_buffer_set_the_consumer_still_holds():
+    """with depth 2 and one queued batch THREE batches are in flight; a single-task stream (every batch
+    in one bucket -- the common case under the reference's random task draw) must not have batch k+2 written into the
+    buffers of batch k while the consumer still holds k.  The consumer here holds every batch for a while, then checks
+    that the buffers and the host-side fields still are that batch's."""
+    import threading
+    import time
+    from vln_bevbert_amd.loader import BucketManager, StreamingLoader
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    base = synthetic.make_batch(cfg, "mlm", 2, seed=7, sems_as="ids")
+    batches = []
+    for i in range(8):          # one shape bucket, distinguishable contents
+        b = dict(base)
+        b["txt_ids"] = base["txt_ids"].clone()
+        b["txt_ids"][:, 1] = 100 + i
+        batches.append(b)
+    mgr = BucketManager(cfg, "cpu", depth=2, max_buckets=4)
+    loader = StreamingLoader((("mlm", b) for b in batches), mgr, prefetch=1)
+    seen = 0
+    for i, (task, sb) in enumerate(loader):
+        time.sleep(0.05)                              # the producer has time to run ahead as far as it may
+        assert int(sb.tensors["txt_ids"][0, 1]) == 100 + i, (i, sb.tensors["txt_ids"][0, :3])
+        assert sb.in_use
+        loader.release(sb)
+        seen += 1
+    assert seen == len(batches) and len(mgr.buckets) == 1
+    assert mgr.stats["buffer_sets_allocated"] == 2 and mgr.stats["refills"] == len(batches) - 2
+    # a consumer that forgets to release: the producer reports it instead of overwriting or hanging silently
+    mgr2 = BucketManager(cfg, "cpu", depth=2, max_buckets=4)
+    mgr2.WAIT_TIMEOUT_S = 0.5
+    mgr2.acquire("mlm", batches[0]); mgr2.acquire("mlm", batches[1])
+    with pytest.raises(RuntimeError, match="never released"):
+        mgr2.acquire("mlm", batches[2])
 
 
 def test_host_feed_cpu_fallback_and_bucket_padding():
@@ -574,3 +613,21 @@ def test_host_feed_cpu_fallback_and_bucket_padding():
         assert torch.equal(out[k], torch.from_numpy(np.ascontiguousarray(v))), k
     assert HostFeed.shared("cpu") is HostFeed.shared("cpu")
     assert [_pad_to(n, 8) for n in (1, 2, 8, 9, 16, 17)] == [8, 8, 8, 16, 16, 24]
+
+
+def test_nav_graph_runner_clears_stale_padding_after_a_full_width_fill():
+    """fill sequence 5 -> 8 (exactly the padded width) -> 6 nodes in one bucket: rows 6..7 must be zero again
+    (they are masked-out padding; stale ``gmap_masks=True`` rows there would be attended to as real nodes)."""
+    from types import SimpleNamespace
+    from vln_bevbert_amd.nav_static import NavGraphRunner
+    runner = NavGraphRunner(SimpleNamespace(training=False, vln_bert=None), eager_uses=10 ** 9)
+    seen = []
+    fn = lambda x: seen.append({k: v.clone() for k, v in x.items()}) or x
+    for G in (5, 8, 6, 8, 3):
+        feeds = {"gmap_masks": torch.ones(2, G, dtype=torch.bool), "gmap_pair_dists": torch.full((2, G, G), float(G))}
+        runner._run(("nav", 2, 8), feeds, fn, {"gmap_masks": (2, 8), "gmap_pair_dists": (2, 8, 8)})
+        got = seen[-1]
+        assert bool(got["gmap_masks"][:, :G].all()) and not bool(got["gmap_masks"][:, G:].any()), G
+        assert float(got["gmap_pair_dists"][:, :G, :G].min()) == G
+        assert float(got["gmap_pair_dists"][:, G:].abs().max() if G < 8 else 0.0) == 0.0
+        assert float(got["gmap_pair_dists"][:, :, G:].abs().max() if G < 8 else 0.0) == 0.0

@@ -110,7 +110,12 @@ class ParamArena:
             p.compute = self.shadow[o:o + k].view(p.shape) if self.shadow is not None else p.data
             p.arena = self
             p.arena_name = n
+        self._index = {n: i for i, (n, _) in enumerate(named)}
         self.sync_shadow()
+        # the compute copy matches the masters as of now: a later write through the parameters (load_state_dict after
+        # wrap_model, as map_nav_src/r2r/agent_base.py does; a torch optimiser) moves a version counter and the next
+        # forward refreshes the copy (maybe_refresh_shadow) -- also when that write happens before the FIRST forward
+        self._param_versions = sum(p._version for _, p in named)
 
     # ---- views over contiguous groups --------------------------------------------------------
     def packed(self, names, shape):
@@ -167,19 +172,31 @@ class ParamArena:
         if self.device.type == "cuda":
             from . import ops
             ops.SCRATCH.reset()
+        fresh = self._fresh
         if self.allreduce_group is not None and not self.defer_allreduce:
             import torch.distributed as dist
             dist.all_reduce(self.grads, group=self.allreduce_group)
             self.grads.div_(dist.get_world_size(self.allreduce_group))
-        for p in self._fresh:
+            # DistributedDataParallel(find_unused_parameters=True) hands the reduced gradient of a parameter to EVERY
+            # rank when any rank used it; a rank that did not use it locally must publish it too, or its optimiser
+            # skips the update the other ranks make and the replicas drift apart: exchange the touched set (MAX)
+            used = torch.zeros(len(self.named), dtype=torch.int32, device=self.grads.device)
+            if fresh:
+                used[torch.tensor(sorted({self._index[p.arena_name] for p in fresh}), device=used.device)] = 1
+            dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.allreduce_group)
+            mine = {id(p) for p in fresh}
+            fresh = list(fresh) + [self.named[i][1] for i in used.nonzero().flatten().tolist()
+                                   if id(self.named[i][1]) not in mine]
+        for p in fresh:
             if p.grad is None:
                 p.grad = p.main_grad
                 self._published.append(p)
         self._fresh.clear()
 
     def maybe_lazy_zero(self):
-        """Zero the gradient arena if the caller dropped the published gradients (zero_grad(set_to_none=True))."""
-        if self._published and self._published[0].grad is None:
+        """Zero the gradient arena if the caller dropped published gradients (zero_grad(set_to_none=True)) -- of ANY
+        published parameter: an optimiser that owns only some of them clears only those."""
+        if self._published and any(p.grad is None for p in self._published):
             for p in self._published:
                 p.grad = None
             self._published.clear()

@@ -299,8 +299,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || (KT <= 2 && !BIAS)) ? 2 : 1) v
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
                 const int qi = q0 + t * 16 + g * 4 + r + j, key = key0 + kt * 16 + c;
-                if (a.dbias && qi < a.Lq && key < a.Lk)
-                  atomicAdd(a.dbias + ((size_t)b * a.Lq + qi) * a.Lk + key, ds2[j] * out_ks);
+                if (a.dbias && qi < a.Lq && key < a.Lk)        // this (batch, head)'s own slice: a plain store
+                  a.dbias[(((size_t)b * a.nh + h) * a.Lq + qi) * a.Lk + key] = ds2[j] * out_ks;
               }
             }
           }

@@ -44,7 +44,8 @@ struct AttnArgs {
   const void* dout;        // (B, Lq, nh*64), strides ldo/bso
   const float* delta;      // (B, nh, Lq) rowsum(dO * O)
   void *dq, *dk, *dv;      // same strides as q/k/v
-  float* dbias;            // (B, Lq, Lk) fp32, accumulated with atomics over heads, or null
+  float* dbias;            // (B, nh, Lq, Lk) fp32 per-head bias gradients (every element written once, no atomics; the
+                           // caller folds the heads in a fixed order), or null
 };
 
 // XCD-aware decode of a 1-D grid: hardware places workgroup id on XCD id % 8, each XCD has a private L2.  Work items

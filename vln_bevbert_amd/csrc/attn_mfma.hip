@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_dq_kernel(AttnArgs a) {
             const float dp = keep[r] ? dpacc[qt][tt][r] * keep_scale : 0.f;
             const float ds = valid ? p * (dp - dlt[qt]) : 0.f;
             sacc[qt][tt][r] = ds;
-            if (a.dbias && valid) atomicAdd(a.dbias + ((size_t)b * a.Lq + qrow[qt]) * a.Lk + key, ds);
+            if (a.dbias && valid) a.dbias[(((size_t)b * a.nh + h) * a.Lq + qrow[qt]) * a.Lk + key] = ds;
           }
         }
         dsb[qt] = pack_pair(sacc[qt][0], sacc[qt][1]);

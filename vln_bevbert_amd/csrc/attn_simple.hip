@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void attn_simple_dq_kernel(AttnArgs a) {
     if (a.drop_p > 0.f) dp = bb_keep(a.drop_key, attn_elem(a, b, h, qi, key), a.drop_thr) ? dp * keep_scale : 0.f;
     const float ds = p * (dp - delta);
     s_ds[w][key] = ds;
-    if (a.dbias) atomicAdd(a.dbias + ((size_t)b * a.Lq + qi) * a.Lk + key, ds);
+    if (a.dbias) a.dbias[(((size_t)b * a.nh + h) * a.Lq + qi) * a.Lk + key] = ds;
   }
   __builtin_amdgcn_wave_barrier();
   float acc = 0.f;

@@ -425,15 +425,82 @@ __global__ __launch_bounds__(256) void multi_accum_kernel(const AccumTask* __res
   else accum_task<float>(t);
 }
 
-// table_grad[ids[r]] += d[r]  (fp32 atomics; the reference's embedding backward is an atomic index_add too)
+// table_grad[t] += sum of d[r] over the rows r with ids[r] == t, WITHOUT atomics and in a fixed order (training runs are
+// bit-reproducible; the reference's index_add is not).  One workgroup per gradient row r: it returns at once unless r
+// is the FIRST row carrying its id (and the id is not padding_idx: nn.Embedding(padding_idx=0) gives the padding row no
+// lookup gradient, vilmodel.py:50); the leader then collects the later rows with the same id in ascending order
+// (wave ballots -> ordered compaction into an LDS list), its four waves sum contiguous quarters of each list batch in
+// row order, the four partial sums are folded as (w0 + w1) + (w2 + w3), and the leader alone read-modify-writes the
+// table row.  rows^2 / 256 id comparisons per launch (5 120 rows: the id vector stays in L2).
+#define EG_LIST 1024
+#define EG_MAXJ 4          // float4 column groups per lane: H <= 64 lanes * 4 floats * EG_MAXJ = 1024
 template <typename T>
-__global__ __launch_bounds__(192) void embedding_grad_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d,
-                                                             float* __restrict__ table_grad, int H) {
-  const int r = blockIdx.x;
-  float* dst = table_grad + (size_t)ids[r] * H;
-  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
-    const float4 v = ld4<T>(d + (size_t)r * H + c);
-    atomicAdd(dst + c, v.x); atomicAdd(dst + c + 1, v.y); atomicAdd(dst + c + 2, v.z); atomicAdd(dst + c + 3, v.w);
+__global__ __launch_bounds__(256) void embedding_grad_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d,
+                                                             float* __restrict__ table_grad, int rows, int H,
+                                                             int padding_idx) {
+  __shared__ int s_flag, s_wc[4], s_list[EG_LIST];
+  __shared__ float s_part[4][256 * EG_MAXJ];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t id = ids[r];
+  if (id == (int64_t)padding_idx) return;
+  if (tid == 0) s_flag = 0;
+  __syncthreads();
+  int hit = 0;
+  for (int i = tid; i < r; i += 256) hit |= (ids[i] == id);
+  if (hit) s_flag = 1;
+  __syncthreads();
+  if (s_flag) return;                       // an earlier row leads this id
+  float4 acc[EG_MAXJ];
+#pragma unroll
+  for (int j = 0; j < EG_MAXJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cnt = 0;                              // uniform: every thread derives it from the same LDS counts
+  for (int base = r; base < rows; base += 256) {
+    const int i = base + tid;
+    const bool m = i < rows && ids[i] == id;
+    const unsigned long long bal = __ballot(m);
+    if (lane == 0) s_wc[wave] = __popcll(bal);
+    __syncthreads();
+    int before = cnt;
+    for (int w = 0; w < wave; ++w) before += s_wc[w];
+    const int tot = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    if (m) s_list[before + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+    cnt += tot;
+    __syncthreads();
+    if (cnt > EG_LIST - 256 || base + 256 >= rows) {        // drain the list: wave w sums its quarter in row order
+      const int q = (cnt + 3) >> 2, lo = wave * q, hi = min(cnt, lo + q);
+      for (int k = lo; k < hi; k += 4) {
+        float4 v[4][EG_MAXJ];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = s_list[min(k + u, hi - 1)];
+#pragma unroll
+          for (int j = 0; j < EG_MAXJ; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            v[u][j] = (k + u < hi && c < H) ? ld4<T>(d + (size_t)row * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < EG_MAXJ; ++j) {
+            acc[j].x += v[u][j].x; acc[j].y += v[u][j].y; acc[j].z += v[u][j].z; acc[j].w += v[u][j].w;
+          }
+      }
+      cnt = 0;
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EG_MAXJ; ++j) *reinterpret_cast<float4*>(&s_part[wave][(lane + 64 * j) * 4]) = acc[j];
+  __syncthreads();
+  float* dst = table_grad + (size_t)id * H;
+  for (int c = tid * 4; c < H; c += 1024) {
+    const float4 p0 = *reinterpret_cast<const float4*>(&s_part[0][c]), p1 = *reinterpret_cast<const float4*>(&s_part[1][c]);
+    const float4 p2 = *reinterpret_cast<const float4*>(&s_part[2][c]), p3 = *reinterpret_cast<const float4*>(&s_part[3][c]);
+    float4 t = *reinterpret_cast<const float4*>(dst + c);
+    t.x += (p0.x + p1.x) + (p2.x + p3.x); t.y += (p0.y + p1.y) + (p2.y + p3.y);
+    t.z += (p0.z + p1.z) + (p2.z + p3.z); t.w += (p0.w + p1.w) + (p2.w + p3.w);
+    *reinterpret_cast<float4*>(dst + c) = t;
   }
 }
 
@@ -881,13 +948,15 @@ BEVBERT_API int bevbert_accum_partials(const void* partials, float* sink, int S,
 }
 
 BEVBERT_API int bevbert_embedding_grad(const int64_t* ids, const void* d, float* table_grad, int rows, int H,
-                                       int dtype, hipStream_t stream) {
-  BB_REQUIRE(H % 4 == 0, "embedding_grad: H=%d must be a multiple of 4", H);
+                                       int padding_idx, int dtype, hipStream_t stream) {
+  BB_REQUIRE(H % 4 == 0 && H <= 256 * EG_MAXJ, "embedding_grad: H=%d must be a multiple of 4 and <= %d", H, 256 * EG_MAXJ);
   if (rows <= 0) return BB_OK;
   if (dtype == BB_F32)
-    hipLaunchKernelGGL(embedding_grad_kernel<float>, dim3(rows), dim3(192), 0, stream, ids, (const float*)d, table_grad, H);
+    hipLaunchKernelGGL(embedding_grad_kernel<float>, dim3(rows), dim3(256), 0, stream, ids, (const float*)d, table_grad, rows, H,
+                       padding_idx);
   else if (dtype == BB_BF16)
-    hipLaunchKernelGGL(embedding_grad_kernel<bf16_raw>, dim3(rows), dim3(192), 0, stream, ids, (const bf16_raw*)d, table_grad, H);
+    hipLaunchKernelGGL(embedding_grad_kernel<bf16_raw>, dim3(rows), dim3(256), 0, stream, ids, (const bf16_raw*)d, table_grad,
+                       rows, H, padding_idx);
   else {
     bb_set_error("embedding_grad: dtype %d unsupported", dtype);
     return BB_EUNSUPPORTED;

@@ -33,17 +33,32 @@ def dtype_code(t):
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip into libbevbert_hip.so for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "attn_common.h", "attn_mfma_common.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    """Compile csrc/*.hip into libbevbert_hip.so for gfx950 (cross-compiles without a GPU): one object per source
+    (only the stale ones, in parallel), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "attn_common.h", "attn_mfma_common.h")]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+    objdir = os.path.join(_HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-o", LIB_PATH] + srcs + ["-lhipblaslt"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+    jobs, objs = [], []
+    for name in SOURCES:
+        src, obj = os.path.join(CSRC, name), os.path.join(objdir, name[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-lhipblaslt"])
     return LIB_PATH
 
 
@@ -68,7 +83,7 @@ _PROTOS = {
     "bevbert_layernorm_post_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "bevbert_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U64, _I, _P],
     "bevbert_embed_sum_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _U64, _U64, _P],
-    "bevbert_embedding_grad": [_P, _P, _P, _I, _I, _I, _P],
+    "bevbert_embedding_grad": [_P, _P, _P, _I, _I, _I, _I, _P],
     "bevbert_embedding_grad_sliced": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "bevbert_bias_gelu_fwd": [_P, _P, _P, _I, _I, _I, _P],
     "bevbert_bias_gelu_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -30,6 +30,16 @@ from .static_step import StaticBatch
 
 
 class BucketManager:
+    """Buffer sets per shape bucket.  Ownership protocol of a buffer set (a refill must never touch buffers a
+    step may still read, and with ``depth`` sets and ``prefetch`` queued batches up to ``prefetch + 2`` batches are in
+    flight): ``acquire`` hands a set out with ``in_use = True``; only ``release`` (called by the consumer AFTER it has
+    enqueued the step that reads the set) clears the flag and records the ``done`` event; a later ``acquire`` that
+    lands on the same set blocks on a condition variable until the flag is clear, then makes the copy stream wait for
+    ``done`` -- so neither the device buffers nor the host-side fields (CPU copies, row counts, CSR) of a set change
+    while the consumer holds it or the GPU still reads it."""
+
+    WAIT_TIMEOUT_S = 120.0       # a consumer that never releases is a bug: say so instead of hanging forever
+
     def __init__(self, cfg, device, depth=2, max_buckets=16, grid_store=None):
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:
@@ -39,13 +49,29 @@ class BucketManager:
         self.buckets = collections.OrderedDict()        # signature -> {"sets": [StaticBatch], "next": int}
         self.copy_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.stats = collections.Counter()
+        self._cv = threading.Condition()
 
     def _on_copy_stream(self):
         return torch.cuda.stream(self.copy_stream) if self.copy_stream is not None else _NullCtx()
 
+    def _wait_free(self, sb):
+        """Block until the consumer has released ``sb``; then order the copy stream behind the step that read it."""
+        t0 = time.perf_counter()
+        with self._cv:
+            while getattr(sb, "in_use", False):
+                if not self._cv.wait(timeout=1.0) and time.perf_counter() - t0 > self.WAIT_TIMEOUT_S:
+                    raise RuntimeError("BucketManager: a buffer set was never released (call release(sb) after the step "
+                                       "on it has been enqueued); depth must be >= 2 for the producer to run ahead")
+        self.stats["wait_s"] += time.perf_counter() - t0
+        done = getattr(sb, "done", None)
+        if done is not None:
+            if self.copy_stream is not None:
+                self.copy_stream.wait_event(done)       # device order: refill after the step that last read the buffers
+            done.synchronize()                          # host order: the host-side fields are rewritten below too
+
     def acquire(self, task, batch, grid_keys=None):
         """Device-resident StaticBatch holding ``batch`` (host tensors, collate schema).  Blocks while the buffer set it
-        is about to overwrite is still being read by an earlier step."""
+        is about to overwrite is still held by the consumer or read by an earlier step."""
         t0 = time.perf_counter()
         host = StaticBatch.plan(self.cfg, task, batch)
         sig = host["signature"]
@@ -55,10 +81,11 @@ class BucketManager:
             self.buckets[sig] = b
             self.stats["buckets_created"] += 1
             while len(self.buckets) > self.max_buckets:
-                old_sig, old = self.buckets.popitem(last=False)
+                old_sig = next(iter(self.buckets))
+                old = self.buckets[old_sig]
                 for sb in old["sets"]:
-                    if getattr(sb, "done", None) is not None:
-                        sb.done.synchronize()
+                    self._wait_free(sb)
+                del self.buckets[old_sig]
                 self.stats["buckets_evicted"] += 1
         self.buckets.move_to_end(sig)
         if len(b["sets"]) < self.depth:                  # first uses of a bucket: allocate another buffer set
@@ -71,12 +98,13 @@ class BucketManager:
         else:
             sb = b["sets"][b["next"] % self.depth]
             b["next"] += 1
-            if sb.done is not None:
-                sb.done.synchronize()                    # the step that last read these buffers has finished
+            self._wait_free(sb)
             with self._on_copy_stream():
                 sb.load(batch, grid_keys=grid_keys, host=host)
                 sb.ready = self._record()
             self.stats["refills"] += 1
+        with self._cv:
+            sb.in_use = True
         self.stats["bytes_h2d"] += sum(v.numel() * v.element_size() for k, v in batch.items()
                                        if torch.is_tensor(v) and not (self.grid_store is not None and k in ("rgbs", "depths", "sems")))
         self.stats["loader_s"] += time.perf_counter() - t0
@@ -95,6 +123,9 @@ class BucketManager:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             sb.done = ev
+        with self._cv:
+            sb.in_use = False
+            self._cv.notify_all()
 
     def captured_graphs(self):
         return sum(sb.graph is not None for b in self.buckets.values() for sb in b["sets"])

@@ -60,6 +60,7 @@ class NavGraphRunner:
             buf = b.inputs[k]
             if v.shape == buf.shape:
                 buf.copy_(v, non_blocking=True)
+                b.filled[k] = tuple(v.shape)      # a later, smaller fill must clear what this one wrote
                 continue
             last = b.filled.get(k)
             if last is not None and any(l > n for l, n in zip(last, v.shape)):

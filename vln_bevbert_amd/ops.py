@@ -1379,11 +1379,14 @@ class _Attention(torch.autograd.Function):
             grads = (dq, dk, dv)
         B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
         delta = torch.empty(B, nh, Lq, dtype=torch.float32, device=q.device)
-        dbias = torch.zeros_like(bias) if (bias is not None and ctx.needs_input_grad[5]) else None
+        # the bias is shared by the heads: the kernels store per-head gradients (no atomics), summed here in a fixed order
+        dbias_h = torch.zeros(B, nh, Lq, Lk, dtype=torch.float32, device=q.device) \
+            if (bias is not None and ctx.needs_input_grad[5]) else None
         assert do.shape == o.shape
         call("bevbert_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk),
-             ptr(dv), ptr(dbias), ptr(key_mask), ptr(bias), _strides(q, k, v, o), B, nh, Lq, Lk, HEAD_DIM, scale,
+             ptr(dv), ptr(dbias_h), ptr(key_mask), ptr(bias), _strides(q, k, v, o), B, nh, Lq, Lk, HEAD_DIM, scale,
              dtype_code(q), impl, drop_p, seed, off, ptr(bits), stream())
+        dbias = None if dbias_h is None else dbias_h.sum(1)
         return (None,) + grads + (None, dbias, None, None, None)
 
 
@@ -1403,7 +1406,7 @@ def attention(q, k, v, key_mask=None, bias=None, nh=12, drop_p=0.0, training=Fal
 # ----------------------------------------------------------------------------- K5 embeddings
 class _EmbedLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, word, pos, typ, gamma, beta, eps, type_index, word_c, pos_c, typ_c):
+    def forward(ctx, ids, word, pos, typ, gamma, beta, eps, type_index, word_c, pos_c, typ_c, pad_idx=-1):
         B, L = ids.shape
         H = word_c.shape[1]
         rows = B * L
@@ -1417,13 +1420,13 @@ class _EmbedLN(torch.autograd.Function):
              ptr(_f32(gamma)), ptr(_f32(beta)), ptr(y), ptr(z), ptr(mean), ptr(rstd), rows, L, H, float(eps),
              dtype_code(y), 0.0, 0, 0, stream())
         ctx.save_for_backward(ids, z, mean, rstd)
-        ctx.params = (word, pos, typ, gamma, beta, type_index)
+        ctx.params = (word, pos, typ, gamma, beta, type_index, int(pad_idx))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         ids, z, mean, rstd = ctx.saved_tensors
-        word, pos, typ, gamma, beta, type_index = ctx.params
+        word, pos, typ, gamma, beta, type_index, pad_idx = ctx.params
         B, L = ids.shape
         H = z.shape[-1]
         rows = B * L
@@ -1453,7 +1456,7 @@ class _EmbedLN(torch.autograd.Function):
         dzf = dz2.float()
 
         def word_grad(t):
-            call("bevbert_embedding_grad", ptr(ids), ptr(dz2), ptr(t), rows, H, dtype_code(dz2), stream())
+            call("bevbert_embedding_grad", ptr(ids), ptr(dz2), ptr(t), rows, H, pad_idx, dtype_code(dz2), stream())
 
         makers = ((word, word_grad),
                   (pos, lambda t: _on_launch_stream(lambda: t[:L].add_(dzf.view(B, L, H).sum(0)))),
@@ -1475,13 +1478,14 @@ class _EmbedLN(torch.autograd.Function):
             # receives the tied MLM decoder's dW there (a deferred, non-atomic read-modify-write), the type table the
             # panorama branch's row-1 gradient -- one stream keeps the writers of a sink in program order
             WgradStream.submit(dy.device, lambda: [m(t) for m, t in deferred], dz2, dzf, ids, dy)
-        return (None, outs[0], outs[1], outs[2], rg, rb, None, None, None, None, None)
+        return (None, outs[0], outs[1], outs[2], rg, rb, None, None, None, None, None, None)
 
 
-def embed_sum_layernorm(ids, word, pos, typ, gamma, beta, eps, type_index=0):
-    """BertEmbeddings (vilmodel.py:62-77): LN(word[ids] + pos[0..L) + type[type_index])."""
+def embed_sum_layernorm(ids, word, pos, typ, gamma, beta, eps, type_index=0, padding_idx=None):
+    """BertEmbeddings (vilmodel.py:62-77): LN(word[ids] + pos[0..L) + type[type_index]).  ``padding_idx``: rows of the
+    word table that receive no lookup gradient (nn.Embedding(padding_idx=0), vilmodel.py:50)."""
     return _EmbedLN.apply(ids, word, pos, typ, gamma, beta, eps, type_index, _compute(word), _compute(pos),
-                          _compute(typ))
+                          _compute(typ), -1 if padding_idx is None else int(padding_idx))
 
 
 # ----------------------------------------------------------------------------- K6 segment gather

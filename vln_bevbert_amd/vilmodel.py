@@ -89,7 +89,7 @@ class BertEmbeddings(nn.Module):
     def forward(self, input_ids, token_type_ids=None, position_ids=None):
         y = ops.embed_sum_layernorm(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
                                     self.token_type_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias,
-                                    self.eps, 0)
+                                    self.eps, 0, padding_idx=self.word_embeddings.padding_idx)
         return ops.dropout(y, self.dropout_p, self.training)
 
 
