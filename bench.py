@@ -84,6 +84,8 @@ def parse():
                     help="sustained block ships the grid features of every batch over PCIe (462 MB fp32 at batch 64) instead "
                          "of reading rows of the device-resident feature store")
     ap.add_argument("--stream-steps", type=int, default=33)
+    ap.add_argument("--loader-workers", type=int, default=4,
+                    help="DataLoader worker processes that collate the sustained run's batches (0: in the producer thread)")
     ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
                     help="how the step is issued: eager (~700 launches from Python), graph (hipGraph replay), or auto = time "
                          "both in the untimed preparation and keep the faster one (BEVBERT_GRAPHS=0/1 in the environment "
@@ -156,7 +158,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from vln_bevbert_amd import ops, synthetic
+    from vln_bevbert_amd import lib, ops, synthetic
     from vln_bevbert_amd.static_step import StaticBatch
     from vln_bevbert_amd.config import BevBertConfig
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
@@ -287,6 +289,8 @@ def main():
                        if (n_graphs and trainer.use_graphs) else "eager",
         "launch_calibration": calibration,
         "graph_error": trainer.graph_error,
+        # library GEMM algorithms dropped because two launches on the same operands gave different bits (gemm.hip)
+        "gemm_plans": ops.gemm_plan_count(), "gemm_candidates_rejected_as_not_reproducible": lib.load().bevbert_gemm_rejected_count(),
         "final_loss": round(float(losses[-1].item()), 4),
     }
 
@@ -434,7 +438,7 @@ def main():
         dom_entry = max(by_entry, key=by_entry.get)
         dom_key, dom = max(((k, r) for k, r in rows.items() if k.split("[")[0] == dom_entry), key=lambda kv: kv[1]["ms"])
         traffic = traffic_source = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f).get(dom_key)
@@ -454,10 +458,20 @@ def main():
             return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4)}
 
+        # the same entry over ALL its shapes of the profiled steps (the heaviest shape is the entry's best case;
+        # its short-sequence launches run far below it): total algorithmic work / total time between the events
+        ent_rows = [r for k, r in rows.items() if k.split("[")[0] == dom_entry]
+        ent = {"ms": sum(r["ms"] for r in ent_rows), "gflop": sum(r["gflop"] for r in ent_rows),
+               "mb": sum(r["mb"] for r in ent_rows)}
         out["roofline"] = {"kernel": dom_key, **roof(dom), "traffic": traffic, "traffic_source": traffic_source,
                            "avg_launch_us": dom["avg_us"],
                            "launches": dom["launches"],
-                           "entry_share_of_custom_ms": round(by_entry[dom_entry] / max(custom_ms, 1e-9), 3)}
+                           "entry_share_of_custom_ms": round(by_entry[dom_entry] / max(custom_ms, 1e-9), 3),
+                           "entry_frac": roof(ent)["frac"], "entry_achieved": roof(ent)["achieved"],
+                           "entry_launches": sum(r["launches"] for r in ent_rows),
+                           "entry_shapes": {k.split("[", 1)[1].rstrip("]") if "[" in k else "all":
+                                            {"launches": r["launches"], "avg_us": r["avg_us"], "frac": roof(r)["frac"]}
+                                            for k, r in rows.items() if k.split("[")[0] == dom_entry}}
         # Cross-check of the bracketed figure for the dominant kernel: the SAME C-ABI call (same arguments; its operands
         # were activations of the profiled step, whose memory is still mapped and no longer in use) ten times back to
         # back between ONE pair of events.  If the per-launch brackets contained launch latency the two would differ;
@@ -525,7 +539,11 @@ def side_configs(a):
                                 "--batch", "32"] + common),
             ("ce_b64", [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "ce"] + common),
             ("finetune_rollout_b32_15steps_infer", [sys.executable, os.path.join(ROOT, "scripts", "bench_nav.py"), "--batch", "32",
-                                                    "--steps", "15", "--iters", "4", "--warmup", "2", "--mode", "infer"])]
+                                                    "--steps", "15", "--iters", "4", "--warmup", "3", "--mode", "infer"]),
+            # the same rollout with the agent's action feedback: logits read back and argmaxed on the host every step
+            ("finetune_rollout_b32_15steps_infer_feedback", [sys.executable, os.path.join(ROOT, "scripts", "bench_nav.py"),
+                                                             "--batch", "32", "--steps", "15", "--iters", "4", "--warmup", "3",
+                                                             "--mode", "infer", "--feedback"])]
     res = {}
     for name, cmd in jobs:
         if time.perf_counter() - T_START > budget_s:
@@ -537,29 +555,56 @@ def side_configs(a):
             line = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
             d = json.loads(line[-1])
             keep = ("value", "unit", "ms_per_step", "step_launch", "config", "final_loss", "ms_per_nav_step", "workload",
-                    "episodes_per_s", "host_map_bookkeeping_ms_per_nav_step", "ms_per_episode_batch")
+                    "episodes_per_s", "host_map_bookkeeping_ms_per_nav_step", "ms_per_episode_batch", "map", "action_feedback",
+                    "neighbour_bound_overflow")
             res[name] = {k: d[k] for k in keep if k in d}
         except Exception as e:      # noqa: BLE001 -- a side figure must not cost the bench line
             res[name] = {"error": repr(e)[:300]}
     return res
 
 
+class _CollateStream(torch.utils.data.IterableDataset):
+    """Fresh collates for the sustained run, produced in DataLoader worker processes like the reference's task loaders
+    (pretrain_src/data/loader.py:122-160 build_dataloader: num_workers = n_workers, collate_fn = the task's collate):
+    step i draws ``batch`` samples from a pool of pre-generated synthetic samples (the pool stands in for the dataset
+    reads; grid features are rows of the device-resident store), collates them (padding, stacking, fresh MLM masking:
+    pretrain_src/data/tasks.py:116-163) and names ``batch`` random rows of the grid-feature store."""
+
+    def __init__(self, cfg, samples, cycle, n_total, batch, seed, n_rows, ship_grid):
+        self.cfg, self.samples, self.cycle, self.n_total, self.batch = cfg, samples, cycle, n_total, batch
+        self.seed, self.n_rows, self.ship_grid = seed, n_rows, ship_grid
+
+    def __iter__(self):
+        import numpy as np
+        from vln_bevbert_amd import synthetic
+        info = torch.utils.data.get_worker_info()
+        w, W = (info.id, info.num_workers) if info is not None else (0, 1)
+        torch.set_num_threads(1)
+        for i in range(w, self.n_total, W):
+            t = self.cycle[i % len(self.cycle)]
+            rng = np.random.default_rng(self.seed + i)
+            pick = rng.integers(0, len(self.samples), self.batch)
+            b = synthetic.collate([self.samples[int(j)] for j in pick], self.cfg, t, rng, sems_as="ids")
+            keys = None if self.ship_grid else [f"s_{int(r)}" for r in rng.integers(0, self.n_rows, self.batch)]
+            yield t, b, keys
+
+
 def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     """Throughput with the loader's work INSIDE the measured loop (the headline figure replays resident batches).
 
-    A producer thread (loader.StreamingLoader) takes the next host batch of the step's task from a pool of pinned
-    synthetic batches (the pool stands in for dataset reads; random-number generation is not loader work), builds
-    everything the reference computes on the host inside its forward (StaticBatch.plan: masked-token positions, SAP
-    fusion table, global-map aggregation CSR), picks the shape bucket (loader.BucketManager), refills one of the
-    bucket's two buffer sets on a copy stream and hands it to the training thread, which waits for the copy on the
-    compute stream and runs the step (captured graph of that buffer set once it exists, eager before).  Grid features
-    come as row numbers of a device-resident feature_store.GridFeatureStore (--ship-grid: as 462 MB of fp32 per batch
-    over PCIe, the reference's way)."""
+    ``--loader-workers`` DataLoader worker processes collate a FRESH batch for every step (``_CollateStream``; pinned by
+    the DataLoader's pin-memory thread); the producer thread of loader.StreamingLoader builds everything the reference
+    computes on the host inside its forward (StaticBatch.plan: masked-token positions, SAP fusion table, global-map
+    aggregation CSR), picks the shape bucket (loader.BucketManager), refills one of the bucket's two buffer sets on a
+    copy stream and hands it to the training thread, which waits for the copy on the compute stream and runs the step
+    (captured graph of that buffer set once it exists, eager before).  Grid features come as row numbers of a
+    device-resident feature_store.GridFeatureStore (--ship-grid: as 462 MB of fp32 per batch over PCIe, the reference's
+    way).  ``loader_ms_per_batch`` is the producer thread's own work per batch (plan + refill), without the time it
+    waits for a buffer set to be released (``loader_wait_ms_per_batch``) or for the workers (``collate_*``)."""
     import numpy as np
     from vln_bevbert_amd import ops, synthetic
     from vln_bevbert_amd.feature_store import GridFeatureStore
     from vln_bevbert_amd.loader import BucketManager, StreamingLoader
-    n_pool = 6 if a.ragged else 4
     store = None
     n_rows = 1024
     if not a.ship_grid:
@@ -570,37 +615,30 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
         depths = depths * (torch.rand(depths.shape, device=dev, generator=g) > 0.05)
         sems = torch.randint(0, max(1, cfg.sem_classes), (n_rows, P), device=dev, generator=g).to(torch.uint8)
         store = GridFeatureStore([f"s_{i}" for i in range(n_rows)], rgbs, depths, sems, dev)
+    # the "dataset": a pool of samples (fixed shapes: T = 5, L = txt_len; --ragged: T in [1,7], text in [L/2, L], 36..38 views)
     rng = np.random.default_rng(11)
-    pool = {}
+    n_pool = 64 if a.ship_grid else 256
+    samples = []
+    for i in range(n_pool):
+        T = int(rng.integers(1, 8)) if a.ragged else 5
+        L = int(rng.integers(a.txt_len // 2, a.txt_len + 1)) if a.ragged else a.txt_len
+        samples.append(synthetic.make_sample(rng, i, cfg, T, L, ragged_views=a.ragged, grid=a.ship_grid))
+    t0 = time.perf_counter()
     for t in tasks:
-        pool[t] = []
-        for j in range(n_pool):
-            b = synthetic.make_batch(cfg, t, a.batch, seed=7000 + 31 * j + len(pool), txt_len=a.txt_len, ragged=a.ragged,
-                                     sems_as="ids")
-            keys = None
-            if store is not None:
-                for k in ("rgbs", "depths", "sems"):
-                    b.pop(k, None)
-                keys = [f"s_{int(i)}" for i in rng.integers(0, n_rows, a.batch)]
-            b = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()}
-            pool[t].append((b, keys))
+        synthetic.collate(samples[:a.batch] if len(samples) >= a.batch else (samples * a.batch)[:a.batch], cfg, t, rng, sems_as="ids")
+    collate_ms = 1000.0 * (time.perf_counter() - t0) / len(tasks)
     mgr = BucketManager(cfg, dev, depth=2, max_buckets=64, grid_store=store)
     # warm-up: every (bucket, buffer set) has to be seen GRAPH_WARMUP + 1 times before its step is a replay
-    seen = {t: 0 for t in tasks}
     per_task_uses = {t: max(1, cycle.count(t)) for t in tasks}
-    n_buckets_guess = {t: (n_pool if a.ragged else 1) for t in tasks}
+    n_buckets_guess = {t: (6 if a.ragged else 1) for t in tasks}
     n_warm = max(len(cycle) * -(-(n_buckets_guess[t] * 2 * (trainer.GRAPH_WARMUP + 1)) // per_task_uses[t]) for t in tasks)
     n_warm = min(n_warm, 40 * len(cycle))
     n_total = n_warm + a.stream_steps
-
-    def source():
-        for i in range(n_total):
-            t = cycle[i % len(cycle)]
-            b, keys = pool[t][seen[t] % n_pool]
-            seen[t] += 1
-            yield t, b, keys
-
-    loader = StreamingLoader(source(), mgr, prefetch=1)
+    workers = max(0, a.loader_workers)
+    ds = _CollateStream(cfg, samples, cycle, n_total, a.batch, 7000, n_rows, a.ship_grid)
+    dl = torch.utils.data.DataLoader(ds, batch_size=None, num_workers=workers, pin_memory=True,
+                                     prefetch_factor=2 if workers else None, persistent_workers=False)
+    loader = StreamingLoader(iter(dl), mgr, prefetch=1)
     plans0 = ops.gemm_plan_count() if hasattr(ops, "gemm_plan_count") else None
     it = iter(loader)
     replayed = eager = 0
@@ -621,17 +659,22 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     loader.close()
+    del it, dl
     st = {k: mgr.stats[k] - stats0.get(k, 0) for k in mgr.stats}
     ms = 1000.0 * dt / a.stream_steps
+    n = max(1, a.stream_steps)
     res = {"samples_per_s": round(a.stream_steps * a.batch / dt, 2), "ms_per_step": round(ms, 3),
            "vs_resident": round(resident_ms / ms, 4), "steps": a.stream_steps, "warmup_steps": n_warm,
            "batches": "ragged (T in [1,7], text in [L/2, L], 36..38 views)" if a.ragged else "fixed shapes (T = 5, L = %d)" % a.txt_len,
            "grid_features": "462 MB fp32 per batch over PCIe" if a.ship_grid else f"rows of a {store.nbytes() / 2**30:.1f} GiB device-resident store",
-           "pool": f"{n_pool} pinned host batches per task, cycled; host-side index building and refill every step",
+           "source": f"a fresh collate per step ({n_pool}-sample pool, {workers} DataLoader worker processes, pinned by the "
+                     f"DataLoader); host-side index building and refill every step",
+           "collate_ms_per_batch_one_process": round(collate_ms, 2), "collate_workers": workers,
            "buckets": len(mgr.buckets), "buckets_created_in_timed_region": st.get("buckets_created", 0),
            "captured_graphs": mgr.captured_graphs(), "steps_replayed": replayed, "steps_eager": eager,
-           "loader_ms_per_batch": round(1000.0 * st.get("loader_s", 0.0) / max(1, a.stream_steps), 3),
-           "h2d_MB_per_step": round(st.get("bytes_h2d", 0) / max(1, a.stream_steps) / 1e6, 2)}
+           "loader_ms_per_batch": round(1000.0 * (st.get("loader_s", 0.0) - st.get("wait_s", 0.0)) / n, 3),
+           "loader_wait_ms_per_batch": round(1000.0 * st.get("wait_s", 0.0) / n, 3),
+           "h2d_MB_per_step": round(st.get("bytes_h2d", 0) / n / 1e6, 2)}
     if plans0 is not None:
         res["gemm_plans_added"] = ops.gemm_plan_count() - plans0
     del store

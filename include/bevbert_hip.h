@@ -234,6 +234,10 @@ int bevbert_gemm_run(int plan, const void* A, const void* B, void* C, const void
 int bevbert_gemm_run_add(int plan, const void* A, const void* B, const void* Cin, void* D, const void* bias,
                          void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int bevbert_gemm_plan_count(void);
+/* library algorithms dropped so far because two launches on the same operands left different output bits (split-K /
+ * stream-K reductions through atomics): plans only ever use algorithms whose results repeat (BEVBERT_GEMM_DETERMINISTIC=0
+ * turns the screening off). */
+int bevbert_gemm_rejected_count(void);
 /* Tuning table (text): one line "<problem key> <choice> <ncand>" per autotuned plan after a header naming the hipBLASLt
  * version.  export returns the bytes the text needs (incl. the final 0) and fills buf when cap suffices; import makes
  * later plans reuse the recorded choice instead of timing candidates (returns the number of rows; -3 when the table
@@ -283,6 +287,52 @@ int bevbert_set_step_salt(const void* device_word);
 /* test hook: keep-mask (uint8) the kernels derive for n consecutive elements starting at `offset` */
 int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p, uint64_t seed, uint64_t offset,
                               hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fine-tune rollout bookkeeping on the device: the B topological maps of a rollout as dense
+ * device arrays over a node capacity N.  Replaces map_nav_src/models/graph_utils.py:44-94 (FloydGraph.add_edge / update /
+ * path lengths), :96-189 (GraphMap.update_graph, get_pos_fts, gather_node_pc's node choice) and the numeric half of
+ * map_nav_src/r2r/agent.py:194-276,326-331 (_nav_gmap_variable, the start-viewpoint position features).  The host keeps
+ * only the viewpoint-id -> node-index dictionaries and the presentation order of the nodes.
+ * All pointers are device pointers except the state block itself (a host struct of device pointers).  f64 add / compare
+ * follow the reference's Python floats bit for bit. */
+typedef struct bevbert_gm_state {
+  double* pos;        /* (B, N, 3)  node positions */
+  double* dis;        /* (B, N, N)  shortest known distances, 95959595 = none (graph_utils.py:46) */
+  int* point;         /* (B, N, N)  next hop of the shortest path, -1 = direct edge */
+  int* hops;          /* (B, N, N)  len(FloydGraph.path(x, y)), written by bevbert_gm_update */
+  uint8_t* visited;   /* (B, N) */
+  int* step_ids;      /* (B, N)     agent.py:471-474 */
+  int* pc_list;       /* (B, N)     visited nodes in first-visit order (GraphMap.node_pc's dict order) */
+  int* npc;           /* (B) */
+  int* node_row;      /* (B, N)     feature-store row of a visited node */
+  float* node_T;      /* (B, N, V, 16) its V camera-to-world matrices */
+  int B, N, V, pad;
+} bevbert_gm_state;
+
+/* One navigation step of every episode: live_graph[b] -> register the edges cur[b] -- cand[b, 0..ncand[b]) (positions
+ * cur_pos (B,3), cand_pos (B,C,3) and edge lengths cand_dist (B,C), f64, computed by the host with the reference's own
+ * arithmetic), relax all pairs through cur[b], mark it visited, rebuild the hop counts of the
+ * first n_nodes[b] nodes; live_step[b] -> step_ids[b, cur[b]] = step_id (if > 0) and, when row != NULL and row[b] >= 0,
+ * remember the node's feature-store row and poses T (B, V*16). */
+int bevbert_gm_update(const bevbert_gm_state* st, const uint8_t* live_graph, const uint8_t* live_step, const int* cur,
+                      const int* ncand, const int* cand, const double* cur_pos, const double* cand_pos,
+                      const double* cand_dist, const int* n_nodes, int C, int step_id, const int* row, const float* T,
+                      hipStream_t stream);
+
+/* The tensors of agent.py:194-276 for the node order node (B, G-1) (cnt[b] real entries per sample, chosen by the host:
+ * visited nodes first): step_ids (B,G) i64, visited / masks (B,G) bool bytes, pair (B,G,G) f32 = dis / 30, pos_fts
+ * (B,G,7) f32 (row 0 = [stop]); gpos (B,7) or NULL: position features of start[b] seen from cur[b]. */
+int bevbert_gm_nav_vars(const bevbert_gm_state* st, const int* node, const int* cnt, const int* cur, const int* start,
+                        const double* heading, const double* elevation, int G, int enc_full_graph, int act_visited,
+                        int64_t* step_ids, uint8_t* visited, uint8_t* masks, float* pair, float* pos_fts, float* gpos,
+                        hipStream_t stream);
+
+/* graph_utils.py:129-144: per sample the visited nodes within `order` hops of cur[b], in first-visit order, as
+ * feature-store rows (B,R) (padding repeats the first row with live = 0) and their poses T_c2w (B,R,V*16);
+ * *overflow = 1 if a sample has more than R such nodes. */
+int bevbert_gm_bev_select(const bevbert_gm_state* st, const int* cur, int order, int R, int* rows, uint8_t* live,
+                          float* T_c2w, int* overflow, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ from vln_bevbert_amd import ops, synthetic  # noqa: E402
 from vln_bevbert_amd.config import BevBertConfig  # noqa: E402
 from vln_bevbert_amd.feature_store import GridFeatureStore  # noqa: E402
 from vln_bevbert_amd.graph_map import GraphMapBatch  # noqa: E402
+from vln_bevbert_amd.graph_map_dev import DeviceGraphMap  # noqa: E402
 from vln_bevbert_amd.nav_model import VLNBert  # noqa: E402
 from vln_bevbert_amd.nav_static import NavGraphRunner  # noqa: E402
 from vln_bevbert_amd.pretrain_cmt import bevpos_polar  # noqa: E402
@@ -44,6 +45,13 @@ def main():
     ap.add_argument("--no-graphs", action="store_true",
                     help="infer mode: issue the panorama / navigation forwards eagerly instead of replaying the captured "
                          "steps of nav_static.NavGraphRunner")
+    ap.add_argument("--map", default="device", choices=["device", "host"],
+                    help="device: graph_map_dev.DeviceGraphMap (maps, relaxation, hop counts, per-step tensors in HIP "
+                         "kernels); host: graph_map.GraphMapBatch (batched numpy, rounds 1-3)")
+    ap.add_argument("--feedback", action="store_true",
+                    help="read the fused logits back every step and pick the action on the host, as the agent does "
+                         "(map_nav_src/r2r/agent.py:520-560: nav_probs -> argmax -> .cpu().numpy()): the host's bookkeeping "
+                         "of step t+1 can then no longer hide behind the GPU work of step t")
     ap.add_argument("--check", action="store_true",
                     help="size-independent properties of the rollout instead of timing (tests/test_gpu_model.py): every step's "
                          "fused logits are finite or -inf, every live sample has a finite best action, a second rollout "
@@ -89,23 +97,35 @@ def main():
 
     trace = []
 
+    on_device = a.map == "device"
+    actions = []
+
     def episode():
-        gm = GraphMapBatch([ob["viewpoint"] for ob in obs_all[0]], cfg.hidden_size, dev, dtype=cdt)
-        gm.update_graph(obs_all[0])
+        start = [ob["viewpoint"] for ob in obs_all[0]]
+        gm = DeviceGraphMap(start, cfg.hidden_size, dev, dtype=cdt) if on_device else \
+            GraphMapBatch(start, cfg.hidden_size, dev, dtype=cdt)
+        if not on_device:
+            gm.update_graph(obs_all[0])
         txt = model("language", {"txt_ids": txt_ids, "txt_masks": txt_masks})
         loss = 0.0
         for t in range(T):
             obs, ended = obs_all[t], ended_all[t]
             h0 = time.perf_counter()
-            if t > 0:
-                gm.update_graph(obs, ended_all[t - 1])
-            gm.set_step_ids(obs, t, ended)
+            keys = [f"{ob['scan']}_{ob['viewpoint']}" for ob in obs]
+            if on_device:       # graph update + step ids + store rows / poses of the new viewpoints: one launch
+                gm.update_graph(obs, None if t == 0 else ended_all[t - 1], step_id=t + 1, step_ended=ended,
+                                store_rows=[store.row[k] for k in keys])
+            else:
+                if t > 0:
+                    gm.update_graph(obs, ended_all[t - 1])
+                gm.set_step_ids(obs, t, ended)
             t_book[0] += time.perf_counter() - h0
             pe, pm = runner.panorama(pano[t]) if use_graphs[0] else model("panorama", pano[t])
             avg = (pe * pm[..., None]).sum(1) / pm.sum(1, keepdim=True)                       # agent.py:478-479
             h0 = time.perf_counter()
             gm.update_node_embeds(obs, [[c["viewpointId"] for c in ob["candidate"]] for ob in obs], avg, pe, ended)
-            gm.remember_views(obs, [f"{ob['scan']}_{ob['viewpoint']}" for ob in obs], store, ended)
+            if not on_device:
+                gm.remember_views(obs, keys, store, ended)
             nav = gm.nav_gmap_variable(obs)
             bi = gm.bev_inputs(obs, store, pc_order=1, bev_dim=cfg.bev_dim, bev_res=cfg.bev_res)
             t_book[0] += time.perf_counter() - h0
@@ -119,6 +139,10 @@ def main():
                 "bev_cand_idxs": bi["bev_cand_idxs"], "bev_cand_vpids": bi["bev_cand_vpids"], "obj_embeds": None,
                 "obj_masks": None})
             out = runner.navigation(nav) if use_graphs[0] else model("navigation", nav)
+            if a.feedback:      # agent.py:520-560: the action is picked on the host from the logits of THIS step
+                probs = torch.softmax(out["fused_logits"].float(), 1)
+                a_t = probs.argmax(1).cpu().numpy()                     # device -> host: the step's synchronisation point
+                actions.append([nav["gmap_vpids"][i][int(k)] for i, k in enumerate(a_t)])
             if a.check:
                 trace.append(out["fused_logits"].float().clone())
             if a.mode == "train":       # teacher action: [stop] is always a valid target of the fused logits
@@ -197,8 +221,22 @@ def main():
         iteration(a.warmup + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
+    overflow = None
+    if on_device:
+        chk = DeviceGraphMap([ob["viewpoint"] for ob in obs_all[0]], cfg.hidden_size, dev, dtype=cdt)
+        for t in range(T):      # the neighbour bound of bev_inputs held on every step of these episodes
+            obs = obs_all[t]
+            chk.update_graph(obs, None if t == 0 else ended_all[t - 1], step_id=t + 1, step_ended=ended_all[t],
+                             store_rows=[store.row[f"{ob['scan']}_{ob['viewpoint']}"] for ob in obs])
+            chk.nav_gmap_variable(obs)
+            chk.bev_inputs(obs, store, pc_order=1, bev_dim=cfg.bev_dim, bev_res=cfg.bev_res)
+        overflow = chk.check_overflow()
     print(json.dumps({"workload": f"R2R fine-tune rollout, {a.mode}, batch {B}, {T} navigation steps, {a.dtype}, "
-                                  f"GraphMapBatch + resident grid-feature store ({store.nbytes() / 2 ** 30:.1f} GiB)",
+                                  f"{'DeviceGraphMap (maps on the device)' if on_device else 'GraphMapBatch (host numpy)'} + "
+                                  f"resident grid-feature store ({store.nbytes() / 2 ** 30:.1f} GiB)",
+                      "action_feedback": "logits read back and argmaxed on the host every step (agent.py:520-560)"
+                      if a.feedback else "none (cached trajectories, no device->host copy inside the episode)",
+                      "map": a.map, "neighbour_bound_overflow": overflow,
                       "ms_per_episode_batch": round(dt * 1e3, 2), "ms_per_nav_step": round(dt * 1e3 / T, 2),
                       "episodes_per_s": round(B / dt, 1), "nav_steps_per_s": round(B * T / dt, 1),
                       "host_map_bookkeeping_ms_per_nav_step": round(t_book[0] / a.iters / T * 1e3, 2),

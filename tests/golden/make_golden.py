@@ -362,6 +362,122 @@ def gen_autocast(ref, cfg):
 
 
 
+def _task_outputs(ref, cfg, B, seed, ragged):
+    """The forward tensors test_gpu_model._check_tasks compares, under whatever autocast state the caller set."""
+    out = {}
+    mk = lambda task: synthetic.make_batch(cfg, task, B, seed=seed, ragged=ragged)
+    with torch.no_grad():
+        out["mlm_loss"] = ref(dict(mk("mlm")), "mlm", True)
+        out["mlm_scores_sub"] = ref(dict(mk("mlm")), "mlm", False)
+        out["sap_loss"] = ref(dict(mk("sap")), "sap", True)
+        g, l, f = ref(dict(mk("sap")), "sap", False)[:3]
+        out.update(sap_global=g, sap_local=l, sap_fused=f)
+        rb = ref.lift_splat(dict(mk("sap")))
+        gm, bev, _, _ = ref.bert(*[rb.get(k) for k in CMT_ARGS])
+        out.update(gmap_embeds=gm, bev_embeds_sub=bev)
+        out["masksem_loss"] = ref(dict(mk("masksem")), "masksem", True)
+        out["masksem_logits"] = ref(dict(mk("masksem")), "masksem", False)[0]
+        for tok in ("sattn", "embed", "cattn"):
+            ref.sem_pred_token = tok
+            out[f"sem_{tok}_logits_sub"] = ref(dict(mk("sem")), "sem", False)[0]
+        ref.sem_pred_token = cfg.sem_pred_token
+    return {k: v.float() for k, v in out.items()}
+
+
+def _task_grads(ref, cfg, B, seed, ragged):
+    out = {}
+    for task in ("mlm", "sap", "masksem"):
+        ref.zero_grad(set_to_none=True)
+        b = synthetic.make_batch(cfg, task, B, seed=seed, ragged=ragged)
+        ref(dict(b), task, True).mean().backward()
+        for k, p in ref.named_parameters():
+            if p.grad is not None and k in GRAD_KEYS:
+                out[f"{task}_grad::{k}"] = sub(p.grad.float(), 97 if p.numel() > 4096 else 1)
+        out[f"{task}_grad_sqnorm"] = np.float64(sum(float((p.grad.double() ** 2).sum()) for p in ref.parameters()
+                                                    if p.grad is not None))
+    ref.zero_grad(set_to_none=True)
+    return out
+
+
+def _obj_outputs(ref, cfg, tasks, B, seed):
+    out = {}
+    with torch.no_grad():
+        for task in tasks:
+            b = synthetic.make_batch(cfg, task, B, seed=seed, ragged=True)
+            out[f"{task}_loss"] = ref(dict(b), task, True)
+            outs = ref(dict(b), task, False)
+            if task == "og":
+                out["og_logits"] = outs
+            elif task == "mrc":
+                out["mrc_pred"] = outs[0]
+            elif task == "sap":
+                out["sap_fused"] = outs[2]
+    return {k: v.float() for k, v in out.items()}
+
+
+def _obj_grads(ref, cfg, tasks, B, seed):
+    out = {}
+    for task in tasks:
+        ref.zero_grad(set_to_none=True)
+        b = synthetic.make_batch(cfg, task, B, seed=seed, ragged=True)
+        ref(dict(b), task, True).mean().backward()
+        for k, p in ref.named_parameters():
+            if p.grad is not None and k in OBJ_GRAD_KEYS:
+                out[f"{task}_grad::{k}"] = sub(p.grad.float(), 97 if p.numel() > 4096 else 1)
+        out[f"{task}_grad_sqnorm"] = np.float64(sum(float((p.grad.double() ** 2).sum()) for p in ref.parameters()
+                                                    if p.grad is not None))
+    ref.zero_grad(set_to_none=True)
+    return out
+
+
+def gen_autocast_errors(ref, cfg, tag, B, seed, ragged, arrs, obj_tasks=None):
+    """The yardstick of the bf16 parity gates: how far the REFERENCE's own autocast-bf16 run
+    (train_r2r.py:256-258 torch.cuda.amp.autocast; bf16 per BASELINE.json) sits from its fp32 run, per compared tensor --
+    forward outputs as max-abs / absmax and mean-abs / absmax, gradients of the named parameters as relative L2 over the
+    same sub-sampled entries the tests read.  The lift + splat is kept in fp32 on both sides (the product lifts in fp32;
+    under a whole-forward autocast the reference's bf16 point coordinates move points across cell borders and even the
+    set of supervised cells changes: that figure stays in ref_autocast_noise.npz)."""
+    print(f"reference autocast-bf16 vs fp32, per tensor [{tag}]")
+    orig = ref.lift_splat
+
+    def lift_fp32(batch):
+        with torch.autocast("cpu", enabled=False):
+            return orig(batch)
+    outputs = (lambda: _obj_outputs(ref, cfg, obj_tasks, B, seed)) if obj_tasks else \
+        (lambda: _task_outputs(ref, cfg, B, seed, ragged))
+    grads = (lambda: _obj_grads(ref, cfg, obj_tasks, B, seed)) if obj_tasks else \
+        (lambda: _task_grads(ref, cfg, B, seed, ragged))
+    want = outputs()
+    want_g = grads()
+    ref.lift_splat = lift_fp32
+    try:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            got = outputs()
+        # a context of its own: the weight casts cached by the no_grad forwards above carry no autograd history
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            got_g = grads()
+    finally:
+        del ref.lift_splat
+    for k, w in want.items():
+        w, gt = npy(w).astype(np.float64), npy(got[k]).astype(np.float64)
+        assert w.shape == gt.shape, (k, w.shape, gt.shape)
+        fin = np.isfinite(w) & np.isfinite(gt)
+        scale = max(1e-6, np.abs(w[fin]).max())
+        err = np.abs(w[fin] - gt[fin])
+        arrs[f"{tag}::{k}::max_rel"] = np.float64(err.max() / scale)
+        arrs[f"{tag}::{k}::mean_rel"] = np.float64(err.mean() / scale)
+        print(f"   {k:28s} max-abs/absmax {err.max() / scale:.3e}  mean-abs/absmax {err.mean() / scale:.3e}")
+    for k, w in want_g.items():
+        if k.endswith("_grad_sqnorm"):
+            arrs[f"{tag}::{k}::rel"] = np.float64(abs(got_g[k] - w) / w)
+            print(f"   {k:60s} rel {abs(got_g[k] - w) / w:.3e}")
+            continue
+        w, gt = np.asarray(w, dtype=np.float64), np.asarray(got_g[k], dtype=np.float64)
+        l2 = np.linalg.norm(gt - w) / max(1e-12, np.linalg.norm(w))
+        arrs[f"{tag}::{k}::rel_l2"] = np.float64(l2)
+        print(f"   {k:60s} rel-L2 {l2:.3e}")
+
+
 CURVE = dict(n_steps=100, batch=2, lr=1e-4, warmup=10, total=200, wd=0.01, betas=(0.9, 0.98), clip=5.0,
              ratio="mlm.5.sap.5.masksem.1", sampler_seed=1, batch_seed0=50)
 
@@ -691,6 +807,18 @@ def main():
             gen_modules(ref, tiny)
         if "--autocast" in sys.argv:
             gen_autocast(ref, tiny)
+            arrs = {}
+            gen_autocast_errors(ref, tiny, "tiny_b3_ragged", 3, 7, True, arrs)
+            gen_autocast_errors(ref, tiny, "tiny_b2_fixed", 2, 8, False, arrs)
+            rvr = BevBertConfig.tiny(image_feat_size=768, obj_feat_size=768, obj_prob_size=50,
+                                     pretrain_tasks=("mlm", "mrc", "sap", "og"))
+            gen_autocast_errors(build_ref_pretrain(rvr), rvr, "tiny_rvr", 4, 31, True, arrs, ("mlm", "mrc", "sap", "og"))
+            objlin = BevBertConfig.tiny(image_feat_size=512, obj_feat_size=640, obj_prob_size=50, num_l_layers=1,
+                                        num_x_layers=1, pretrain_tasks=("mrc", "og"))
+            gen_autocast_errors(build_ref_pretrain(objlin), objlin, "tiny_objlin", 4, 32, True, arrs, ("mrc", "og"))
+            full = BevBertConfig()
+            gen_autocast_errors(build_ref_pretrain(full), full, "r2r_b2", 2, 1000, False, arrs)
+            save("ref_autocast_errors", **arrs)
         return
 
     tiny = BevBertConfig.tiny()

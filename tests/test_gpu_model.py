@@ -16,12 +16,36 @@ DEV = "cuda"
 FP32_TOL = 1e-3          # north_star: "within 1e-3 fp32"
 
 
-BF16_MEAN_TOL = 1e-2     # north_star "1e-2 bf16": mean-abs error relative to the output's abs-max
-BF16_MAX_TOL = 2.5e-2    # and the worst element.  Achieved over the forward comparisons of this suite (MI355X): worst 2.1e-2
-#                          (SAP fused logits), typical 1e-2 -- the gate is the achieved worst plus a 20 % margin; the
-#                          reference's own CPU-autocast forward sits at 3.4e-2 on MLM scores
-#                          (tests/golden/ref_autocast_noise.npz).  Every comparison appends its achieved error to
-#                          gpurun_out/bf16_errors.jsonl (a copy of a full run: profiles/r03_bf16_errors_full_suite.jsonl).
+# ---- bf16 parity gates: the yardstick is the REFERENCE's own autocast-bf16 error, not the build's -------------------------
+# north_star: "within 1e-2 bf16".  tests/golden/ref_autocast_errors.npz (make_golden.py --autocast)
+# holds, for every tensor compared here, how far the reference's own autocast-bf16 run sits from its fp32 run on the same
+# batch (lift + splat in fp32 on both sides): forward outputs 0.4e-2 .. 1.6e-2 max-abs / absmax (sap_local, sap_fused and
+# masksem_logits are ABOVE 1e-2 in the reference itself), gradients 0.5e-2 .. 0.14 relative L2 (the SAP gradients are the
+# noisy ones there too).  A comparison passes when the product is within
+#     forward:   max-abs / absmax <= max(1e-2, REF_FACTOR x reference's own error of THAT tensor);  mean-abs / absmax <= 1e-2
+#     gradients: relative L2      <= max(BF16_GRAD_FLOOR, REF_FACTOR x reference's own error of that tensor)
+# REF_FACTOR = 2.5: the product rounds LayerNorm outputs and the residual stream to bf16 where torch.autocast keeps them in
+# fp32, i.e. a tensor passes through about twice as many roundings (measured ratio product / reference: 1.0 .. 2.0,
+# profiles/r04_bf16_errors_vs_reference_autocast.txt); 2.5 leaves the sampling noise of a maximum over a few hundred
+# entries.  Tensors of configurations without a reference autocast vector (RxR vocabulary, CE fork, fine-tune API) fall
+# back to the reference's WORST own error over all recorded tensors (forward 1.64e-2, gradients 0.142) x the same factor.
+BF16_MEAN_TOL = 1e-2
+REF_FACTOR = 2.5
+BF16_GRAD_FLOOR = 0.05
+_REF_ERR = None
+
+
+def _ref_err(tag, key, kind):
+    """The reference's own autocast error for (config tag, tensor key): kind 'max_rel' | 'mean_rel' | 'rel_l2'.  Unknown
+    tensor: the worst value over the file for that kind."""
+    global _REF_ERR
+    if _REF_ERR is None:
+        g = load_golden("ref_autocast_errors")
+        _REF_ERR = {k: float(g[k]) for k in g.files}
+    v = _REF_ERR.get(f"{tag}::{key}::{kind}")
+    if v is None:
+        v = max(x for k, x in _REF_ERR.items() if k.endswith("::" + kind) and "sprel_linear.bias" not in k)
+    return v
 
 
 def _record(kind, what, **vals):
@@ -37,42 +61,37 @@ def _record(kind, what, **vals):
         pass
 
 
-def bf16_close(got, want, what):
-    """north_star "1e-2 bf16", read as SURVEY section 7 fixes it: mean-abs error relative to the output's abs-max
-    <= 1e-2, and max-abs <= BF16_MAX_TOL * absmax; the achieved numbers go into the assertion message and the log."""
+def bf16_close(got, want, what, tag=None):
+    """Forward comparison in bf16 (see the block comment above); the achieved numbers and the reference's own go into the
+    assertion message and the log."""
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
     fin = np.isfinite(want)
     assert (np.isfinite(got) == fin).all(), what
     scale = max(1e-6, float(np.abs(want[fin]).max()))
     err = np.abs(got[fin] - want[fin])
-    _record("fwd", what, mean_rel=err.mean() / scale, max_rel=err.max() / scale)
-    assert err.mean() / scale < BF16_MEAN_TOL and err.max() / scale < BF16_MAX_TOL, \
-        (what, f"mean {err.mean() / scale:.3e} (tol {BF16_MEAN_TOL}) max {err.max() / scale:.3e} (tol {BF16_MAX_TOL})")
+    ref_max = _ref_err(tag, what, "max_rel")
+    gate = max(1e-2, REF_FACTOR * ref_max)
+    _record("fwd", f"{tag}::{what}", mean_rel=err.mean() / scale, max_rel=err.max() / scale, ref_max_rel=ref_max, gate=gate)
+    assert err.mean() / scale < BF16_MEAN_TOL and err.max() / scale < gate, \
+        (tag, what, f"mean {err.mean() / scale:.3e} (tol {BF16_MEAN_TOL}) max {err.max() / scale:.3e} "
+                    f"(gate {gate:.3e} = max(1e-2, {REF_FACTOR} x the reference's own {ref_max:.3e}))")
 
 
-BF16_GRAD_TOL = 0.18     # per-tensor relative L2 of bf16 gradients: achieved worst 0.15 + 20 % margin, median 0.03 ...
-BF16_GRAD_TOL_TINY_TABLES = 0.25     # ... except (a) tables of 2-3 rows (token / navigation type embeddings): every row is the sum
-#                                      of thousands of cancelling bf16-rounded token gradients, achieved worst 0.22 (OG task);
-#                                      (b) the word-embedding table behind the whole text encoder in the tiny OG model: a
-#                                      noise-dominated sum as well -- 0.152 with three roundings in the image-embedding sums,
-#                                      0.215 with one (bevbert_layernorm_post_fwd): the realisation moves with any upstream
-#                                      rounding change, the fp32 mode pins the same tensor to 2e-3
-TINY_TABLES = ("token_type_embeddings", "nav_type_embedding", "type_embedding", "word_embeddings")
-
-
-def bf16_grad_close(got, ref, what):
-    """bf16 gradients of single tensors: relative L2 error of the sampled entries.  Small gradients that are sums of
-    cancelling bf16-rounded paths (word embeddings behind the whole text encoder, 3-row type tables) sit at 0.1-0.25;
-    analytically-zero gradients (softmax shift invariance: sprel bias, the 1-wide head's bias) are checked absolutely.
-    The fp32 mode pins the same tensors to 2e-3, and the global gradient norm is checked separately."""
+def bf16_grad_close(got, ref, what, tag=None):
+    """bf16 gradients of single tensors: relative L2 error of the sampled entries against the reference's fp32 gradient,
+    gated by the reference's own autocast error for that tensor.  Analytically-zero gradients (softmax shift invariance:
+    sprel bias, the 1-wide head's bias) are checked absolutely.  The fp32 mode pins the same tensors to 2e-3, and the
+    global gradient norm is checked separately."""
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     if float(np.abs(ref).max()) < 1e-6:
         assert float(np.abs(got).max()) < 5e-2, (what, got)
         return
     l2 = float(np.linalg.norm(got - ref) / max(1e-12, np.linalg.norm(ref)))
-    _record("grad", what, rel_l2=l2)
-    tol = BF16_GRAD_TOL_TINY_TABLES if any(t in str(what) for t in TINY_TABLES) else BF16_GRAD_TOL
-    assert l2 < tol, (what, f"relative L2 {l2:.3e} (tol {tol})")
+    ref_l2 = _ref_err(tag, what, "rel_l2")
+    gate = max(BF16_GRAD_FLOOR, REF_FACTOR * ref_l2)
+    _record("grad", f"{tag}::{what}", rel_l2=l2, ref_rel_l2=ref_l2, gate=gate)
+    assert l2 < gate, (tag, what, f"relative L2 {l2:.3e} (gate {gate:.3e} = max({BF16_GRAD_FLOOR}, {REF_FACTOR} x the "
+                                  f"reference's own {ref_l2:.3e}))")
 
 
 @pytest.fixture(scope="module")
@@ -108,7 +127,7 @@ def _check_tasks(env, cfg, tag, keys_file, dtype, check_grads=False):
         if fp32:
             assert max_abs(got, ref) < FP32_TOL, (key, max_abs(got, ref))
         else:
-            bf16_close(got, ref, key)
+            bf16_close(got, ref, key, tag)
 
     mk = lambda task: synthetic.batch_to(synthetic.make_batch(cfg, task, B, seed=seed, ragged=ragged), DEV)
     with torch.no_grad():
@@ -147,7 +166,7 @@ def _check_tasks(env, cfg, tag, keys_file, dtype, check_grads=False):
                     if fp32:
                         assert max_abs(got, ref) < 2e-3 * scale + 1e-7, (gk, max_abs(got, ref), scale)
                     else:
-                        bf16_grad_close(got, ref, gk)
+                        bf16_grad_close(got, ref, gk, tag)
             # parameters the task does not use keep an exactly-zero gradient (find_unused_parameters semantics)
             used = {k[len(task) + 7:] for k in g.files if k.startswith(f"{task}_grad::")}
             assert len(used) > 0
@@ -198,7 +217,7 @@ def test_object_token_tasks(env, tag, kw, tasks, dtype):
         if fp32:
             assert max_abs(got, ref) < FP32_TOL, (what, max_abs(got, ref))
         else:
-            bf16_close(got, ref, what)
+            bf16_close(got, ref, what, tag)
 
     for task in tasks:
         b = synthetic.batch_to(synthetic.make_batch(cfg, task, B, seed=seed, ragged=True), DEV)
@@ -228,7 +247,7 @@ def test_object_token_tasks(env, tag, kw, tasks, dtype):
                 if fp32:
                     assert max_abs(got, ref) < 2e-3 * scale + 1e-7, (gk, max_abs(got, ref), scale)
                 else:
-                    bf16_grad_close(got, ref, gk)
+                    bf16_grad_close(got, ref, gk, tag)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -877,6 +896,117 @@ def test_finetune_bev_from_store_rows_of_visited_neighbours(env):
         # candidate cells feed bev_nav_masks; the centre cell is the [stop] token
         assert bool(bi["bev_nav_masks"][:, (K - 1) // 2].all())
     assert multi >= 2          # the walks did revisit neighbourhoods: several steps splat more than one panorama
+
+
+def _drive(gm, obs_all, ended_all, t, store, avg, pano, combined):
+    """One navigation step of the rollout loop (scripts/bench_nav.py) on a graph-map object."""
+    obs, ended = obs_all[t], ended_all[t]
+    keys = [f"{ob['scan']}_{ob['viewpoint']}" for ob in obs]
+    if combined:          # DeviceGraphMap: graph update + step ids + store rows in one launch
+        gm.update_graph(obs, None if t == 0 else ended_all[t - 1], step_id=t + 1, step_ended=ended,
+                        store_rows=[store.row[k] for k in keys])
+    else:
+        if t > 0:
+            gm.update_graph(obs, ended_all[t - 1])
+        gm.set_step_ids(obs, t, ended)
+        gm.remember_views(obs, keys, store, ended)
+    gm.update_node_embeds(obs, [[c["viewpointId"] for c in ob["candidate"]] for ob in obs], avg, pano, ended)
+    return gm.nav_gmap_variable(obs), gm.bev_inputs(obs, store, pc_order=1)
+
+
+@pytest.mark.parametrize("combined", [False, True])
+def test_device_graph_map_equals_the_host_graph_map(env, combined):
+    """f3 on the device: graph_map_dev.DeviceGraphMap (csrc/graph_nav.hip: batched min-plus relaxation, hop counts, pair
+    distances, position features, visited-neighbour choice) against graph_map.GraphMapBatch -- which is pinned bit for bit
+    to the reference's GraphMap / FloydGraph (tests/golden/graph_nav.npz, test_host_logic).  Integer tensors, f64
+    distances / next hops / hop counts and everything derived from them without transcendentals: EXACT.  Position
+    features (asin / sin / cos of the device math library): 2e-6."""
+    from vln_bevbert_amd.feature_store import GridFeatureStore
+    from vln_bevbert_amd.graph_map import GraphMapBatch
+    from vln_bevbert_amd.graph_map_dev import DeviceGraphMap
+    B, T, H, n_nodes = 6, 9, 16, 14
+    obs_all, ended_all = synthetic.make_nav_episodes(B, T, seed=31, n_nodes=n_nodes)
+    g = torch.Generator().manual_seed(31)
+    keys = [f"scan{i}_e{i}_v{n}" for i in range(B) for n in range(n_nodes)]
+    N = len(keys)
+    store = GridFeatureStore(keys, torch.randn(N, 12, 14, 14, 8, generator=g).half(), torch.rand(N, 12, 14, 14, generator=g),
+                             torch.zeros(N, 12, 14, 14, dtype=torch.uint8), DEV)
+    host = GraphMapBatch([ob["viewpoint"] for ob in obs_all[0]], H, DEV)
+    dev = DeviceGraphMap([ob["viewpoint"] for ob in obs_all[0]], H, DEV, node_capacity=8)      # 8: exercises growth
+    host.update_graph(obs_all[0])
+    if not combined:
+        dev.update_graph(obs_all[0])
+    multi = 0
+    for t in range(T):
+        avg = torch.randn(B, H, generator=g).to(DEV)
+        pano = torch.randn(B, 36, H, generator=g).to(DEV)
+        hn, hb = _drive(host, obs_all, ended_all, t, store, avg, pano, False)
+        dn, db = _drive(dev, obs_all, ended_all, t, store, avg, pano, combined)
+        torch.cuda.synchronize()
+        nm = int(host.n.max())
+        assert np.array_equal(dev.n, host.n) and dev.names == [ep.names for ep in host.eps]
+        assert np.array_equal(dev.t["dis"][:, :nm, :nm].cpu().numpy(), host.dis[:, :nm, :nm]), t          # f64, bit for bit
+        assert np.array_equal(dev.t["point"][:, :nm, :nm].cpu().numpy(), host.point[:, :nm, :nm]), t
+        hh = host.hops()
+        for b in range(B):
+            k = int(host.n[b])
+            assert np.array_equal(dev.t["hops"][b, :k, :k].cpu().numpy(), hh[b, :k, :k]), (t, b)
+        assert np.array_equal(dev.visited_host[:, :nm], host.visited[:, :nm])
+        assert np.array_equal(dev.t["visited"][:, :nm].cpu().numpy().astype(bool), host.visited[:, :nm])
+        assert dn["gmap_vpids"] == hn["gmap_vpids"] and dn["no_vp_left"] == hn["no_vp_left"]
+        for k in ("gmap_step_ids", "gmap_visited_masks", "gmap_masks", "gmap_pair_dists"):
+            assert torch.equal(dn[k], hn[k]), (t, k)
+        assert torch.equal(dn["gmap_visited_masks_cpu"], hn["gmap_visited_masks_cpu"])
+        assert float((dn["gmap_pos_fts"] - hn["gmap_pos_fts"]).abs().max()) <= 2e-6, t
+        assert torch.equal(dn["gmap_pos_fts"][..., 5:], hn["gmap_pos_fts"][..., 5:]), t       # graph distances / hops: exact
+        assert float((dn["gmap_img_embeds"] - hn["gmap_img_embeds"]).abs().max()) <= 1e-6, t
+        for k in ("grid_rows", "depths", "T_c2w", "T_w2c", "S_w2c", "bev_nav_masks", "bev_cand_idxs"):
+            assert torch.equal(db[k], hb[k]), (t, k)
+        assert db["bev_cand_vpids"] == hb["bev_cand_vpids"]
+        assert float((db["bev_gpos_fts"] - hb["bev_gpos_fts"]).abs().max()) <= 2e-6
+        multi += int(db["grid_rows"].shape[1] > 1)
+        for b in range(B):
+            cur = obs_all[t][b]["viewpoint"]
+            for vp in host.eps[b].names[:4]:
+                assert dev.path(b, cur, vp) == host.eps[b].path(cur, vp), (t, b, vp)
+    assert multi >= 2 and not dev.check_overflow()
+
+
+def test_device_graph_map_against_the_reference_golden(env):
+    """The same device-resident map against the vectors captured from the reference's GraphMap / FloydGraph themselves
+    (tests/golden/graph_nav.npz, as test_host_logic's host-side test): ids, step ids, visited masks and pair distances
+    exact, position features 2e-6, node embeddings 1e-6."""
+    import json
+    from vln_bevbert_amd.graph_map_dev import DeviceGraphMap
+    g = load_golden("graph_nav")
+    B, T, H, seed = int(g["B"]), int(g["T"]), int(g["H"]), int(g["seed"])
+    steps = json.loads(str(g["steps_json"]))
+    obs_all, ended_all = synthetic.make_nav_episodes(B, T, seed)
+    gm = DeviceGraphMap([ob["viewpoint"] for ob in obs_all[0]], H, DEV, node_capacity=4)
+    gm.update_graph(obs_all[0])
+    for t in range(T):
+        obs, ended, ref = obs_all[t], ended_all[t], steps[t]
+        if t > 0:
+            gm.update_graph(obs, ended_all[t - 1])
+        gm.set_step_ids(obs, t, ended)
+        avg, pano = torch.tensor(ref["avg"]).to(DEV), torch.tensor(ref["pano"]).to(DEV)
+        gm.update_node_embeds(obs, [[c["viewpointId"] for c in ob["candidate"]] for ob in obs], avg, pano, ended)
+        nv = gm.nav_gmap_variable(obs)
+        assert nv["gmap_vpids"] == ref["gmap_vpids"] and nv["no_vp_left"] == ref["no_vp_left"]
+        G = nv["gmap_img_embeds"].shape[1]
+        cpu = {k: v.cpu() for k, v in nv.items() if torch.is_tensor(v)}
+        for i in range(B):
+            n = len(ref["gmap_vpids"][i])
+            assert cpu["gmap_masks"][i].tolist() == [True] * n + [False] * (G - n)
+            assert cpu["gmap_step_ids"][i, :n].tolist() == ref["gmap_step_ids"][i]
+            assert cpu["gmap_visited_masks"][i, :n].long().tolist() == ref["gmap_visited_masks"][i]
+            assert np.array_equal(cpu["gmap_pair_dists"][i, :n, :n].numpy(), np.asarray(ref["gmap_pair_dists"][i], dtype=np.float32))
+            want = np.asarray(ref["gmap_pos_fts"][i], dtype=np.float32)
+            assert float(np.abs(cpu["gmap_pos_fts"][i, :n].numpy() - want).max()) <= 2e-6
+            assert float(cpu["gmap_pair_dists"][i, n:].abs().sum()) == 0 and float(cpu["gmap_pos_fts"][i, n:].abs().sum()) == 0
+            assert torch.allclose(cpu["gmap_img_embeds"][i, :n], torch.tensor(ref["gmap_img_embeds"][i]), rtol=0, atol=1e-6)
+            for vp, path in ref["paths"][i].items():
+                assert gm.path(i, obs[i]["viewpoint"], vp) == path
 
 
 def R_lift(bi, cfg):

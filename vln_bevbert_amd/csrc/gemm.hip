@@ -13,6 +13,8 @@
 // hipBLASLt is column-major, so the call is issued as C^T = op(B)^T . op(A)^T on the same memory.
 #include <hipblaslt/hipblaslt.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -34,6 +36,7 @@ struct Plan {
   int choice = -1, ncand = 0;   // index of the chosen candidate in the heuristic's list of `ncand` (tuning table)
   std::string key;
   bool ok = false, tuned = false, has_bias = false, accumulate = false;
+  bool verified = false;        // the chosen algorithm has passed the reproducibility screening (tune_plan)
 };
 
 hipblasLtHandle_t g_handle = nullptr;
@@ -134,7 +137,11 @@ int make_plan(const Problem& q, int64_t workspace_bytes, int autotune) {
     p.choice = -1;
   }
   if (p.ok) p.algo = p.cand[p.choice].algo;
-  if (p.tuned) { p.cand.clear(); p.cand.shrink_to_fit(); }
+  if (p.tuned && p.ncand <= 1) {      // nothing to choose from: the library's only algorithm is used as it is
+    p.verified = true;
+    p.cand.clear();
+    p.cand.shrink_to_fit();
+  }                                   // table rows keep their candidates until the first run has verified the choice
   p.id = (int)g_plan_list.size();
   Plan* stored = &g_plans.emplace(key, std::move(p)).first->second;   // unordered_map nodes are address-stable
   g_plan_list.push_back(stored);
@@ -145,12 +152,56 @@ int make_plan(const Problem& q, int64_t workspace_bytes, int autotune) {
   return stored->id;
 }
 
-// time the candidates once on the real operands and keep the fastest.  beta == 0: the product is simply recomputed in
-// place; accumulate plans are timed into a temporary so that C is not touched.
+// Order-independent checksum of a buffer (integer adds commute): two runs of a GEMM that differ in ANY output bit give
+// different sums.  Used to screen out library algorithms whose result depends on the order in which workgroups
+// accumulate (split-K / stream-K reductions through atomics): training on this path is bit-reproducible (DESIGN.md
+// section 2), and a single such kernel in the tuned table breaks that -- observed in round 4 as ~40 differing gradient
+// elements out of 238 M between two identical MLM steps on one box (the 30 522-deep decoder input-gradient GEMM).
+__global__ __launch_bounds__(256) void gemm_checksum_kernel(const uint32_t* __restrict__ p, size_t nwords,
+                                                            unsigned long long* __restrict__ out) {
+  unsigned long long h = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256)
+    h += (unsigned long long)p[i] * (0x9E3779B97F4A7C15ull ^ (unsigned long long)i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
+bool g_screen = true;          // BEVBERT_GEMM_DETERMINISTIC=0 turns the screening off (A/B)
+bool g_screen_read = false;
+
+// true when `reps` launches of the candidate leave the same bits in C.  C must be a buffer the launches may overwrite
+// (the real output for beta = 0 plans, a temporary for accumulating ones: it is zeroed before each launch).
+bool reproducible(Plan& p, const hipblasLtMatmulAlgo_t& algo, const void* A, const void* B, void* C, void* workspace,
+                  int64_t workspace_bytes, hipStream_t stream, unsigned long long* sums_dev, int reps = 3) {
+  const float alpha = 1.f, beta0 = p.accumulate ? 1.f : 0.f;
+  unsigned long long sums[4] = {0, 0, 0, 0};
+  (void)hipMemsetAsync(sums_dev, 0, sizeof(sums), stream);
+  for (int r = 0; r < reps; ++r) {
+    if (p.accumulate) (void)hipMemsetAsync(C, 0, p.c_bytes, stream);
+    if (hipblasLtMatmul(g_handle, p.desc, &alpha, B, p.la, A, p.lb, &beta0, C, p.lc, C, p.lc, &algo, workspace,
+                        workspace_bytes, stream) != HIPBLAS_STATUS_SUCCESS)
+      return false;
+    const size_t nwords = p.c_bytes / 4;
+    const int nb = (int)((nwords + 255) / 256 < 2048 ? (nwords + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gemm_checksum_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, stream, (const uint32_t*)C, nwords, sums_dev + r);
+  }
+  if (hipMemcpyAsync(sums, sums_dev, sizeof(sums), hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+  (void)hipStreamSynchronize(stream);
+  for (int r = 1; r < reps; ++r)
+    if (sums[r] != sums[0]) return false;
+  return true;
+}
+
+// time the candidates once on the real operands and keep the fastest REPRODUCIBLE one.  beta == 0: the product is simply
+// recomputed in place; accumulate plans are timed into a temporary so that C is not touched.
+int g_rejected = 0;             // candidates dropped by the screening so far (bevbert_gemm_rejected_count)
+
 void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, int64_t workspace_bytes,
-               hipStream_t stream) {
+               hipStream_t stream, int only = -1) {
   const float alpha = 1.f, beta0 = p.accumulate ? 1.f : 0.f;
   void* scratch = nullptr;
+  void* const C_real = C;
   // Time in isolation: the candidate list contains stream-K kernels whose workgroups spin on flags written by peer
   // workgroups.  Exercised while another stream holds part of the chip with a kernel of the same kind, two partially
   // resident grids can wait for each other's unscheduled peers (observed: a run with concurrent weight-gradient and
@@ -160,18 +211,28 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
   if (p.accumulate) {
     if (hipMalloc(&scratch, p.c_bytes) != hipSuccess || hipMemsetAsync(scratch, 0, p.c_bytes, stream) != hipSuccess) {
       if (scratch) (void)hipFree(scratch);
-      p.algo = p.cand[0].algo;      // cannot time: keep the heuristic's first choice
+      if (!p.tuned) p.algo = p.cand[0].algo;      // cannot time: keep the heuristic's first choice / the table's
       p.tuned = true;
+      p.verified = true;
       return;
     }
     C = scratch;
   }
+  if (!g_screen_read) {
+    const char* e = getenv("BEVBERT_GEMM_DETERMINISTIC");
+    g_screen = !(e != nullptr && e[0] == '0');
+    g_screen_read = true;
+  }
+  unsigned long long* sums_dev = nullptr;
+  if (g_screen && hipMalloc(&sums_dev, 4 * sizeof(unsigned long long)) != hipSuccess) sums_dev = nullptr;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   float best_ms = 1e30f;
   int best = -1;
+  std::vector<std::pair<float, int>> timed;
   for (size_t i = 0; i < p.cand.size(); ++i) {
+    if (only >= 0 && (int)i != only) continue;
     if (p.cand[i].state != HIPBLAS_STATUS_SUCCESS || (int64_t)p.cand[i].workspaceSize > workspace_bytes) continue;
     bool run_ok = true;
     for (int rep = 0; rep < 10 && run_ok; ++rep) {   // 2 warm-up + 8 timed launches per candidate
@@ -184,11 +245,35 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    if (ms < best_ms) { best_ms = ms; best = (int)i; }
+    timed.emplace_back(ms, (int)i);
   }
+  // fastest first; the first one whose output bits repeat wins (screening in this order costs three extra launches for
+  // the typical problem, whose fastest candidate is a plain data-parallel kernel)
+  std::sort(timed.begin(), timed.end());
+  for (const auto& t : timed) {
+    if (sums_dev != nullptr && !reproducible(p, p.cand[t.second].algo, A, B, C, workspace, workspace_bytes, stream, sums_dev)) {
+      ++g_rejected;
+      continue;
+    }
+    best_ms = t.first;
+    best = t.second;
+    break;
+  }
+  if (sums_dev) (void)hipFree(sums_dev);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (scratch) (void)hipFree(scratch);
+  if (only >= 0) {                // verification of a table row: keep it, or fall back to a full timing pass
+    if (best == only) {
+      p.verified = true;
+      p.cand.clear();
+      p.cand.shrink_to_fit();
+      return;
+    }
+    tune_plan(p, A, B, C_real, workspace, workspace_bytes, stream, -1);
+    return;
+  }
+  p.verified = true;
   p.tuned = true;
   if (best < 0) {                 // no candidate is usable (invalid state / workspace too small / launch failure)
     p.ok = false;
@@ -216,8 +301,10 @@ int run_plan(Plan& p, const void* A, const void* B, void* C, const void* bias, f
     bb_set_error("gemm: cannot set the bias pointer");
     return BB_ELAUNCH;
   }
-  if (!p.tuned) {
-    tune_plan(p, A, B, C, workspace, workspace_bytes, stream);
+  if (!p.tuned || !p.verified) {
+    // first use (never inside a graph capture: the warm-up steps come first): time the candidates -- or, for a choice
+    // imported from the shipped table, check that this algorithm's output bits repeat, else time them all
+    tune_plan(p, A, B, C, workspace, workspace_bytes, stream, p.tuned ? p.choice : -1);
     if (!p.ok) {
       bb_set_error("gemm: none of the library's candidates for plan %d can run", p.id);
       return BB_EUNSUPPORTED;
@@ -338,6 +425,12 @@ BEVBERT_API int bevbert_gemm_tuning_import(const char* text) {
     }
   }
   return n;
+}
+
+// candidates the reproducibility screening has rejected so far (algorithms whose output bits changed between launches)
+BEVBERT_API int bevbert_gemm_rejected_count(void) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  return g_rejected;
 }
 
 BEVBERT_API int bevbert_gemm_plan_count(void) {

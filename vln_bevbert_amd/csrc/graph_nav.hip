@@ -1,0 +1,256 @@
+// Fine-tune rollout bookkeeping on the device.
+//
+// The reference keeps one GraphMap per episode -- Python dicts and a dict-of-dicts Floyd graph
+// (map_nav_src/models/graph_utils.py:44-94,96-189) -- and rebuilds the navigation inputs of every step with nested Python
+// loops (map_nav_src/r2r/agent.py:194-337).  Here the B maps of a rollout are dense device arrays over a fixed node
+// capacity N, one workgroup per episode:
+//
+//   pos (B,N,3) f64 | dis (B,N,N) f64 | point (B,N,N) i32 (next hop, -1 = direct edge) | hops (B,N,N) i32
+//   visited (B,N) u8 | step_ids (B,N) i32 | pc_list (B,N) i32 + npc (B): visited nodes in first-visit order
+//   node_row (B,N) i32: feature-store row of a visited node | node_T (B,N,V,16) f32: its camera poses
+//
+// What the host still does is what is host data: viewpoint-id strings -> node indices, and the order in which the nodes of
+// a map are presented (it needs the id lists of that order anyway).  Everything numeric -- edge distances, the min-plus
+// relaxation through the current viewpoint, hop counts, pair distances, position features, the choice of the visited
+// 1-hop neighbours whose grid features feed the BEV -- happens here.  Integer and f64 add / compare / sqrt results are
+// bit-equal to the reference's Python floats: edge lengths arrive from the host (numpy float64, the reference's own
+// arithmetic), the device only adds and compares them.  The position features (sqrt / asin / sin / cos of the device math
+// library, no FMA contraction) are within 2 ulp of numpy's.
+#include "common.h"
+
+#define GM_INF 95959595.0      // graph_utils.py:46
+
+struct GmState {               // mirrors bevbert_gm_state (include/bevbert_hip.h)
+  double* pos;
+  double* dis;
+  int* point;
+  int* hops;
+  uint8_t* visited;
+  int* step_ids;
+  int* pc_list;
+  int* npc;
+  int* node_row;
+  float* node_T;
+  int B, N, V, pad;
+};
+
+// GraphMap.update_graph (graph_utils.py:109-115) + FloydGraph.add_edge / update (:55-72) for every live episode,
+// agent.py:471-474 (step ids), GraphMap.update_node_pc's bookkeeping (which store row / poses a visited node has), and the
+// hop counts len(FloydGraph.path(x, y)) of the new graph.
+__global__ __launch_bounds__(256) void gm_update_kernel(GmState s, const uint8_t* __restrict__ live_graph,
+                                                        const uint8_t* __restrict__ live_step, const int* __restrict__ cur,
+                                                        const int* __restrict__ ncand, const int* __restrict__ cand,
+                                                        const double* __restrict__ cur_pos, const double* __restrict__ cand_pos,
+                                                        const double* __restrict__ cand_dist,
+                                                        const int* __restrict__ n_nodes, int C, int step_id,
+                                                        const int* __restrict__ row, const float* __restrict__ T) {
+  const int b = blockIdx.x, tid = threadIdx.x, N = s.N;
+  const int k = cur[b], nb = n_nodes[b];
+  double* dis = s.dis + (size_t)b * N * N;
+  int* point = s.point + (size_t)b * N * N;
+  int* hops = s.hops + (size_t)b * N * N;
+  double* pos = s.pos + (size_t)b * N * 3;
+  if (live_graph[b]) {
+    if (tid < 3) pos[k * 3 + tid] = cur_pos[b * 3 + tid];
+    for (int j = tid; j < ncand[b]; j += 256) {
+      const int jn = cand[b * C + j];
+      const double* p = cand_pos + ((size_t)b * C + j) * 3;
+      pos[jn * 3] = p[0]; pos[jn * 3 + 1] = p[1]; pos[jn * 3 + 2] = p[2];
+      // edge length: computed by the host in float64 exactly as the reference does (graph_utils.py:8-13) -- the device
+      // math library's f64 sqrt is not guaranteed to round like numpy's, and every later distance is a SUM of these
+      const double d = cand_dist[(size_t)b * C + j];
+      if (d < dis[k * N + jn]) {
+        dis[k * N + jn] = d; dis[jn * N + k] = d;
+        point[k * N + jn] = -1; point[jn * N + k] = -1;
+      }
+    }
+    __syncthreads();
+    // relax every pair through k.  Row / column k cannot change (dis[k][k] stays "infinite"), so the pairs are independent
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+      const int i = idx / nb, j = idx - i * nb;
+      if (i == j) continue;
+      const double via = dis[i * N + k] + dis[k * N + j];
+      if (via < dis[i * N + j]) {
+        dis[i * N + j] = via;
+        point[i * N + j] = k;
+      }
+    }
+    if (tid == 0) s.visited[(size_t)b * N + k] = 1;
+  }
+  if (live_step[b]) {
+    if (tid == 0 && step_id > 0) s.step_ids[(size_t)b * N + k] = step_id;
+    if (row != nullptr && row[b] >= 0) {         // remember_views: store row + camera poses; first visit fixes the order
+      if (tid == 0) {
+        s.node_row[(size_t)b * N + k] = row[b];
+        const int np = s.npc[b];
+        bool seen = false;
+        for (int i = 0; i < np; ++i) seen |= s.pc_list[(size_t)b * N + i] == k;
+        if (!seen) {
+          s.pc_list[(size_t)b * N + np] = k;
+          s.npc[b] = np + 1;
+        }
+      }
+      for (int i = tid; i < s.V * 16; i += 256) s.node_T[((size_t)b * N + k) * s.V * 16 + i] = T[(size_t)b * s.V * 16 + i];
+    }
+  }
+  if (!live_graph[b]) return;
+  __syncthreads();
+  // hop counts from the next-hop table the way the reference's recursion reads it: path(x, y) = path(x, k) + path(k, y)
+  // with k = point[x][y]; a direct edge (or no known path) is one hop.  Bottom-up to the unique fixpoint.
+  for (int idx = tid; idx < nb * nb; idx += 256) {
+    const int i = idx / nb, j = idx - i * nb;
+    hops[i * N + j] = i == j ? 0 : (point[i * N + j] < 0 ? 1 : -1);
+  }
+  __syncthreads();
+  for (int round = 0; round <= nb; ++round) {
+    int pending = 0;
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+      const int i = idx / nb, j = idx - i * nb;
+      if (hops[i * N + j] >= 0) continue;
+      const int m = point[i * N + j];
+      const int a = ((volatile int*)hops)[i * N + m], c = ((volatile int*)hops)[m * N + j];
+      if (a >= 0 && c >= 0) hops[i * N + j] = a + c;
+      else pending = 1;
+    }
+    if (!__syncthreads_or(pending)) break;
+  }
+}
+
+// graph_utils.py:16-42,149-172 (calculate_vp_rel_pos_fts, get_angle_fts, get_pos_fts) for one (origin, target) pair
+__device__ __forceinline__ void gm_pos_fts(const double* __restrict__ pos, const double* __restrict__ dis,
+                                           const int* __restrict__ hops, int N, int cur, int tgt, double heading,
+                                           double elevation, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const double ax = pos[cur * 3], ay = pos[cur * 3 + 1], az = pos[cur * 3 + 2];
+  const double bx = pos[tgt * 3], by = pos[tgt * 3 + 1], bz = pos[tgt * 3 + 2];
+  const double dx = bx - ax, dy = by - ay, dz = bz - az;
+  const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  const double sxy = xx + yy;
+  const double xy = fmax(__dsqrt_rn(sxy), 1e-8), xyz = fmax(__dsqrt_rn(sxy + zz), 1e-8);
+  double h = asin(dx / xy);
+  if (by < ay) h = 3.141592653589793 - h;
+  h = h - heading;
+  const double e = asin(dz / xyz) - elevation;
+  const float hf = (float)h, ef = (float)e;
+  out[0] = sinf(hf); out[1] = cosf(hf); out[2] = sinf(ef); out[3] = cosf(ef);
+  const double gd = cur == tgt ? 0.0 : dis[cur * N + tgt];
+  out[4] = (float)(xyz / 30.0);
+  out[5] = (float)(gd / 30.0);
+  out[6] = (float)((double)hops[cur * N + tgt] / 10.0);
+}
+
+// agent.py:194-276 (_nav_gmap_variable) for the node order the host chose: row 0 is [stop], rows 1..cnt[b] the map nodes
+// node[b, 0..cnt[b]), the rest padding.  Also the position features of the start viewpoint (agent.py:326-331).
+__global__ __launch_bounds__(256) void gm_nav_vars_kernel(GmState s, const int* __restrict__ node, const int* __restrict__ cnt,
+                                                          const int* __restrict__ cur, const int* __restrict__ start,
+                                                          const double* __restrict__ heading,
+                                                          const double* __restrict__ elevation, int G, int enc_full_graph,
+                                                          int act_visited, int64_t* __restrict__ step_ids,
+                                                          uint8_t* __restrict__ visited, uint8_t* __restrict__ masks,
+                                                          float* __restrict__ pair, float* __restrict__ posf,
+                                                          float* __restrict__ gpos) {
+  const int b = blockIdx.x, tid = threadIdx.x, N = s.N, G1 = G - 1;
+  const double* dis = s.dis + (size_t)b * N * N;
+  const int* hops = s.hops + (size_t)b * N * N;
+  const double* pos = s.pos + (size_t)b * N * 3;
+  const int c = cnt[b], k = cur[b];
+  const int* nd = node + (size_t)b * G1;
+  for (int j = tid; j < G; j += 256) {
+    const bool real = j >= 1 && j - 1 < c;
+    const int m = real ? nd[j - 1] : 0;
+    masks[(size_t)b * G + j] = j < c + 1;
+    const bool vis = act_visited ? m == k : s.visited[(size_t)b * N + m] != 0;
+    visited[(size_t)b * G + j] = real && enc_full_graph && vis;
+    step_ids[(size_t)b * G + j] = real ? s.step_ids[(size_t)b * N + m] : 0;
+    float* o = posf + ((size_t)b * G + j) * 7;
+    if (real) gm_pos_fts(pos, dis, hops, N, k, m, heading[b], elevation[b], o);
+    else {
+      const float on = j < c + 1 ? 1.f : 0.f;       // [stop]: angle features of (0, 0); padding: zeros
+      o[0] = 0.f; o[1] = on; o[2] = 0.f; o[3] = on; o[4] = 0.f; o[5] = 0.f; o[6] = 0.f;
+    }
+  }
+  for (int idx = tid; idx < G * G; idx += 256) {
+    const int i = idx / G, j = idx - i * G;
+    float v = 0.f;
+    if (i >= 1 && j >= 1 && i - 1 < c && j - 1 < c && i != j) v = (float)(dis[nd[i - 1] * N + nd[j - 1]] / 30.0);
+    pair[(size_t)b * G * G + idx] = v;
+  }
+  if (tid == 0 && gpos != nullptr) gm_pos_fts(pos, dis, hops, N, k, start[b], heading[b], elevation[b], gpos + (size_t)b * 7);
+}
+
+// GraphMap.gather_node_pc's node selection (graph_utils.py:129-144): the visited nodes within `order` hops of the current
+// viewpoint, in first-visit order; rows padded to R by repeating the first row with live = 0.
+__global__ __launch_bounds__(64) void gm_bev_select_kernel(GmState s, const int* __restrict__ cur, int order, int R,
+                                                           int* __restrict__ rows, uint8_t* __restrict__ live,
+                                                           float* __restrict__ T_c2w, int* __restrict__ overflow) {
+  const int b = blockIdx.x, lane = threadIdx.x, N = s.N, k = cur[b], TV = s.V * 16;
+  __shared__ int sel[64], s_n;
+  const int* hops = s.hops + (size_t)b * N * N;
+  const int np = s.npc[b];
+  int n = 0;
+  for (int base = 0; base < np; base += 64) {
+    const int i = base + lane;
+    const int c = i < np ? s.pc_list[(size_t)b * N + i] : -1;
+    const bool take = c >= 0 && (order == 0 ? c == k : hops[k * N + c] <= order);
+    const unsigned long long bal = __ballot(take);
+    const int at = n + __popcll(bal & ((1ull << lane) - 1ull));
+    if (take && at < 64 && at < R) sel[at] = c;
+    n += __popcll(bal);
+  }
+  if (lane == 0) {
+    if (n > R || n > 64) *overflow = 1;
+    s_n = min(n, min(R, 64));
+  }
+  __syncthreads();
+  n = s_n;
+  const int first = n > 0 ? s.node_row[(size_t)b * N + sel[0]] : 0;
+  for (int r = lane; r < R; r += 64) {
+    rows[(size_t)b * R + r] = r < n ? s.node_row[(size_t)b * N + sel[r]] : first;
+    live[(size_t)b * R + r] = r < n;
+  }
+  for (int r = 0; r < R; ++r) {
+    const float* src = r < n ? s.node_T + ((size_t)b * N + sel[r]) * TV : nullptr;
+    for (int i = lane; i < TV; i += 64) T_c2w[((size_t)b * R + r) * TV + i] = src ? src[i] : 0.f;
+  }
+}
+
+static int gm_check(const GmState* st, const char* what) {
+  BB_REQUIRE(st != nullptr && st->B > 0 && st->N > 0 && st->V > 0, "%s: empty graph-map state", what);
+  BB_REQUIRE(st->pos && st->dis && st->point && st->hops && st->visited && st->step_ids, "%s: null state array", what);
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_gm_update(const GmState* st, const uint8_t* live_graph, const uint8_t* live_step, const int* cur,
+                                  const int* ncand, const int* cand, const double* cur_pos, const double* cand_pos,
+                                  const double* cand_dist, const int* n_nodes, int C, int step_id, const int* row,
+                                  const float* T, hipStream_t stream) {
+  if (int rc = gm_check(st, "gm_update")) return rc;
+  BB_REQUIRE(row == nullptr || (T != nullptr && st->pc_list && st->npc && st->node_row && st->node_T),
+             "gm_update: store rows need the pose table and the visit list");
+  hipLaunchKernelGGL(gm_update_kernel, dim3(st->B), dim3(256), 0, stream, *st, live_graph, live_step, cur, ncand, cand,
+                     cur_pos, cand_pos, cand_dist, n_nodes, C, step_id, row, T);
+  BB_CHECK_LAUNCH("gm_update");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_gm_nav_vars(const GmState* st, const int* node, const int* cnt, const int* cur, const int* start,
+                                    const double* heading, const double* elevation, int G, int enc_full_graph,
+                                    int act_visited, int64_t* step_ids, uint8_t* visited, uint8_t* masks, float* pair,
+                                    float* pos_fts, float* gpos, hipStream_t stream) {
+  if (int rc = gm_check(st, "gm_nav_vars")) return rc;
+  BB_REQUIRE(G >= 1, "gm_nav_vars: G=%d", G);
+  hipLaunchKernelGGL(gm_nav_vars_kernel, dim3(st->B), dim3(256), 0, stream, *st, node, cnt, cur, start, heading, elevation,
+                     G, enc_full_graph, act_visited, step_ids, visited, masks, pair, pos_fts, gpos);
+  BB_CHECK_LAUNCH("gm_nav_vars");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_gm_bev_select(const GmState* st, const int* cur, int order, int R, int* rows, uint8_t* live,
+                                      float* T_c2w, int* overflow, hipStream_t stream) {
+  if (int rc = gm_check(st, "gm_bev_select")) return rc;
+  BB_REQUIRE(R >= 1 && R <= 64, "gm_bev_select: R=%d outside 1..64", R);
+  BB_REQUIRE(st->pc_list && st->npc && st->node_row && st->node_T, "gm_bev_select: no visit list in the state");
+  hipLaunchKernelGGL(gm_bev_select_kernel, dim3(st->B), dim3(64), 0, stream, *st, cur, order, R, rows, live, T_c2w, overflow);
+  BB_CHECK_LAUNCH("gm_bev_select");
+  return BB_OK;
+}

@@ -1,0 +1,361 @@
+"""Fine-tune rollout bookkeeping with the maps ON THE DEVICE (csrc/graph_nav.hip).
+
+``graph_map.GraphMapBatch`` (rounds 1-3) keeps the B topological maps of a rollout as batched numpy arrays on the host:
+2.8 ms of host time per navigation step at batch 32, three quarters of the step once the two model calls are replayed
+from hipGraphs.  ``DeviceGraphMap`` has the same interface, but the maps -- node positions, Floyd distance / next-hop
+matrices, hop counts, visited flags, step ids, the visit-ordered list of nodes whose grid features feed the BEV, their
+feature-store rows and camera poses, the running-mean node embeddings -- are device arrays updated by three kernels:
+
+    update_graph / set_step_ids / remember_views  -> bevbert_gm_update     (edges, min-plus relaxation, hop counts, ...)
+    nav_gmap_variable                             -> bevbert_gm_nav_vars   (pair distances, position features, masks)
+    bev_inputs                                    -> bevbert_gm_bev_select (visited 1-hop neighbours -> store rows, poses)
+
+The host keeps what is host data in the reference too (map_nav_src/r2r/agent.py:194-337 works on viewpoint-id strings):
+the id -> node-index dictionaries, a visited-flag mirror and the observed adjacency (both fall out of the id lookups),
+from which it derives the presentation order of the nodes (visited first) and the id lists the agent needs back.  Every
+builder ships its small index arrays in ONE pinned copy (graph_map.HostFeed).  Integer results and f64 distances are
+bit-equal to ``GraphMapBatch`` (hence to the reference's GraphMap, golden graph_nav.npz); the sin / cos / asin of the
+position features come from the device math library (<= 2 ulp).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib
+from .graph_map import _INF, GraphMapBatch, HostFeed, pose_matrix
+
+
+class _GmState(ctypes.Structure):
+    """bevbert_gm_state (include/bevbert_hip.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("pos", "dis", "point", "hops", "visited", "step_ids", "pc_list", "npc",
+                                                "node_row", "node_T")] + [(n, ctypes.c_int) for n in ("B", "N", "V", "pad")]
+
+
+class DeviceGraphMap:
+    """Drop-in for GraphMapBatch in the rollout loop (scripts/bench_nav.py, the agent): same calls, same outputs."""
+
+    def __init__(self, start_vps, hidden_size, device, dtype=torch.float32, node_capacity=64, views=12):
+        self.B, self.H, self.device, self.dtype = len(start_vps), hidden_size, torch.device(device), dtype
+        if self.device.type != "cuda":
+            raise lib.BevBertHipError("DeviceGraphMap keeps the maps in device memory: it needs the MI355X "
+                                      "(graph_map.GraphMapBatch is the host-side form)")
+        self.V = views
+        self.start_vps = list(start_vps)
+        self.index = [{} for _ in range(self.B)]          # viewpoint id -> node index (registration order)
+        self.names = [[] for _ in range(self.B)]
+        self.adj = [{} for _ in range(self.B)]            # node -> set of nodes it was observed next to
+        self.n = np.zeros(self.B, dtype=np.int32)
+        self.N = 0
+        self._alloc(node_capacity)
+        self._overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._last = None                                 # (obs object, resolved arrays) of the latest _resolve
+        self._point_host = None
+
+    # -- storage -------------------------------------------------------------------------------------------------------
+    def _alloc(self, N):
+        B, dev, old = self.B, self.device, self.N
+        new = {
+            "pos": torch.zeros(B, N, 3, dtype=torch.float64, device=dev),
+            "dis": torch.full((B, N, N), float(_INF), dtype=torch.float64, device=dev),
+            "point": torch.full((B, N, N), -1, dtype=torch.int32, device=dev),
+            "hops": torch.zeros(B, N, N, dtype=torch.int32, device=dev),
+            "visited": torch.zeros(B, N, dtype=torch.uint8, device=dev),
+            "step_ids": torch.zeros(B, N, dtype=torch.int32, device=dev),
+            "pc_list": torch.zeros(B, N, dtype=torch.int32, device=dev),
+            "npc": torch.zeros(B, dtype=torch.int32, device=dev),
+            "node_row": torch.zeros(B, N, dtype=torch.int32, device=dev),
+            "node_T": torch.zeros(B, N, self.V * 16, dtype=torch.float32, device=dev),
+            "embed_sum": torch.zeros(B, N, self.H, dtype=self.dtype, device=dev),
+            "embed_cnt": torch.zeros(B, N, dtype=torch.float32, device=dev),
+        }
+        vis_host = np.zeros((B, N), dtype=bool)
+        if old:                                           # growth (rare: capacity 64 covers 15-step R2R episodes)
+            for k in ("dis", "point", "hops"):
+                new[k][:, :old, :old] = self.t[k]
+            for k in ("pos", "visited", "step_ids", "pc_list", "node_row", "node_T", "embed_sum", "embed_cnt"):
+                new[k][:, :old] = self.t[k]
+            new["npc"].copy_(self.t["npc"])
+            vis_host[:, :old] = self.visited_host
+        self.t, self.N, self.visited_host = new, N, vis_host
+        st = _GmState()
+        for k in ("pos", "dis", "point", "hops", "visited", "step_ids", "pc_list", "npc", "node_row", "node_T"):
+            setattr(st, k, new[k].data_ptr())
+        st.B, st.N, st.V, st.pad = B, N, self.V, 0
+        self.state = st
+        self._st_ptr = ctypes.addressof(st)
+
+    embed_sum = property(lambda self: self.t["embed_sum"])
+    embed_cnt = property(lambda self: self.t["embed_cnt"])
+
+    @property
+    def feed(self):
+        return HostFeed.shared(self.device)
+
+    # -- viewpoint ids -> node indices (the only per-sample Python) -----------------------------------------------------
+    def _node(self, b, vp):
+        idx = self.index[b]
+        i = idx.get(vp)
+        if i is None:
+            i = idx[vp] = len(idx)
+            self.names[b].append(vp)
+            self.n[b] = i + 1
+        return i
+
+    def _resolve(self, obs, register, ended=None):
+        """(cur (B,), cand (B,C) node indices padded with -1, ncand (B,)) of a step's observations.  ``register``: new
+        ids of live samples become nodes (update_graph); otherwise unknown candidate ids resolve to -1."""
+        B = self.B
+        last = self._last
+        if last is not None and last[0] is obs and not register:
+            return last[1]
+        C = max(1, max(len(ob["candidate"]) for ob in obs))
+        cur = np.zeros(B, dtype=np.int32)
+        cand = np.full((B, C), -1, dtype=np.int32)
+        ncand = np.zeros(B, dtype=np.int32)
+        for b, ob in enumerate(obs):
+            live = register and not (ended is not None and ended[b])
+            idx = self.index[b]
+            if live:
+                k = cur[b] = self._node(b, ob["viewpoint"])
+                cc = ob["candidate"]
+                ncand[b] = len(cc)
+                a = self.adj[b].setdefault(k, set())
+                for j, c in enumerate(cc):
+                    m = cand[b, j] = self._node(b, c["viewpointId"])
+                    a.add(m)
+                    self.adj[b].setdefault(m, set()).add(k)
+            else:
+                cur[b] = idx[ob["viewpoint"]]
+                cc = ob["candidate"]
+                ncand[b] = len(cc)
+                for j, c in enumerate(cc):
+                    cand[b, j] = idx.get(c["viewpointId"], -1)
+        out = (cur, cand, ncand)
+        self._last = (obs, out)
+        return out
+
+    # -- graph structure -----------------------------------------------------------------------------------------------
+    def update_graph(self, obs, ended=None, step_id=0, step_ended=None, store_rows=None):
+        """GraphMap.update_graph for every live episode (graph_utils.py:109-115; agent.py:447-449,556-559) -- and, in the
+        same launch when asked, agent.py:471-474 (``step_id`` = t + 1 for the samples not in ``step_ended``) and the
+        bookkeeping of GraphMap.update_node_pc (``store_rows``: feature-store row of each sample's viewpoint)."""
+        B = self.B
+        cur, cand, ncand = self._resolve(obs, True, ended)
+        if int(self.n.max()) > self.N:
+            self._alloc(max(2 * self.N, int(self.n.max())))
+        live_g = np.ones(B, dtype=np.uint8) if ended is None else (~np.asarray(ended, dtype=bool)).astype(np.uint8)
+        self.visited_host[np.nonzero(live_g)[0], cur[live_g.astype(bool)]] = True
+        self._point_host = None
+        self._launch_update(obs, cur, cand, ncand, live_g, np.zeros(B, dtype=np.uint8) if step_id <= 0 else
+                            self._live(step_ended), step_id, store_rows)
+
+    @staticmethod
+    def _live_of(ended, B):
+        return np.ones(B, dtype=np.uint8) if ended is None else (~np.asarray(ended, dtype=bool)).astype(np.uint8)
+
+    def _live(self, ended):
+        return self._live_of(ended, self.B)
+
+    def _launch_update(self, obs, cur, cand, ncand, live_g, live_s, step_id, store_rows):
+        B, C = cand.shape
+        cur_pos = np.asarray([ob["position"] for ob in obs], dtype=np.float64).reshape(B, 3)
+        cand_pos = np.zeros((B, C, 3), dtype=np.float64)
+        flat = [c["position"] for ob in obs for c in ob["candidate"]]
+        if flat:
+            bi = np.repeat(np.arange(B), [len(ob["candidate"]) for ob in obs])
+            ji = np.concatenate([np.arange(len(ob["candidate"])) for ob in obs])
+            cand_pos[bi, ji] = np.asarray(flat, dtype=np.float64)
+        d = cand_pos - cur_pos[:, None]             # edge lengths in float64, the reference's arithmetic (graph_utils.py:8-13)
+        cand_dist = np.sqrt(d[..., 0] ** 2 + d[..., 1] ** 2 + d[..., 2] ** 2)
+        arrays = {"live_g": live_g, "live_s": live_s, "cur": cur, "ncand": np.where(live_g > 0, ncand, 0).astype(np.int32),
+                  "cand": np.maximum(cand, 0), "cur_pos": cur_pos, "cand_pos": cand_pos, "cand_dist": cand_dist,
+                  "n": self.n.copy()}
+        if store_rows is not None:
+            arrays["row"] = np.where(live_s > 0, np.asarray(store_rows, dtype=np.int32), -1).astype(np.int32)
+            arrays["T"] = self._poses(obs)
+        up = self.feed(arrays)
+        lib.call("bevbert_gm_update", self._st_ptr, up["live_g"].data_ptr(), up["live_s"].data_ptr(), up["cur"].data_ptr(),
+                 up["ncand"].data_ptr(), up["cand"].data_ptr(), up["cur_pos"].data_ptr(), up["cand_pos"].data_ptr(),
+                 up["cand_dist"].data_ptr(), up["n"].data_ptr(), C, int(step_id), up["row"].data_ptr() if store_rows is not None else None,
+                 up["T"].data_ptr() if store_rows is not None else None, lib.stream())
+
+    def set_step_ids(self, obs, t, ended=None):
+        """agent.py:471-474 as its own call (the rollout loop of the reference sets them at the top of a step)."""
+        cur, cand, ncand = self._resolve(obs, False)
+        z = np.zeros(self.B, dtype=np.uint8)
+        self._launch_update(obs, cur, cand, ncand, z, self._live(ended), t + 1, None)
+
+    def _poses(self, obs):
+        """agent.py:114-126: the 12 camera-to-world matrices of a panorama -- position (x, z, -y), heading
+        -(k * 30 deg + heading), elevation pi -- in float64, cast to fp32 like the agent's."""
+        V = self.V
+        xyzhe = np.zeros((self.B, V, 5))
+        p = np.asarray([ob["position"] for ob in obs], dtype=np.float64)
+        xyzhe[:, :, 0], xyzhe[:, :, 1], xyzhe[:, :, 2] = p[:, None, 0], p[:, None, 2], -p[:, None, 1]
+        hd = np.asarray([ob["heading"] for ob in obs], dtype=np.float64)
+        xyzhe[:, :, 3] = -(np.arange(V)[None] * np.radians(30) + hd[:, None])
+        xyzhe[:, :, 4] = np.pi
+        return pose_matrix(xyzhe.reshape(-1, 5)).reshape(self.B, V * 16).astype(np.float32)
+
+    def remember_views(self, obs, store_keys, store, ended=None, views=12):
+        """GraphMap.update_node_pc's bookkeeping (agent.py:488): a visited node keeps its feature-store row and poses."""
+        assert views == self.V
+        cur, cand, ncand = self._resolve(obs, False)
+        rows = np.asarray([store.row[k] for k in store_keys], dtype=np.int32)
+        self._launch_update(obs, cur, cand, ncand, np.zeros(self.B, dtype=np.uint8), self._live(ended), 0, rows)
+
+    # -- node embeddings -----------------------------------------------------------------------------------------------
+    def update_node_embeds(self, obs, cand_vpids, avg_pano_embeds, pano_embeds, ended=None):
+        """agent.py:485-494 for the whole batch (as GraphMapBatch.update_node_embeds; the slot of a node is its index)."""
+        cur, cand, ncand = self._resolve(obs, False)
+        live = self._live(ended).astype(bool)
+        rb = np.nonzero(live)[0]
+        if not len(rb):
+            return
+        valid = (np.arange(cand.shape[1])[None] < ncand[:, None]) & (cand >= 0) & live[:, None]
+        unvis = valid & ~self.visited_host[np.arange(self.B)[:, None], np.maximum(cand, 0)]
+        ab, aj = np.nonzero(unvis)
+        ix = self.feed({"rb": rb.astype(np.int64), "rs": cur[rb].astype(np.int64), "ab": ab.astype(np.int64),
+                        "as": cand[ab, aj].astype(np.int64), "aj": aj.astype(np.int64)})
+        t = self.t
+        rb_t, rs_t = ix["rb"], ix["rs"]
+        t["embed_sum"] = t["embed_sum"].index_put((rb_t, rs_t), avg_pano_embeds[rb_t].to(self.dtype))
+        t["embed_cnt"] = t["embed_cnt"].index_put((rb_t, rs_t), torch.ones(len(rb), device=self.device))
+        if len(ab):
+            ab_t, as_t, aj_t = ix["ab"], ix["as"], ix["aj"]
+            t["embed_sum"] = t["embed_sum"].index_put((ab_t, as_t), pano_embeds[ab_t, aj_t].to(self.dtype), accumulate=True)
+            t["embed_cnt"] = t["embed_cnt"].index_put((ab_t, as_t), torch.ones(len(ab), device=self.device),
+                                                      accumulate=True)
+
+    # -- per-step navigation inputs ------------------------------------------------------------------------------------
+    def nav_gmap_variable(self, obs, enc_full_graph=True, act_visited_nodes=False, angle_feat_size=4):
+        """agent.py:194-276: [stop] + map nodes per sample (visited first, each group in registration order), padded to
+        the batch maximum.  The host chooses the order (it must return the id lists in that order); the tensors are
+        built on the device."""
+        assert angle_feat_size == 4
+        B, n = self.B, self.n.astype(np.int64)
+        nm = max(1, int(n.max()))
+        cur, _, _ = self._resolve(obs, False)
+        col = np.arange(nm)
+        valid = col[None] < n[:, None]
+        vis = (col[None] == cur[:, None]) if act_visited_nodes else self.visited_host[:, :nm]
+        vis = vis & valid
+        key = np.where(valid, np.where(vis, 0, 1), 2) * nm + col[None]
+        order = np.argsort(key, axis=1, kind="stable")
+        nvis = vis.sum(1)
+        first = np.zeros(B, dtype=np.int64) if enc_full_graph else nvis
+        cnt = n - first
+        G = 1 + int(cnt.max())
+        j = np.arange(G - 1)
+        real = j[None] < cnt[:, None]
+        node = np.take_along_axis(order, np.minimum(first[:, None] + j[None], nm - 1), axis=1) if G > 1 else \
+            np.zeros((B, 0), dtype=np.int64)
+        node = np.where(real, node, 0)
+        visited = np.zeros((B, G), dtype=bool)
+        if enc_full_graph and G > 1:
+            visited[:, 1:] = vis[np.arange(B)[:, None], node] & real
+        names = self.names
+        vpids = [[None] + [names[b][k] for k in node[b, :cnt[b]]] for b in range(B)]
+        start = np.asarray([self.index[b][self.start_vps[b]] for b in range(B)], dtype=np.int32)
+        up = self.feed({"node": np.ascontiguousarray(node, dtype=np.int32) if G > 1 else np.zeros((B, 1), np.int32),
+                        "cnt": cnt.astype(np.int32), "cur": cur, "start": start,
+                        "heading": np.asarray([ob["heading"] for ob in obs], dtype=np.float64),
+                        "elevation": np.asarray([ob["elevation"] for ob in obs], dtype=np.float64)})
+        dev = self.device
+        step_ids = torch.empty(B, G, dtype=torch.int64, device=dev)
+        vis_t = torch.empty(B, G, dtype=torch.bool, device=dev)
+        masks = torch.empty(B, G, dtype=torch.bool, device=dev)
+        pair = torch.empty(B, G, G, dtype=torch.float32, device=dev)
+        pos = torch.empty(B, G, 7, dtype=torch.float32, device=dev)
+        gpos = torch.empty(B, 7, dtype=torch.float32, device=dev)
+        lib.call("bevbert_gm_nav_vars", self._st_ptr, up["node"].data_ptr(), up["cnt"].data_ptr(), up["cur"].data_ptr(),
+                 up["start"].data_ptr(), up["heading"].data_ptr(), up["elevation"].data_ptr(), G, int(enc_full_graph),
+                 int(act_visited_nodes), step_ids.data_ptr(), vis_t.data_ptr(), masks.data_ptr(), pair.data_ptr(),
+                 pos.data_ptr(), gpos.data_ptr(), lib.stream())
+        self._gpos = (obs, gpos)
+        # running-mean node embeddings of the listed nodes ([stop] / padding rows = 0)
+        if G > 1:
+            nd = up["node"].long()
+            bt = torch.arange(B, device=dev)[:, None].expand(-1, G - 1)
+            c = self.t["embed_cnt"][bt, nd]
+            ok = (masks[:, 1:] & (c > 0)).to(self.dtype)
+            e = (self.t["embed_sum"][bt, nd] / c.clamp(min=1.0).to(self.dtype)[..., None]) * ok[..., None]
+            embeds = torch.cat([e.new_zeros(B, 1, self.H), e], 1)
+        else:
+            embeds = torch.zeros(B, 1, self.H, dtype=self.dtype, device=dev)
+        return {"gmap_vpids": vpids, "gmap_img_embeds": embeds, "gmap_step_ids": step_ids, "gmap_pos_fts": pos,
+                "gmap_visited_masks": vis_t, "gmap_visited_masks_cpu": torch.from_numpy(visited),
+                "gmap_pair_dists": pair, "gmap_masks": masks, "no_vp_left": [bool(x) for x in (n - nvis) == 0]}
+
+    # -- BEV inputs ----------------------------------------------------------------------------------------------------
+    def _neighbour_bound(self, cur, order):
+        """Host-side upper bound on the number of visited nodes within ``order`` hops of the current viewpoints.  One
+        hop: the node itself + the visited nodes it was observed next to (a direct edge is the shortest path between two
+        viewpoints: edge lengths are Euclidean distances).  The kernel makes the exact choice from the hop counts and
+        raises ``overflow`` should a map ever hold more (checked by ``check_overflow``)."""
+        if order == 0:
+            return 1
+        if order > 1:
+            return max(1, int(self.visited_host.sum(1).max()))
+        r = 1
+        for b in range(self.B):
+            vh = self.visited_host[b]
+            r = max(r, 1 + sum(1 for m in self.adj[b].get(int(cur[b]), ()) if vh[m]))
+        return r
+
+    def bev_inputs(self, obs, store, pc_order=1, bev_dim=21, bev_res=0.5):
+        """agent.py:143-192,282-337 as inputs of the fused lift / splat kernels (see GraphMapBatch.bev_inputs): the choice
+        of the visited neighbours, their store rows and poses come from the device-resident map."""
+        B, V = self.B, self.V
+        cur, _, _ = self._resolve(obs, False)
+        R = min(64, self._neighbour_bound(cur, pc_order))
+        P = np.asarray([ob["position"] for ob in obs], dtype=np.float32)
+        S = np.stack([P[:, 0], P[:, 2], -P[:, 1]], 1)
+        xyzhe = np.zeros((B, 5))
+        xyzhe[:, 3] = [ob["heading"] for ob in obs]
+        K = bev_dim * bev_dim
+        cand_vpids = [[None] + [c["viewpointId"] for c in ob["candidate"]] for ob in obs]
+        cells = GraphMapBatch.cand_cells_batch(obs, bev_dim, bev_res)
+        C = 1 + max(len(c) for c in cells)
+        cand_np = np.zeros((B, C), dtype=np.int64)
+        cand_np[:, 0] = (K - 1) // 2                                  # [stop]: the centre cell (agent.py:318)
+        nav_masks = np.zeros((B, K), dtype=bool)
+        for i, c in enumerate(cells):
+            cand_np[i, 1:1 + len(c)] = c
+            nav_masks[i, cand_np[i, :1 + len(c)]] = True
+        up = self.feed({"cur": cur, "T_w2c": pose_matrix(xyzhe), "S": S, "nav_masks": nav_masks, "cand": cand_np})
+        dev = self.device
+        rows = torch.empty(B, R, dtype=torch.int32, device=dev)
+        live = torch.empty(B, R, dtype=torch.bool, device=dev)
+        T_c2w = torch.empty(B, R * V, 4, 4, dtype=torch.float32, device=dev)
+        lib.call("bevbert_gm_bev_select", self._st_ptr, up["cur"].data_ptr(), int(pc_order), R, rows.data_ptr(),
+                 live.data_ptr(), T_c2w.data_ptr(), self._overflow.data_ptr(), lib.stream())
+        depths = store.depths.index_select(0, rows.reshape(-1).long()).reshape(B, R * V, store.hw, store.hw)
+        depths = depths * live.repeat_interleave(V, 1)[..., None, None]                              # padding: no depth
+        g = getattr(self, "_gpos", None)
+        if g is None or g[0] is not obs:       # position features of the start viewpoint come with nav_gmap_variable's launch
+            self.nav_gmap_variable(obs)
+            g = self._gpos
+        return {"grid_rows": rows, "depths": depths, "T_c2w": T_c2w, "T_w2c": up["T_w2c"][:, None],
+                "S_w2c": up["S"][:, None], "bev_nav_masks": up["nav_masks"], "bev_cand_idxs": up["cand"],
+                "bev_cand_vpids": cand_vpids, "bev_gpos_fts": g[1][:, None]}
+
+    def check_overflow(self):
+        """True if a bev_inputs call ever met more neighbours than its host-side bound (one D2H sync: call it once per
+        episode batch, e.g. where the agent reads the logits back anyway)."""
+        return bool(int(self._overflow.item()))
+
+    # -- read-back for callers that think in episodes (the agent's make_equiv_action; tests) ---------------------------
+    def path(self, b, x, y):
+        """FloydGraph.path (graph_utils.py:85-93) from the device's next-hop table (fetched once per graph update)."""
+        if x == y:
+            return []
+        if self._point_host is None:
+            self._point_host = self.t["point"].cpu().numpy()
+        P, idx, names = self._point_host[b], self.index[b], self.names[b]
+
+        def rec(i, j):
+            k = int(P[i, j])
+            return [names[j]] if k < 0 else rec(i, k) + rec(k, j)
+        return rec(idx[x], idx[y])

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbevbert_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "attn_bwd1.hip", "attn_fwd2.hip", "attn_bwd2.hip", "attn_small.hip", "sap_loss.hip", "gemm.hip", "capi.hip"]
+SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_mfma.hip", "attn_bwd1.hip", "attn_fwd2.hip", "attn_bwd2.hip", "attn_small.hip", "sap_loss.hip", "graph_nav.hip", "gemm.hip", "capi.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bevbert_hip.h")
 
 F32, BF16, F16 = 0, 1, 2
@@ -102,6 +102,9 @@ _PROTOS = {
                      _I64, _I, _P],
     "bevbert_colsum_finalize": [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     "bevbert_dropout_add": [_P, _P, _P, _I64, _I, _I, _F, _U64, _U64, _P],
+    "bevbert_gm_update": [_P] * 10 + [_I, _I, _P, _P, _P],
+    "bevbert_gm_nav_vars": [_P] * 7 + [_I, _I, _I] + [_P] * 7,
+    "bevbert_gm_bev_select": [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     "bevbert_sap_loss_fwd": [_P] * 15 + [_I, _I, _I, _I, _I, _P],
     "bevbert_sap_loss_bwd": [_P] * 7 + [_I, _I, _I, _I, _P],
     "bevbert_cross_entropy_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
@@ -127,6 +130,7 @@ def load():
     lib.bevbert_colsum_workspace_floats.restype = _I64
     lib.bevbert_colsum_workspace_floats.argtypes = [_I]
     lib.bevbert_gemm_plan_count.restype = _I
+    lib.bevbert_gemm_rejected_count.restype = _I
     lib.bevbert_gemm_tuning_export.restype = _I64
     lib.bevbert_gemm_tuning_export.argtypes = [ctypes.c_char_p, _I64]
     lib.bevbert_gemm_tuning_import.restype = _I

@@ -1285,6 +1285,80 @@ def linear_packed(x, pw, pb):
     return _LinearPacked.apply(x, pw, pb)
 
 
+HOIST_KV = _os.environ.get("BEVBERT_HOIST_KV", "1") == "1"      # A/B knob
+
+
+class _KVGradHolder:
+    """The (B, Lk, layers * 2H) gradient buffer of a hoisted K/V projection, allocated when the first attention backward
+    asks for its slice."""
+
+    def __init__(self, n_layers, width):
+        self.n, self.width, self.buf = n_layers, width, None
+
+    def grad_slice(self, layer, like):
+        if self.buf is None:
+            self.buf = torch.empty(like.shape[:-1] + (self.n * self.width,), dtype=like.dtype, device=like.device)
+        return self.buf[..., layer * self.width:(layer + 1) * self.width]
+
+
+class _HoistedKV(torch.autograd.Function):
+    """The key / value projections of ALL cross-attention layers of an encoder in one GEMM.
+
+    The context of the cross-attention is the same tensor in every layer (the text states in the map encoders --
+    ``lang_feats`` is never updated, vilmodel.py:383-398,446-463 -- or the BEV / map tokens in the MLM direction), so
+    layers x (x W_kv^T) is one (rows, layers * 2H, C) problem: at the 5 120 text rows of the step that is 96 output
+    tiles of 256 x 256 instead of four launches of 24.  Backward: each layer's attention writes dK / dV into its column
+    slice of one buffer (``_KVGradHolder``); when the last one has run, ONE K-concatenated input-gradient GEMM
+    (rows x C, K = layers * 2H) and ONE weight-gradient GEMM (layers * 2H x C) into the arena follow."""
+
+    @staticmethod
+    def forward(ctx, x, pw, pb, n_layers):
+        ctx.save_for_backward(x)
+        ctx.packed = (pw, pb)
+        y = _gemm("fwd", lambda: _linear_fwd(x, pw.compute, pb.compute), x.numel() // x.shape[-1],
+                  pw.compute.shape[0], pw.compute.shape[1])
+        width = y.shape[-1] // n_layers
+        ctx.holder = _KVGradHolder(n_layers, width)
+        return tuple(y[..., i * width:(i + 1) * width] for i in range(n_layers))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (x,) = ctx.saved_tensors
+        pw, pb = ctx.packed
+        h = ctx.holder
+        some = next((g for g in grads if g is not None), None)
+        if some is None:
+            return None, None, None, None
+        for i, g in enumerate(grads):
+            dst = h.grad_slice(i, some)
+            if g is None:
+                dst.zero_()                        # a layer whose output reached no loss
+            elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                dst.copy_(g)                       # a gradient that did not come from the attention backward (tests)
+        dy2 = h.buf.reshape(-1, h.buf.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        M, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
+        dx = _gemm("dgrad", lambda: _linear_dgrad(dy2, pw.compute), M, K, N).view(x.shape) if ctx.needs_input_grad[0] else None
+        if pw.requires_grad:
+            pw.touch()
+            pb.touch()
+            xc = x2 if x2.is_contiguous() else x2.contiguous()
+            WgradStream.submit(dy2.device, lambda: _param_grads(pw.main_grad, pb.main_grad, dy2, xc), dy2, xc, h.buf)
+        return dx, None, None, None
+
+
+def hoisted_kv(context, pw, pb, n_layers):
+    """[(B, Lk, 2H) K|V view of layer i] for the cross-attention layers whose packed parameters ``pw`` (layers * 2H, C) /
+    ``pb`` (layers * 2H) describe; pass the views as ``kv=`` to BertOutAttention.forward."""
+    outs = _HoistedKV.apply(context, pw, pb, n_layers)
+    if torch.is_grad_enabled() and any(o.requires_grad for o in outs):
+        holder = outs[0].grad_fn.holder if hasattr(outs[0].grad_fn, "holder") else None
+        if holder is not None:
+            for i, o in enumerate(outs):
+                o._kv_grad_slot = (holder, i)
+    return outs
+
+
 def linear_packed_res(x, pw, pb):
     """(packed projection of x, x as residual tap) -- see linear_res."""
     if not (x.requires_grad and torch.is_grad_enabled()):
@@ -1354,6 +1428,7 @@ class _Attention(torch.autograd.Function):
              ptr(bits), bits_ready, stream())
         ctx.save_for_backward(a, b_, c_, key_mask, bias, o, lse, bits)
         ctx.cfg = (mode, nh, float(drop_p), RT.seed, off, impl, scale)
+        ctx.kv_slot = getattr(b_, "_kv_grad_slot", None) if mode == "cross" else None     # see hoisted_kv
         return o
 
     @staticmethod
@@ -1370,7 +1445,10 @@ class _Attention(torch.autograd.Function):
         elif mode == "cross":
             H = a.shape[-1]
             q, k, v = a, b_[..., :H], b_[..., H:]
-            dq, dkv = torch.empty_like(a), torch.empty_like(b_)
+            dq = torch.empty_like(a)
+            # K/V projected for all layers of an encoder at once (hoisted_kv): the gradient goes straight into this
+            # layer's column slice of the shared (B, Lk, layers * 2H) buffer, which feeds ONE input-gradient GEMM
+            dkv = ctx.kv_slot[0].grad_slice(ctx.kv_slot[1], b_) if ctx.kv_slot is not None else torch.empty_like(b_)
             dk, dv = dkv[..., :H], dkv[..., H:]
             grads = (dq, dkv, None)
         else:

@@ -58,8 +58,9 @@ def _mask_tokens(rng, ids, vocab_lo, vocab_hi, mask_id):
     return out, lab
 
 
-def make_sample(rng, i, cfg, n_steps, txt_len, ragged_views=False):
-    """One sample in the schema of ``get_input`` + the task Dataset ``__getitem__``."""
+def make_sample(rng, i, cfg, n_steps, txt_len, ragged_views=False, grid=True):
+    """One sample in the schema of ``get_input`` + the task Dataset ``__getitem__``.  ``grid=False``: without the grid
+    features / depths / class ids (samples whose grid features live in a device-resident feature_store.GridFeatureStore)."""
     bev_dim = cfg.bev_dim
     n_cells = bev_dim * bev_dim
     hw = cfg.grid_hw
@@ -155,11 +156,12 @@ def make_sample(rng, i, cfg, n_steps, txt_len, ragged_views=False):
     # ---- local metric map inputs (get_bev_inputs)
     V = cfg.grid_views
     P = V * hw * hw
-    s["rgbs"] = rng.standard_normal((V, hw, hw, cfg.grid_feat_size)).astype(np.float32)
-    dep = rng.uniform(0, 0.6, size=(V, 1, hw, hw)).astype(np.float32)
-    dep[rng.random(dep.shape) < 0.05] = 0.0
-    s["depths"] = dep
-    s["sem_ids"] = rng.integers(0, max(1, cfg.sem_classes), size=(P,)).astype(np.int64)
+    if grid:
+        s["rgbs"] = rng.standard_normal((V, hw, hw, cfg.grid_feat_size)).astype(np.float32)
+        dep = rng.uniform(0, 0.6, size=(V, 1, hw, hw)).astype(np.float32)
+        dep[rng.random(dep.shape) < 0.05] = 0.0
+        s["depths"] = dep
+        s["sem_ids"] = rng.integers(0, max(1, cfg.sem_classes), size=(P,)).astype(np.int64)
     xyz = rng.uniform(-5, 5, size=3)
     xyzhe = np.zeros((V, 5), dtype=np.float32)
     xyzhe[:, 0], xyzhe[:, 1], xyzhe[:, 2] = xyz
@@ -256,15 +258,16 @@ def collate(samples, cfg, task, rng, sems_as="onehot64"):
     b["gmap_pair_dists"] = torch.from_numpy(pd)
 
     n_cells = cfg.bev_dim * cfg.bev_dim
-    b["rgbs"] = torch.from_numpy(np.stack([s["rgbs"] for s in samples]))
-    b["depths"] = torch.from_numpy(np.stack([s["depths"] for s in samples]))
-    sem_ids = np.stack([s["sem_ids"] for s in samples])
-    if cfg.sem_classes <= 0:            # continuous-environment fork: no semantic maps in the batch
-        pass
-    elif sems_as == "onehot64":
-        b["sems"] = torch.from_numpy(np.eye(cfg.sem_classes)[sem_ids])          # float64
-    else:
-        b["sems"] = torch.from_numpy(sem_ids.astype(np.uint8))
+    if "rgbs" in samples[0]:            # absent: the grid features are rows of a device-resident store
+        b["rgbs"] = torch.from_numpy(np.stack([s["rgbs"] for s in samples]))
+        b["depths"] = torch.from_numpy(np.stack([s["depths"] for s in samples]))
+        sem_ids = np.stack([s["sem_ids"] for s in samples])
+        if cfg.sem_classes <= 0:            # continuous-environment fork: no semantic maps in the batch
+            pass
+        elif sems_as == "onehot64":
+            b["sems"] = torch.from_numpy(np.eye(cfg.sem_classes)[sem_ids])          # float64
+        else:
+            b["sems"] = torch.from_numpy(sem_ids.astype(np.uint8))
     b["T_c2w"] = torch.from_numpy(np.stack([s["T_c2w"] for s in samples]))
     b["T_w2c"] = torch.from_numpy(np.stack([s["T_w2c"] for s in samples]))
     b["S_w2c"] = torch.from_numpy(np.stack([s["S_w2c"] for s in samples]))

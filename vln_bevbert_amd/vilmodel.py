@@ -251,10 +251,12 @@ class BertOutAttention(_Finalizable):
     def arena_groups(prefix):
         return [[f"{prefix}key.weight", f"{prefix}value.weight"], [f"{prefix}key.bias", f"{prefix}value.bias"]]
 
-    def forward(self, hidden_states, context, key_mask=None):
-        """Returns (attention output, hidden_states as residual tap)."""
+    def forward(self, hidden_states, context, key_mask=None, kv=None):
+        """Returns (attention output, hidden_states as residual tap).  ``kv``: this layer's (B, Lk, 2H) K|V projection of
+        ``context`` when the encoder computed it for all its layers at once (CrossmodalEncoder.hoist_kv)."""
         q, res = ops.linear_res(hidden_states, self.query.weight, self.query.bias)
-        kv = ops.linear_packed(context, self.pw, self.pb)
+        if kv is None:
+            kv = ops.linear_packed(context, self.pw, self.pb)
         return ops.attention_cross(q, kv, key_mask, self.num_attention_heads, self.drop_p, self.training), res
 
 
@@ -264,8 +266,8 @@ class BertXAttention(nn.Module):
         self.att = BertOutAttention(config, ctx_dim=ctx_dim)
         self.output = BertSelfOutput(config)
 
-    def forward(self, input_tensor, ctx_tensor, ctx_key_mask=None):
-        a, res = self.att(input_tensor, ctx_tensor, ctx_key_mask)
+    def forward(self, input_tensor, ctx_tensor, ctx_key_mask=None, ctx_kv=None):
+        a, res = self.att(input_tensor, ctx_tensor, ctx_key_mask, ctx_kv)
         return self.output(a, res)
 
 
@@ -283,13 +285,13 @@ class GraphLXRTXLayer(nn.Module):
         self.visn_output = BertOutput(config)
         self.visual_attention = BertXAttention(config)
 
-    def forward(self, lang_feats, lang_key_mask, visn_feats, visn_key_mask, graph_sprels=None):
-        a = self.visual_attention(visn_feats, lang_feats, lang_key_mask)
+    def forward(self, lang_feats, lang_key_mask, visn_feats, visn_key_mask, graph_sprels=None, ctx_kv=None):
+        a = self.visual_attention(visn_feats, lang_feats, lang_key_mask, ctx_kv)
         a = self.visn_self_att(a, visn_key_mask, graph_sprels)
         return self.visn_output(*self.visn_inter(a))
 
-    def forward_lang2visn(self, lang_feats, lang_key_mask, visn_feats, visn_key_mask):
-        a = self.visual_attention(lang_feats, visn_feats, visn_key_mask)
+    def forward_lang2visn(self, lang_feats, lang_key_mask, visn_feats, visn_key_mask, ctx_kv=None):
+        a = self.visual_attention(lang_feats, visn_feats, visn_key_mask, ctx_kv)
         a = self.lang_self_att(a, lang_key_mask)
         return self.lang_output(*self.lang_inter(a))
 
@@ -317,17 +319,52 @@ class LanguageEncoder(nn.Module):
         return txt_embeds
 
 
-class CrossmodalEncoder(nn.Module):
+class CrossmodalEncoder(_Finalizable):
     def __init__(self, config):
         super().__init__()
         self.num_x_layers = config.num_x_layers
         self.x_layers = nn.ModuleList([GraphLXRTXLayer(config) for _ in range(self.num_x_layers)])
+        self.kv_pw = self.kv_pb = None
+
+    # The cross-attention context is the same tensor in every layer (vilmodel.py:383-398,446-463: lang_feats is never
+    # updated; in the MLM direction the map / BEV tokens are not either), so the key / value projections of all layers
+    # are ONE GEMM over weights laid out back to back in the arena (ops.hoisted_kv).
+    @staticmethod
+    def _kv_names(prefix, n_layers, kind):
+        return [f"{prefix}x_layers.{i}.visual_attention.att.{k}.{kind}" for i in range(n_layers) for k in ("key", "value")]
+
+    def arena_groups(self, prefix):
+        return [self._kv_names(prefix, self.num_x_layers, "weight"), self._kv_names(prefix, self.num_x_layers, "bias")]
+
+    def _after_arena(self, arena, prefix):
+        n = self.num_x_layers
+        att = self.x_layers[0].visual_attention.att
+        H, C = att.key.weight.shape
+        wc, wg = arena.packed(self._kv_names(prefix, n, "weight"), (n * 2 * H, C))
+        bc, bg = arena.packed(self._kv_names(prefix, n, "bias"), (n * 2 * H,))
+        ws = [p for l in self.x_layers for p in (l.visual_attention.att.key.weight, l.visual_attention.att.value.weight)]
+        bs = [p for l in self.x_layers for p in (l.visual_attention.att.key.bias, l.visual_attention.att.value.bias)]
+        self.kv_pw, self.kv_pb = ops._PackedParam(ws, wc, wg), ops._PackedParam(bs, bc, bg)
+
+    def hoist_kv(self, context):
+        """Per-layer (B, Lk, 2H) K|V views of ``context`` from one GEMM, or [None] * layers when hoisting is off."""
+        if not ops.HOIST_KV or self.kv_pw is None or self.num_x_layers < 2:
+            return [None] * self.num_x_layers
+        return ops.hoisted_kv(context, self.kv_pw, self.kv_pb, self.num_x_layers)
 
     def forward(self, txt_embeds, txt_masks, img_embeds, img_masks, graph_sprels=None):
         tm, im = neg_key_mask(txt_masks), neg_key_mask(img_masks)
-        for layer in self.x_layers:
-            img_embeds = layer(txt_embeds, tm, img_embeds, im, graph_sprels=graph_sprels)
+        kvs = self.hoist_kv(txt_embeds)
+        for layer, kv in zip(self.x_layers, kvs):
+            img_embeds = layer(txt_embeds, tm, img_embeds, im, graph_sprels=graph_sprels, ctx_kv=kv)
         return img_embeds
+
+    def forward_lang2visn(self, txt_embeds, txt_key_mask, visn_feats, visn_key_mask):
+        """The MLM direction (vilmodel.py:790-800): text queries over fixed map / BEV tokens in every layer."""
+        kvs = self.hoist_kv(visn_feats)
+        for layer, kv in zip(self.x_layers, kvs):
+            txt_embeds = layer.forward_lang2visn(txt_embeds, txt_key_mask, visn_feats, visn_key_mask, ctx_kv=kv)
+        return txt_embeds
 
 
 # ----------------------------------------------------------------------------- panorama encoder
@@ -745,9 +782,7 @@ class GlocalTextPathCMT(nn.Module):
             g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
                                               gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens, gmap_csr)
             gm = neg_key_mask(g_masks)
-            g_txt = txt_embeds
-            for layer in self.global_encoder.encoder.x_layers:
-                g_txt = layer.forward_lang2visn(g_txt, tm, g_in, gm)
+            g_txt = self.global_encoder.encoder.forward_lang2visn(txt_embeds, tm, g_in, gm)
         bev_in = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
         obj_embeds = obj_masks = None
         if traj_obj_img_fts is not None:
@@ -757,9 +792,7 @@ class GlocalTextPathCMT(nn.Module):
                                                                 obj_masks)
         bev_in = bev_in.contiguous()
         bm = neg_key_mask(bev_obj_masks)
-        b_txt = txt_embeds
-        for layer in self.local_encoder.encoder.x_layers:
-            b_txt = layer.forward_lang2visn(b_txt, tm, bev_in, bm)
+        b_txt = self.local_encoder.encoder.forward_lang2visn(txt_embeds, tm, bev_in, bm)
         br.join(g_txt)
         return g_txt + b_txt
 
@@ -830,10 +863,20 @@ class GlocalTextPathCMTCE(GlocalTextPathCMT):
 
 
 def arena_groups(module):
-    groups = []
+    """Parameter runs that must be contiguous in the arena: packed QKV per self-attention, K|V per cross-attention --
+    and, where a CrossmodalEncoder hoists them, the K|V of all its layers back to back (the per-layer pairs stay
+    adjacent inside that run, so BertOutAttention's own packed views remain valid)."""
+    groups, taken = [], set()
+    for name, m in module.named_modules():
+        if isinstance(m, CrossmodalEncoder) and m.num_x_layers >= 2:
+            for g in m.arena_groups(name + "." if name else ""):
+                groups.append(g)
+                taken.update(g)
     for name, m in module.named_modules():
         if isinstance(m, (BertSelfAttention, BertOutAttention)):
-            groups.extend(m.arena_groups(name + "." if name else ""))
+            for g in m.arena_groups(name + "." if name else ""):
+                if not taken.intersection(g):
+                    groups.append(g)
     return groups
 
 
