@@ -636,7 +636,9 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     n_total = n_warm + a.stream_steps
     workers = max(0, a.loader_workers)
     ds = _CollateStream(cfg, samples, cycle, n_total, a.batch, 7000, n_rows, a.ship_grid)
-    dl = torch.utils.data.DataLoader(ds, batch_size=None, num_workers=workers, pin_memory=True,
+    # pin_memory=False: the buffer sets stage through pinned buffers of their own (StaticBatch._staged); a DataLoader
+    # pin thread would hipHostMalloc / hipHostFree 23 MB per batch, which synchronises with the device
+    dl = torch.utils.data.DataLoader(ds, batch_size=None, num_workers=workers, pin_memory=False,
                                      prefetch_factor=2 if workers else None, persistent_workers=False)
     loader = StreamingLoader(iter(dl), mgr, prefetch=1)
     plans0 = ops.gemm_plan_count() if hasattr(ops, "gemm_plan_count") else None
@@ -667,8 +669,8 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
            "vs_resident": round(resident_ms / ms, 4), "steps": a.stream_steps, "warmup_steps": n_warm,
            "batches": "ragged (T in [1,7], text in [L/2, L], 36..38 views)" if a.ragged else "fixed shapes (T = 5, L = %d)" % a.txt_len,
            "grid_features": "462 MB fp32 per batch over PCIe" if a.ship_grid else f"rows of a {store.nbytes() / 2**30:.1f} GiB device-resident store",
-           "source": f"a fresh collate per step ({n_pool}-sample pool, {workers} DataLoader worker processes, pinned by the "
-                     f"DataLoader); host-side index building and refill every step",
+           "source": f"a fresh collate per step ({n_pool}-sample pool, {workers} DataLoader worker processes); host-side "
+                     f"index building, staging through pinned buffers and refill every step",
            "collate_ms_per_batch_one_process": round(collate_ms, 2), "collate_workers": workers,
            "buckets": len(mgr.buckets), "buckets_created_in_timed_region": st.get("buckets_created", 0),
            "captured_graphs": mgr.captured_graphs(), "steps_replayed": replayed, "steps_eager": eager,

@@ -35,6 +35,8 @@ class _Dry(graph_map_dev.DeviceGraphMap):
         self.n = np.zeros(self.B, dtype=np.int32)
         self.N = 0
         self._alloc(64)
+        for b, vp in enumerate(self.start_vps):
+            self._node(b, vp)
         self._overflow = torch.zeros(1, dtype=torch.int32)
         self._last = None
         self._point_host = None

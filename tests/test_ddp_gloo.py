@@ -269,7 +269,7 @@ def test_a_parameter_used_on_one_rank_only_is_updated_on_every_rank(tmp_path):
     assert not torch.equal(r0["extra"], torch.full((3, 3), 0.5))
 
 
-def _bf16_exchange_run(rank, world, port, out):
+def _bf16_exchange_run(rank, world, port, out, exchange="bf16_a2a"):
     from vln_bevbert_amd.train import GradReducer
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -279,8 +279,8 @@ def _bf16_exchange_run(rank, world, port, out):
     want = local.clone()
     dist.all_reduce(want)                                  # fp32 reference (the default exchange)
     got = local.clone()
-    red = GradReducer(got, split=4000, exchange="bf16")
-    assert red.active and red.exchange == "bf16"
+    red = GradReducer(got, split=4000, exchange=exchange)
+    assert red.active and red.exchange == exchange
     red.phase_a()                                          # [4000, n) first, as the backward hook would
     red.launch_region(1000, 2500)
     red.finish()                                           # the rest
@@ -289,12 +289,14 @@ def _bf16_exchange_run(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_bf16_gradient_exchange_sums_in_fp32_and_stays_within_two_bf16_roundings(tmp_path):
-    """BEVBERT_GRAD_EXCHANGE=bf16: half the bytes per link; against the fp32 all-reduce every element is within the
-    bf16 rounding of each rank's contribution plus that of the result (each 2^-9 relative), in any region order."""
+@pytest.mark.parametrize("exchange", ["bf16", "bf16_a2a"])
+def test_bf16_gradient_exchange_sums_in_fp32_and_stays_within_two_bf16_roundings(tmp_path, exchange):
+    """BEVBERT_GRAD_EXCHANGE=bf16 (reduce-scatter + all-gather: capturable) / bf16_a2a (all-to-all + fp32 sum +
+    all-gather): half the bytes per link; against the fp32 all-reduce every element is within the bf16 rounding of each
+    rank's contribution plus that of the result (each 2^-9 relative), in any region order."""
     out = str(tmp_path / "x.pt")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_bf16_exchange_run, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_bf16_exchange_run, args=(2, port, out, exchange), nprocs=2, join=True)
     r = torch.load(out)
     got, want = r["got"], r["want"]
     assert bool(torch.isfinite(got).all())

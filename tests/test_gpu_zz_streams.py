@@ -98,6 +98,63 @@ def test_four_steps_with_forced_collectives_track_a_run_without(one_rank_group):
     assert np.max(np.abs(curves[True] - curves[False]) / np.maximum(1.0, np.abs(curves[False]))) < 1e-3, curves
 
 
+def test_a_failed_capture_with_collectives_active_continues_eagerly_on_the_same_curve(one_rank_group, monkeypatch):
+    """a rank whose hipGraph capture fails must not leave the group -- it redoes the step eagerly and
+    keeps issuing the SAME sequence of collectives per step as the ranks that replay their graphs (regions in hook order,
+    then the remainder), with nothing of the dead capture left behind (deferred weight-gradient closures, queued
+    reductions, collective work handles).  Injected here on a one-rank RCCL group with forced collectives: the capture
+    of the third use of each batch raises at the top of the captured step; the run must continue, report the error, and
+    reproduce the losses of a run that never tried to capture -- bit for bit (training is deterministic)."""
+    from vln_bevbert_amd import train
+    from vln_bevbert_amd.static_step import StaticBatch
+    cfg = BevBertConfig.tiny(num_l_layers=2, num_x_layers=2, vocab_size=400)
+    seq = ("sap", "mlm") * 4
+    real = train.PretrainTrainer._forward_backward
+
+    def failing(self, task, batch):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected capture failure")
+        return real(self, task, batch)
+
+    curves, calls = {}, {}
+    for mode in ("eager", "capture_fails"):
+        model, arena = _fresh(cfg, torch.bfloat16)
+        tr = train.PretrainTrainer(model, arena, learning_rate=1e-4, warmup_steps=2, num_train_steps=40,
+                                   force_collectives=True)
+        assert tr.reducer.active
+        tr.use_graphs = mode != "eager"
+        n_coll = [0]
+        launch = tr.reducer._launch
+
+        def counted(lo, hi, launch=launch, n_coll=n_coll):
+            n_coll[0] += 1
+            return launch(lo, hi)
+        tr.reducer._launch = counted
+        if mode == "capture_fails":
+            monkeypatch.setattr(train.PretrainTrainer, "_forward_backward", failing)
+        sbs = {t: StaticBatch(cfg, t, synthetic.make_batch(cfg, t, 3, seed=90, ragged=True, sems_as="ids"), DEV)
+               for t in ("sap", "mlm")}
+        with pytest.warns(UserWarning, match="capture") if mode == "capture_fails" else _no_warning():
+            curves[mode] = np.asarray([float(tr.step(t, sbs[t])) for t in seq])
+        torch.cuda.synchronize()
+        calls[mode] = n_coll[0]
+        if mode == "capture_fails":
+            assert tr.graph_error is not None and "injected" in tr.graph_error and tr.use_graphs is False
+            assert all(sb.graph is None for sb in sbs.values())
+            monkeypatch.setattr(train.PretrainTrainer, "_forward_backward", real)
+        assert not tr.reducer._works and not tr.reducer._done
+    assert calls["eager"] == calls["capture_fails"], calls               # the same collectives, step for step
+    assert np.array_equal(curves["eager"], curves["capture_fails"]), curves
+
+
+class _no_warning:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_phase_a_gradients_are_final_when_the_text_hook_fires(env, dtype):
     """The overlapped all-reduce (train.GradReducer.phase_a) reduces the arena region [split, end) -- map encoders and

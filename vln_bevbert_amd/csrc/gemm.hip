@@ -12,6 +12,7 @@
 //   opA == 0: A is stored M x K (lda);  opA == 1: A is stored K x M (lda) and used transposed.  Same for B (K x N / N x K).
 // hipBLASLt is column-major, so the call is issued as C^T = op(B)^T . op(A)^T on the same memory.
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
 
 #include <algorithm>
 #include <cstdlib>
@@ -33,7 +34,11 @@ struct Plan {
   int64_t ws_limit = 0;
   size_t c_bytes = 0;
   int id = -1;
-  int choice = -1, ncand = 0;   // index of the chosen candidate in the heuristic's list of `ncand` (tuning table)
+  int choice = -1, ncand = 0;   // tuning-table row: index of the chosen candidate in the heuristic's list of `ncand`,
+                                // or (ncand == -1) the library-wide solution index of an exhaustive search
+  int sel = -1;                 // position of the chosen algorithm in `cand` while candidates are kept
+  hipblasOperation_t ta = HIPBLAS_OP_N, tb = HIPBLAS_OP_N;
+  hipDataType tin = HIP_R_16BF, tout = HIP_R_16BF;
   std::string key;
   bool ok = false, tuned = false, has_bias = false, accumulate = false;
   bool verified = false;        // the chosen algorithm has passed the reproducibility screening (tune_plan)
@@ -90,6 +95,7 @@ int make_plan(const Problem& q, int64_t workspace_bytes, int autotune) {
   bool good = hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
   // column-major view: first operand comes from B, second from A (see the header comment)
   const hipblasOperation_t ta = q.opB ? HIPBLAS_OP_T : HIPBLAS_OP_N, tb = q.opA ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+  p.ta = ta; p.tb = tb; p.tin = tin; p.tout = tout;
   good = good && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)) == HIPBLAS_STATUS_SUCCESS;
   good = good && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)) == HIPBLAS_STATUS_SUCCESS;
   if (q.bias_dtype >= 0) {
@@ -122,22 +128,39 @@ int make_plan(const Problem& q, int64_t workspace_bytes, int autotune) {
   p.ncand = (int)p.cand.size();
   p.choice = p.ok ? 0 : -1;
   const auto imported = g_tuning.find(key);
-  if (p.ok && !p.tuned && imported != g_tuning.end() && imported->second.second == p.ncand &&
-      imported->second.first >= 0 && imported->second.first < p.ncand) {
+  if (p.ok && imported != g_tuning.end() && imported->second.second == -1 && imported->second.first >= 0) {
+    // the pick of an exhaustive search (all solutions of the library, not only the heuristic's): by solution index
+    std::vector<int> idx{imported->second.first};
+    std::vector<hipblasLtMatmulHeuristicResult_t> one;
+    const float alpha = 1.f, beta0 = q.accumulate ? 1.f : 0.f;
+    size_t ws = 0;
+    if (hipblaslt_ext::getAlgosFromIndex(g_handle, idx, one) == HIPBLAS_STATUS_SUCCESS && one.size() == 1 &&
+        hipblaslt_ext::matmulIsAlgoSupported(g_handle, p.desc, &alpha, p.la, p.lb, &beta0, p.lc, p.lc, one[0].algo, ws) ==
+            HIPBLAS_STATUS_SUCCESS && (int64_t)ws <= workspace_bytes) {
+      one[0].workspaceSize = ws;
+      one[0].state = HIPBLAS_STATUS_SUCCESS;
+      p.cand = one;
+      p.choice = imported->second.first;
+      p.ncand = -1;
+      p.tuned = true;
+    }
+  } else if (p.ok && !p.tuned && imported != g_tuning.end() && imported->second.second == p.ncand &&
+             imported->second.first >= 0 && imported->second.first < p.ncand) {
     p.choice = imported->second.first;       // a previous run timed this problem on this library: reuse its pick
     p.tuned = true;
   }
+  p.sel = p.ncand == -1 ? 0 : p.choice;
   p.has_bias = q.bias_dtype >= 0;
   p.accumulate = q.accumulate != 0;
   p.c_bytes = (size_t)(q.batch > 1 ? q.batch * q.sc : q.M * q.ldc) * (q.out_dtype == BB_F32 ? 4 : 2);
   p.ws_limit = workspace_bytes;
   if (p.ok && p.tuned &&
-      (p.cand[p.choice].state != HIPBLAS_STATUS_SUCCESS || (int64_t)p.cand[p.choice].workspaceSize > workspace_bytes)) {
+      (p.cand[p.sel].state != HIPBLAS_STATUS_SUCCESS || (int64_t)p.cand[p.sel].workspaceSize > workspace_bytes)) {
     p.ok = false;                 // the only / the recorded candidate is not usable here
     p.choice = -1;
   }
-  if (p.ok) p.algo = p.cand[p.choice].algo;
-  if (p.tuned && p.ncand <= 1) {      // nothing to choose from: the library's only algorithm is used as it is
+  if (p.ok) p.algo = p.cand[p.sel].algo;
+  if (p.tuned && p.ncand >= 0 && p.ncand <= 1) {      // nothing to choose from: the library's only algorithm is used as it is
     p.verified = true;
     p.cand.clear();
     p.cand.shrink_to_fit();
@@ -223,6 +246,31 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
     g_screen = !(e != nullptr && e[0] == '0');
     g_screen_read = true;
   }
+  static const bool exhaustive = [] { const char* e = getenv("BEVBERT_LT_EXHAUSTIVE"); return e != nullptr && e[0] == '1'; }();
+  bool all_algos = false;
+  if (only < 0 && exhaustive) {
+    // every solution the library has for this operand layout / type combination (hipblaslt-bench --algo_method all),
+    // filtered by matmulIsAlgoSupported on THIS problem: the heuristic's top picks favour large tiles, which leave most
+    // of the 256 CUs idle on the 5 120-row problems of the text stream
+    std::vector<hipblasLtMatmulHeuristicResult_t> all;
+    if (hipblaslt_ext::getAllAlgos(g_handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, p.ta, p.tb, p.tin, p.tin, p.tout, p.tout,
+                                   HIPBLAS_COMPUTE_32F, all) == HIPBLAS_STATUS_SUCCESS) {
+      std::vector<hipblasLtMatmulHeuristicResult_t> usable;
+      for (auto& r : all) {
+        size_t ws = 0;
+        if (hipblaslt_ext::matmulIsAlgoSupported(g_handle, p.desc, &alpha, p.la, p.lb, &beta0, p.lc, p.lc, r.algo, ws) !=
+            HIPBLAS_STATUS_SUCCESS || (int64_t)ws > workspace_bytes)
+          continue;
+        r.workspaceSize = ws;
+        r.state = HIPBLAS_STATUS_SUCCESS;
+        usable.push_back(r);
+      }
+      if (!usable.empty()) {
+        p.cand.swap(usable);
+        all_algos = true;
+      }
+    }
+  }
   unsigned long long* sums_dev = nullptr;
   if (g_screen && hipMalloc(&sums_dev, 4 * sizeof(unsigned long long)) != hipSuccess) sums_dev = nullptr;
   hipEvent_t e0, e1;
@@ -235,8 +283,9 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
     if (only >= 0 && (int)i != only) continue;
     if (p.cand[i].state != HIPBLAS_STATUS_SUCCESS || (int64_t)p.cand[i].workspaceSize > workspace_bytes) continue;
     bool run_ok = true;
-    for (int rep = 0; rep < 10 && run_ok; ++rep) {   // 2 warm-up + 8 timed launches per candidate
-      if (rep == 2) (void)hipEventRecord(e0, stream);
+    const int warm = all_algos ? 1 : 2, reps = all_algos ? 3 : 10;   // exhaustive: a quick first pass over hundreds of kernels
+    for (int rep = 0; rep < reps && run_ok; ++rep) {
+      if (rep == warm) (void)hipEventRecord(e0, stream);
       run_ok = hipblasLtMatmul(g_handle, p.desc, &alpha, B, p.la, A, p.lb, &beta0, C, p.lc, C, p.lc, &p.cand[i].algo,
                                workspace, workspace_bytes, stream) == HIPBLAS_STATUS_SUCCESS;
     }
@@ -245,7 +294,24 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    timed.emplace_back(ms, (int)i);
+    timed.emplace_back(ms / (reps - warm), (int)i);
+  }
+  if (all_algos && timed.size() > 8) {             // second pass: the eight fastest, timed like the heuristic candidates
+    std::sort(timed.begin(), timed.end());
+    timed.resize(8);
+    for (auto& t : timed) {
+      bool run_ok = true;
+      for (int rep = 0; rep < 10 && run_ok; ++rep) {
+        if (rep == 2) (void)hipEventRecord(e0, stream);
+        run_ok = hipblasLtMatmul(g_handle, p.desc, &alpha, B, p.la, A, p.lb, &beta0, C, p.lc, C, p.lc, &p.cand[t.second].algo,
+                                 workspace, workspace_bytes, stream) == HIPBLAS_STATUS_SUCCESS;
+      }
+      (void)hipEventRecord(e1, stream);
+      (void)hipEventSynchronize(e1);
+      float ms = 1e30f;
+      if (run_ok) (void)hipEventElapsedTime(&ms, e0, e1);
+      t.first = run_ok ? ms / 8.f : 1e30f;
+    }
   }
   // fastest first; the first one whose output bits repeat wins (screening in this order costs three extra launches for
   // the typical problem, whose fastest candidate is a plain data-parallel kernel)
@@ -282,7 +348,12 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
     return;
   }
   p.algo = p.cand[best].algo;
-  p.choice = best;
+  if (all_algos) {
+    p.choice = hipblaslt_ext::getIndexFromAlgo(p.algo);      // library-wide solution index (stable for one library version)
+    p.ncand = -1;
+  } else {
+    p.choice = best;
+  }
   p.cand.clear();
   p.cand.shrink_to_fit();
 }
@@ -304,7 +375,7 @@ int run_plan(Plan& p, const void* A, const void* B, void* C, const void* bias, f
   if (!p.tuned || !p.verified) {
     // first use (never inside a graph capture: the warm-up steps come first): time the candidates -- or, for a choice
     // imported from the shipped table, check that this algorithm's output bits repeat, else time them all
-    tune_plan(p, A, B, C, workspace, workspace_bytes, stream, p.tuned ? p.choice : -1);
+    tune_plan(p, A, B, C, workspace, workspace_bytes, stream, p.tuned ? p.sel : -1);
     if (!p.ok) {
       bb_set_error("gemm: none of the library's candidates for plan %d can run", p.id);
       return BB_EUNSUPPORTED;
@@ -393,7 +464,8 @@ BEVBERT_API int64_t bevbert_gemm_tuning_export(char* buf, int64_t cap) {
   std::string text = "# bevbert gemm tuning v1 hipblaslt " + std::to_string(lt_version()) + "\n";
   std::unordered_map<std::string, std::pair<int, int>> rows = g_tuning;   // keep imported rows of shapes not seen in this run
   for (const auto& kv : g_plans)
-    if (kv.second.ok && kv.second.tuned && kv.second.ncand > 1) rows[kv.first] = {kv.second.choice, kv.second.ncand};
+    if (kv.second.ok && kv.second.tuned && (kv.second.ncand > 1 || kv.second.ncand == -1))
+      rows[kv.first] = {kv.second.choice, kv.second.ncand};
   for (const auto& kv : rows)
     text += kv.first + " " + std::to_string(kv.second.first) + " " + std::to_string(kv.second.second) + "\n";
   if (buf != nullptr && cap > (int64_t)text.size()) memcpy(buf, text.c_str(), text.size() + 1);

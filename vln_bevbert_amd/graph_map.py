@@ -589,10 +589,9 @@ class GraphMapBatch:
         P = P - np.repeat(S, counts, axis=0)
         p1 = np.concatenate([P, np.ones((total, 1), dtype=np.float32)], -1)
         ends = np.cumsum(counts)
-        q = np.empty((total, 4), dtype=np.float32)
-        for i, n in enumerate(counts):
-            if n:
-                q[ends[i] - n:ends[i]] = p1[ends[i] - n:ends[i]] @ T[i]                              # see cand_cells
+        # one stacked (1 x 4) @ (4 x 4) product per candidate: the same BLAS path per row as the reference's per-sample
+        # np.dot, hence the same roundings (checked bit for bit against the per-sample loop: tests/test_host_logic.py)
+        q = np.matmul(p1[:, None, :], T[np.repeat(np.arange(len(obs)), counts)])[:, 0]           # see cand_cells
         c = np.clip(np.round(q[:, [0, 2]] / bev_res) + (bev_dim - 1) // 2, 0, bev_dim - 1).astype(np.int64)
         cells = c[:, 1] * bev_dim + c[:, 0]
         return [cells[ends[i] - n:ends[i]] for i, n in enumerate(counts)]

@@ -48,6 +48,8 @@ class DeviceGraphMap:
         self.n = np.zeros(self.B, dtype=np.int32)
         self.N = 0
         self._alloc(node_capacity)
+        for b, vp in enumerate(self.start_vps):           # node 0 of every episode: its start viewpoint (GraphMap.__init__)
+            self._node(b, vp)
         self._overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._last = None                                 # (obs object, resolved arrays) of the latest _resolve
         self._point_host = None
@@ -257,7 +259,7 @@ class DeviceGraphMap:
             visited[:, 1:] = vis[np.arange(B)[:, None], node] & real
         names = self.names
         vpids = [[None] + [names[b][k] for k in node[b, :cnt[b]]] for b in range(B)]
-        start = np.asarray([self.index[b][self.start_vps[b]] for b in range(B)], dtype=np.int32)
+        start = np.zeros(B, dtype=np.int32)      # the start viewpoint is the first node every episode registers
         up = self.feed({"node": np.ascontiguousarray(node, dtype=np.int32) if G > 1 else np.zeros((B, 1), np.int32),
                         "cnt": cnt.astype(np.int32), "cur": cur, "start": start,
                         "heading": np.asarray([ob["heading"] for ob in obs], dtype=np.float64),

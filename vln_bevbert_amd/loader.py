@@ -62,12 +62,12 @@ class BucketManager:
                 if not self._cv.wait(timeout=1.0) and time.perf_counter() - t0 > self.WAIT_TIMEOUT_S:
                     raise RuntimeError("BucketManager: a buffer set was never released (call release(sb) after the step "
                                        "on it has been enqueued); depth must be >= 2 for the producer to run ahead")
-        self.stats["wait_s"] += time.perf_counter() - t0
         done = getattr(sb, "done", None)
         if done is not None:
             if self.copy_stream is not None:
                 self.copy_stream.wait_event(done)       # device order: refill after the step that last read the buffers
             done.synchronize()                          # host order: the host-side fields are rewritten below too
+        self.stats["wait_s"] += time.perf_counter() - t0      # time spent waiting (consumer + GPU), not loader work
 
     def acquire(self, task, batch, grid_keys=None):
         """Device-resident StaticBatch holding ``batch`` (host tensors, collate schema).  Blocks while the buffer set it

@@ -150,7 +150,7 @@ class StaticBatch:
         for k, v in src.items():
             if torch.is_tensor(v):
                 if k in t and torch.is_tensor(t[k]):
-                    t[k].copy_(v, non_blocking=True)
+                    t[k].copy_(self._staged(k, v), non_blocking=True)
                 if k + "_cpu" in t:
                     t[k + "_cpu"] = v
             elif k in t:
@@ -159,13 +159,28 @@ class StaticBatch:
         st = t["_static"]
         for k, v in host["static"].items():
             if torch.is_tensor(v):
-                st[k].copy_(v, non_blocking=True)
+                st[k].copy_(self._staged("_static." + k, v), non_blocking=True)
             else:
                 st[k] = v                      # host integers (row counts): they are part of the shape bucket or a
         if "grid_store" in t and grid_keys is not None:      # divisor the step reads from device memory (see below)
             t["grid_rows"].copy_(t["grid_store"].rows(grid_keys), non_blocking=True)
         self._refresh_counts()
         return self
+
+    def _staged(self, key, v):
+        """A pageable host tensor goes through a PINNED staging buffer this buffer set owns (allocated once per key): the
+        host -> device copy is then truly asynchronous, and nothing pins / unpins memory per batch -- hipHostMalloc /
+        hipHostFree are slow and synchronise with the device, which a DataLoader's pin_memory thread pays for every batch.
+        The staging buffer is rewritten by the next refill of THIS set, which the loader orders behind the step that read
+        the previous contents (loader.BucketManager), i.e. behind the copy out of it."""
+        if self.device.type != "cuda" or v.is_pinned() or v.numel() == 0:
+            return v
+        st = self.__dict__.setdefault("_stage", {})
+        buf = st.get(key)
+        if buf is None or buf.shape != v.shape or buf.dtype != v.dtype:
+            buf = st[key] = torch.empty(v.shape, dtype=v.dtype).pin_memory()
+        buf.copy_(v)
+        return buf
 
     def _refresh_counts(self):
         """Host-known divisors of the mean (the number of real masked-token rows) live in a device scalar, so that a

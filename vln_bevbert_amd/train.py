@@ -69,14 +69,19 @@ class GradReducer:
 
     def __init__(self, flat_grads, split, group=None, force=False, exchange=None):
         """force=True issues the collectives even for a single-rank group (used to exercise the RCCL path on one GPU).
-        exchange: "fp32" (in-place SUM all-reduce of the fp32 arena: the reference's DDP semantics, 956 MB per step for
-        the R2R model) or "bf16" (BEVBERT_GRAD_EXCHANGE=bf16): gradients travel as bf16 and are summed in fp32 --
-        cast -> all-to-all of the W shards -> fp32 sum of the W received pieces -> all-gather of the bf16 result: half
-        the bytes on every xGMI link, one bf16 rounding on the way out and one on the way back (2^-9 relative each)
-        instead of W - 1 roundings of a bf16 ring sum."""
+        exchange (BEVBERT_GRAD_EXCHANGE):
+          "fp32"     in-place SUM all-reduce of the fp32 arena: the reference's DDP semantics, 956 MB per step for the
+                     R2R model (default);
+          "bf16"     gradients travel as bf16: cast -> reduce-scatter (RCCL sums each hop in fp32 and forwards bf16:
+                     at most W - 1 roundings of 2^-9 relative) -> all-gather of the bf16 result: half the bytes on every
+                     xGMI link, and -- unlike all-to-all -- both collectives survive hipGraph stream capture, so a step
+                     with this exchange is captured like one with the fp32 all-reduce;
+          "bf16_a2a" bf16 on the wire with fp32 ACCUMULATION: cast -> all-to-all of the W shards -> fp32 sum of the W
+                     received pieces -> all-gather: two roundings whatever W is, but RCCL 2.26's all-to-all takes the
+                     process down under stream capture, so steps with it are issued eagerly."""
         import os
         self.exchange = exchange or os.environ.get("BEVBERT_GRAD_EXCHANGE", "fp32")
-        assert self.exchange in ("fp32", "bf16"), self.exchange
+        assert self.exchange in ("fp32", "bf16", "bf16_a2a"), self.exchange
         self.flat = flat_grads
         self.split = int(split)
         self.group = group
@@ -112,17 +117,22 @@ class GradReducer:
         return gaps
 
     def _exchange_bf16(self, view):
-        """SUM over ranks of ``view`` (fp32, in place) with bf16 on the wire and fp32 accumulation (see __init__)."""
+        """SUM over ranks of ``view`` (fp32, in place) with bf16 on the wire (see __init__ for the two variants)."""
         W, n = self.world, view.numel()
         per = -(-n // W)
         send = torch.zeros(W * per, dtype=torch.bfloat16, device=view.device)
         send[:n].copy_(view)                                   # fp32 -> bf16 (round to nearest even)
-        recv = torch.empty_like(send)
-        # RCCL moves bf16 natively; gloo (the CPU tests) does not know the type: raw bytes there
-        as_wire = (lambda t: t) if view.is_cuda else (lambda t: t.view(torch.uint8))
-        dist.all_to_all_single(as_wire(recv), as_wire(send), group=self.group)
-        mine = recv.view(W, per).float().sum(0).to(torch.bfloat16)          # fp32 sum of the W pieces of MY shard
-        dist.all_gather_into_tensor(as_wire(send), as_wire(mine), group=self.group)
+        if self.exchange == "bf16":
+            mine = torch.empty(per, dtype=torch.bfloat16, device=view.device)
+            dist.reduce_scatter_tensor(mine, send, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(send, mine, group=self.group)
+        else:
+            recv = torch.empty_like(send)
+            # RCCL moves bf16 natively; gloo (the CPU tests) does not know the type in all-to-all: raw bytes there
+            as_wire = (lambda t: t) if view.is_cuda else (lambda t: t.view(torch.uint8))
+            dist.all_to_all_single(as_wire(recv), as_wire(send), group=self.group)
+            mine = recv.view(W, per).float().sum(0).to(torch.bfloat16)      # fp32 sum of the W pieces of MY shard
+            dist.all_gather_into_tensor(as_wire(send), as_wire(mine), group=self.group)
         view.copy_(send[:n])                                   # bf16 -> fp32
 
     def _launch(self, lo, hi):
@@ -141,11 +151,11 @@ class GradReducer:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.stream)
                     self.timeline.append((lo, hi, e0, e1))
-                if self.exchange == "bf16":
+                if self.exchange != "fp32":
                     self._exchange_bf16(view)                  # stream-ordered on the reducer's stream
                 else:
                     self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        elif self.exchange == "bf16":
+        elif self.exchange != "fp32":
             self._exchange_bf16(view)
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -204,10 +214,10 @@ class PretrainTrainer:
         # the arena keeps registration order: embeddings, lang_encoder, img_embeddings come before the map encoders
         self.reducer = GradReducer(arena.grads, first_map, force=force_collectives)
         self.overlap = overlap and self.reducer.active
-        # the bf16 exchange is built from all-to-all + all-gather; RCCL 2.26's all-to-all under stream capture takes the
-        # process down (segmentation fault on the MI355X box, one-rank group, gpurun_out r03w) while its all-reduce
-        # captures fine: steps with that exchange are issued eagerly
-        self.capture_ok = not (self.reducer.active and self.reducer.exchange == "bf16")
+        # RCCL 2.26's all-to-all under stream capture takes the process down (segmentation fault on the MI355X box,
+        # one-rank group, gpurun_out r03w) while all-reduce, reduce-scatter and all-gather capture fine: only steps with
+        # the all-to-all form of the bf16 exchange are issued eagerly
+        self.capture_ok = not (self.reducer.active and self.reducer.exchange == "bf16_a2a")
         if self.reducer.active:
             self.broadcast_state()             # replicas start from rank 0's weights, as under DistributedDataParallel
         if self.overlap:

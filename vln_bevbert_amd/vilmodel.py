@@ -637,8 +637,10 @@ class GlobalMapEncoder(nn.Module):
     def pos_step_embedding(self, gmap_img_fts, gmap_step_ids, gmap_pos_fts):
         lin, ln = self.gmap_pos_embeddings[0], self.gmap_pos_embeddings[1]
         pos = _small_k_linear(gmap_pos_fts, lin, gmap_img_fts.dtype)
-        pos = ops.bias_dropout_residual_layernorm(pos, lin.bias, None, ln.weight, ln.bias, 1e-12)
-        return gmap_img_fts + embedding_lookup(self.gmap_step_embeddings, gmap_step_ids) + pos
+        # (LN(pos) + img) + step embedding on the store of the LayerNorm: one rounding of the sum in bf16 instead of three
+        # (vilmodel.py:589-593 adds the same three terms)
+        return ops.bias_layernorm_plus(pos, lin.bias, ln.weight, ln.bias, 1e-12, gmap_img_fts.contiguous(),
+                                       embedding_lookup(self.gmap_step_embeddings, gmap_step_ids))
 
     def gmap_input_embedding(self, traj_embeds_flat, csr, G, gmap_step_ids, gmap_pos_fts, gmap_lens):
         B = gmap_step_ids.shape[0]
