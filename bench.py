@@ -636,9 +636,12 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     n_total = n_warm + a.stream_steps
     workers = max(0, a.loader_workers)
     ds = _CollateStream(cfg, samples, cycle, n_total, a.batch, 7000, n_rows, a.ship_grid)
-    # pin_memory=False: the buffer sets stage through pinned buffers of their own (StaticBatch._staged); a DataLoader
-    # pin thread would hipHostMalloc / hipHostFree 23 MB per batch, which synchronises with the device
-    dl = torch.utils.data.DataLoader(ds, batch_size=None, num_workers=workers, pin_memory=False,
+    # pin_memory=True: the DataLoader's pin thread takes the batches out of the workers' shared memory and pins them
+    # ahead of the producer thread (measured, round 4, one box: sustained 18.4 ms/step = the resident-batch step with it;
+    # 39.5 ms/step when the producer thread itself copies out of the shared-memory segments -- 10 ms per batch of page
+    # faults).  Pageable tensors from other sources are staged through pinned buffers the buffer sets own (StaticBatch._staged).
+    dl = torch.utils.data.DataLoader(ds, batch_size=None, num_workers=workers,
+                                     pin_memory=os.environ.get("BEVBERT_BENCH_DL_PIN", "1") == "1",
                                      prefetch_factor=2 if workers else None, persistent_workers=False)
     loader = StreamingLoader(iter(dl), mgr, prefetch=1)
     plans0 = ops.gemm_plan_count() if hasattr(ops, "gemm_plan_count") else None
@@ -669,13 +672,15 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
            "vs_resident": round(resident_ms / ms, 4), "steps": a.stream_steps, "warmup_steps": n_warm,
            "batches": "ragged (T in [1,7], text in [L/2, L], 36..38 views)" if a.ragged else "fixed shapes (T = 5, L = %d)" % a.txt_len,
            "grid_features": "462 MB fp32 per batch over PCIe" if a.ship_grid else f"rows of a {store.nbytes() / 2**30:.1f} GiB device-resident store",
-           "source": f"a fresh collate per step ({n_pool}-sample pool, {workers} DataLoader worker processes); host-side "
-                     f"index building, staging through pinned buffers and refill every step",
+           "source": f"a fresh collate per step ({n_pool}-sample pool, {workers} DataLoader worker processes + its pin-memory "
+                     f"thread); host-side index building and refill every step",
            "collate_ms_per_batch_one_process": round(collate_ms, 2), "collate_workers": workers,
            "buckets": len(mgr.buckets), "buckets_created_in_timed_region": st.get("buckets_created", 0),
            "captured_graphs": mgr.captured_graphs(), "steps_replayed": replayed, "steps_eager": eager,
            "loader_ms_per_batch": round(1000.0 * (st.get("loader_s", 0.0) - st.get("wait_s", 0.0)) / n, 3),
            "loader_wait_ms_per_batch": round(1000.0 * st.get("wait_s", 0.0) / n, 3),
+           "producer_waits_for_collate_ms_per_batch": round(1000.0 * st.get("source_s", 0.0) / n, 3),
+           "producer_waits_for_consumer_ms_per_batch": round(1000.0 * st.get("queue_s", 0.0) / n, 3),
            "h2d_MB_per_step": round(st.get("bytes_h2d", 0) / n / 1e6, 2)}
     if plans0 is not None:
         res["gemm_plans_added"] = ops.gemm_plan_count() - plans0

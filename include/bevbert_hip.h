@@ -38,6 +38,9 @@ typedef struct ihipStream_t* hipStream_t;
 
 const char* bevbert_last_error(void);
 int bevbert_version(void); /* major*10000 + minor*100 + patch */
+/* drain the HIP runtime's sticky last-error slot after a FAILED stream capture (the stale code would otherwise be
+ * reported by the next launch check of any library in the process); returns the number of errors dropped. */
+int bevbert_hip_error_reset(void);
 const char* bevbert_arch(void);
 
 /* ---------------------------------------------------------------------------------------------------------------

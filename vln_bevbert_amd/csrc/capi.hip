@@ -14,6 +14,16 @@ void bb_set_error(const char* fmt, ...) {
 }
 
 BEVBERT_API const char* bevbert_last_error(void) { return g_err; }
+// A failed stream capture (hipErrorStreamCaptureInvalidated and friends) leaves its code in the runtime's sticky
+// last-error slot: the NEXT launch check of any library in the process (PyTorch checks hipGetLastError after every
+// kernel launch) would report it as its own.  Callers that recover from a failed capture drain the slot here; returns
+// the number of stale errors dropped.
+BEVBERT_API int bevbert_hip_error_reset(void) {
+  int n = 0;
+  while (hipGetLastError() != hipSuccess && n < 16) ++n;
+  return n;
+}
+
 BEVBERT_API int bevbert_version(void) { return 110; }  // 0.1.1: step salt, device-resident learning rate
 
 static const uint32_t* g_step_salt = nullptr;

@@ -127,6 +127,7 @@ def load():
     lib.bevbert_last_error.restype = ctypes.c_char_p
     lib.bevbert_arch.restype = ctypes.c_char_p
     lib.bevbert_version.restype = _I
+    lib.bevbert_hip_error_reset.restype = _I
     lib.bevbert_colsum_workspace_floats.restype = _I64
     lib.bevbert_colsum_workspace_floats.argtypes = [_I]
     lib.bevbert_gemm_plan_count.restype = _I

@@ -153,12 +153,21 @@ class StreamingLoader:
         try:
             if self.manager.device.type == "cuda":
                 torch.cuda.set_device(self.manager.device)
-            for item in self.source:
-                if self._stop:
+            st = self.manager.stats
+            src = iter(self.source)
+            while not self._stop:
+                t0 = time.perf_counter()
+                try:
+                    item = next(src)
+                except StopIteration:
                     break
+                st["source_s"] += time.perf_counter() - t0          # waiting for the collate workers / the dataset
                 task, batch = item[0], item[1]
                 keys = item[2] if len(item) > 2 else None
-                self.q.put((task, self.manager.acquire(task, batch, grid_keys=keys)))
+                sb = self.manager.acquire(task, batch, grid_keys=keys)
+                t0 = time.perf_counter()
+                self.q.put((task, sb))
+                st["queue_s"] += time.perf_counter() - t0           # waiting for the consumer to take the previous batch
         except Exception as e:          # noqa: BLE001 -- surfaced in the consumer thread
             self.error = e
         self.q.put(None)

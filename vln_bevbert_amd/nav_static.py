@@ -79,7 +79,7 @@ class NavGraphRunner:
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g, pool=self.pool):
+            with torch.no_grad(), torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
                 out = fn(b.inputs)
             self.pool = self.pool or g.pool()
             b.graph, b.outputs = g, out
@@ -89,6 +89,8 @@ class NavGraphRunner:
             return out
         except Exception as e:      # noqa: BLE001 -- a refused capture is reported, the rollout goes on eagerly
             self.graph_error = f"{type(e).__name__}: {e}"
+            from . import lib
+            lib.load().bevbert_hip_error_reset()
             torch.cuda.synchronize()
             self.stats["eager"] += 1
             with torch.no_grad():

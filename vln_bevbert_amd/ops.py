@@ -229,6 +229,29 @@ class Branches:
             for t in tensors:
                 if t is not None:
                     t.record_stream(self.main)
+def join_captured_side_streams(extra=()):
+    """Recovery step of a FAILED stream capture: make the capturing (current) stream wait for every side stream that was
+    forked into the capture (keep-bit stream, model-branch stream, weight-gradient streams, the reducer's stream).
+    hipStreamEndCapture refuses to end a capture with unjoined forks (hipErrorStreamCaptureUnjoined) and -- on ROCm 7.2 --
+    then leaves the origin stream IN capture mode, so that every later launch of the process fails; with the forks
+    joined the capture ends normally and its graph is simply dropped."""
+    if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+        return 0
+    cur = torch.cuda.current_stream()
+    seen, n = {cur.cuda_stream}, 0
+    cands = [ATTN_BITS.stream] + list(Branches._streams.values()) + list(WgradStream.streams) + list(extra)
+    for st in cands:
+        if st is None or st.cuda_stream in seen:
+            continue
+        seen.add(st.cuda_stream)
+        with torch.cuda.stream(st):
+            capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            cur.wait_stream(st)
+            n += 1
+    return n
+
+
 TRACE = None     # dict name -> [(start_event, end_event)] while bench.py's kernel-timing pass is active
 
 

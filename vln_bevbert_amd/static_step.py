@@ -30,6 +30,7 @@ from .vilmodel import gmap_csr_arrays
 MLM_ROW_PAD = 256       # masked-token rows are padded to a multiple of this (15 % of B x L tokens +- a few dozen: a coarse
                         # step keeps consecutive batches in ONE shape bucket, i.e. on one captured graph)
 SEM_ROW_PAD = 512       # supervised BEV cells (MaskSEM) likewise
+_STAGE_PINNED = __import__("os").environ.get("BEVBERT_STAGE_PINNED", "1") == "1"      # A/B knob (StaticBatch._staged)
 GMAP_PAD = 4            # global-map width G (batch max of the node counts) is rounded up to a multiple of this
 
 
@@ -173,7 +174,7 @@ class StaticBatch:
         hipHostFree are slow and synchronise with the device, which a DataLoader's pin_memory thread pays for every batch.
         The staging buffer is rewritten by the next refill of THIS set, which the loader orders behind the step that read
         the previous contents (loader.BucketManager), i.e. behind the copy out of it."""
-        if self.device.type != "cuda" or v.is_pinned() or v.numel() == 0:
+        if self.device.type != "cuda" or not _STAGE_PINNED or v.numel() == 0 or v.is_pinned():
             return v
         st = self.__dict__.setdefault("_stage", {})
         buf = st.get(key)

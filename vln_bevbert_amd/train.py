@@ -220,6 +220,16 @@ class PretrainTrainer:
         self.capture_ok = not (self.reducer.active and self.reducer.exchange == "bf16_a2a")
         if self.reducer.active:
             self.broadcast_state()             # replicas start from rank 0's weights, as under DistributedDataParallel
+        # Without collectives the same moment of backward -- d loss / d text-embeddings complete: every kernel of the two
+        # map encoders and the heads has been enqueued, 57 % of the parameter bytes -- is used to issue the batched
+        # reductions queued so far (split-K partial sums -> arena, LayerNorm / bias column sums): they then run on the
+        # weight-gradient stream beside the text encoder's backward instead of all at the END of backward, in front of
+        # clip + AdamW on the critical path (multi_accum alone is ~0.6 ms per step at batch 64).  MEASURED SLOWER (round 4,
+        # same box, two runs each: 18.40 vs 17.89 ms per step): the flush makes the weight-gradient streams join, which
+        # serialises work that otherwise overlaps the text encoder's backward.  Off unless BEVBERT_EARLY_FLUSH=1.
+        self.early_flush = os.environ.get("BEVBERT_EARLY_FLUSH", "0") == "1" and arena.device.type == "cuda"
+        if self.early_flush and not self.overlap:
+            model.bert.lang_encoder.register_forward_hook(self._hook_flush)
         if self.overlap:
             model.bert.lang_encoder.register_forward_hook(self._hook_text)
             # finer pipeline for phase B (embeddings + text + panorama encoders, 43 % of the gradient bytes): when the
@@ -256,6 +266,11 @@ class PretrainTrainer:
             if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled():
                 x.register_hook(lambda g: (self.reducer.launch_region(lo, hi), g)[1])
         return pre_hook
+
+    def _hook_flush(self, module, inputs, output):
+        if output.requires_grad and torch.is_grad_enabled():
+            output.register_hook(lambda g: (ops.WgradStream.flush_all(), g)[1])
+        return output
 
     def _hook_text(self, module, inputs, output):
         if output.requires_grad and torch.is_grad_enabled():
@@ -366,30 +381,45 @@ class PretrainTrainer:
             # and exchange nothing through pool memory, so the pool is as large as the largest step, not the sum
             self._graph_pool = torch.cuda.graph_pool_handle()
         ops.Branches.enabled = branches or self.graph_branches
-        mode = "global"
+        # thread-local capture mode: other threads of the process keep making HIP calls while this one captures -- the
+        # loader's producer thread allocates pinned staging buffers and device buffer sets (loader.BucketManager), and
+        # ProcessGroupNCCL's watchdog polls the completion events of earlier eager collectives; in "global" mode any such
+        # call invalidates the capture (hipErrorStreamCaptureInvalidated; seen in round 4 with the first pin_memory() of a
+        # buffer set).  Calls made by THIS thread and by autograd's backward thread on its behalf are still checked.
+        mode = "thread_local"
         if self.reducer.active:
-            # ProcessGroupNCCL's watchdog thread polls the completion events of the EAGER collectives issued so far; an
-            # event query from another thread while a capture in "global" mode is open is an error that takes the
-            # process down (hipErrorStreamCaptureUnsupported thrown inside the watchdog).  The device is idle (synchronize
-            # above): give the watchdog one polling period to retire those works, and capture in thread-local mode so
-            # that a straggling query is legal.  Collectives issued DURING capture are not handed to the watchdog.
+            # the device is idle (synchronize above): give the watchdog one polling period to retire the eager works;
+            # collectives issued DURING capture are not handed to it
             import time
             time.sleep(0.3)
-            mode = "thread_local"
+        err = None
         try:
             with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode=mode):
-                # offsets restart; the salt word is read by the kernels at replay; the keep-bit generation of every
-                # attention site is captured as a side branch of the graph (ops.ATTN_BITS)
-                ops.RT.new_step(0, write_salt=False, plan_key=self._plan_key(task, sb))
-                loss = self._forward_backward(task, sb)
-                a.clip_and_step(None, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
-        except Exception as e:      # noqa: BLE001 -- a step that cannot be captured (e.g. a collective library that refuses
-            # stream capture) is not fatal: nothing has executed yet, the trainer says so loudly and goes on eagerly
+                try:
+                    # offsets restart; the salt word is read by the kernels at replay; the keep-bit generation of every
+                    # attention site is captured as a side branch of the graph (ops.ATTN_BITS)
+                    ops.RT.new_step(0, write_salt=False, plan_key=self._plan_key(task, sb))
+                    loss = self._forward_backward(task, sb)
+                    a.clip_and_step(None, self.betas, 1e-6, self.wd, self.grad_norm, grad_pre_scale=1.0 / self.world)
+                except Exception as e:      # noqa: BLE001 -- still inside the capture: join the forked side streams so that
+                    err = e                 # the capture can END (an unjoined capture stays open on this ROCm, see ops)
+                    ops.join_captured_side_streams(extra=[self.reducer.stream])
+        except Exception as e:      # noqa: BLE001 -- ending the capture failed as well
+            err = err or e
+        if err is not None:
+            # a step that cannot be captured (e.g. a collective library that refuses stream capture) is not fatal: nothing
+            # has executed, the trainer says so loudly and goes on eagerly
+            e = err
             import warnings
             self.graph_error = f"{type(e).__name__}: {e}"[:400]
             self.use_graphs = False
             warnings.warn(f"hipGraph capture of the {task} step failed, continuing with eager steps: {self.graph_error}")
             ops.Branches.enabled = branches
+            from . import lib
+            lib.load().bevbert_hip_error_reset()     # the capture's error code must not surface in the next launch check
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the failed hipGraph capture could not be ended: the stream is still capturing and the "
+                                   f"process cannot issue work any more ({self.graph_error})") from e
             torch.cuda.synchronize()
             # host state the aborted capture left behind points into its dead memory pool: deferred weight-gradient
             # closures, queued reduction records, collective work handles -- forget them, the step is redone eagerly
@@ -400,8 +430,7 @@ class PretrainTrainer:
             loss = self._forward_backward(task, sb)
             self.optimizer_step(lr=None)
             return loss
-        finally:
-            ops.Branches.enabled = branches
+        ops.Branches.enabled = branches
         gs = GraphedStep(graph, loss)
         gs.owner = self
         sb.graph = gs
