@@ -717,6 +717,23 @@ def test_checkpoint_loaded_after_wrapping_reaches_the_bf16_compute_copy_before_t
     assert torch.equal(first_loss(True), first_loss(False))
 
 
+def test_fp16_autocast_is_mapped_to_bf16_with_a_warning(env):
+    """The reference's --fp16 is torch.cuda.amp.autocast() = float16 + GradScaler (train_r2r.py:226-227,256-258).  The
+    MI355X path has one reduced-precision mode, bf16 compute copies over fp32 masters: a float16 autocast context is
+    honoured as "reduced precision" but says so (an import-only swap must not change dtype without a word)."""
+    from vln_bevbert_amd import weights
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    model = GlocalTextPathCMTPreTraining(cfg)
+    model.load_state_dict(weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
+    model.tie_weights()
+    model.to(DEV).eval()
+    batch = synthetic.batch_to(synthetic.make_batch(cfg, "sap", 2, seed=3, ragged=True), DEV)
+    with pytest.warns(RuntimeWarning, match="computes in bfloat16"), torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        loss = model(batch, "sap", compute_loss=True)
+    assert model.arena.compute_dtype == torch.bfloat16 and bool(torch.isfinite(loss.float()).all())
+
+
 def test_training_step_bf16_full_size_runs_and_learns(env):
     """BASELINE configs[1] shapes at a reduced batch: bf16, dropout on; loss is finite and falls on a fixed batch."""
     from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining

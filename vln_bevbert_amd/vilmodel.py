@@ -894,7 +894,21 @@ def ensure_arena(module):
         if dev.type != "cuda":
             raise lib.BevBertHipError("the model has not been moved to the GPU: call .to('cuda') (or finalize(device, dtype)) "
                                       "first -- there is no CPU path")
-        arena = finalize(module, dev, torch.bfloat16 if torch.is_autocast_enabled() else torch.float32)
+        amp = torch.is_autocast_enabled()
+        if amp:
+            try:
+                req = torch.get_autocast_dtype("cuda")
+            except Exception:       # noqa: BLE001 -- older torch
+                req = torch.get_autocast_gpu_dtype()
+            if req != torch.bfloat16:
+                # the reference's --fp16 is torch.cuda.amp.autocast() = float16 + GradScaler (train_r2r.py:226-227,256-258);
+                # the MI355X path has one reduced-precision mode: bf16 compute copies over fp32 masters (no loss scaling
+                # needed: GradScaler's scale / unscale_ / step still work and simply never find an overflow)
+                import warnings
+                warnings.warn(f"vln_bevbert_amd: autocast({req}) requested -- this build computes in bfloat16 with fp32 "
+                              "master weights instead (same exponent range as fp32: no loss scaling required); a "
+                              "GradScaler in the loop keeps working", RuntimeWarning, stacklevel=3)
+        arena = finalize(module, dev, torch.bfloat16 if amp else torch.float32)
     elif arena.publish_grads:
         arena.maybe_lazy_zero()
         arena.maybe_refresh_shadow()
