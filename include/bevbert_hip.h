@@ -127,6 +127,13 @@ int bevbert_layernorm_bwd(const void* dy, const void* z, const float* mean, cons
                           void* dz, void* dx, float* dgamma, float* dbeta, float* dbias, float* workspace, int rows,
                           int H, int dtype, float drop_p, uint64_t seed, uint64_t offset, int accumulate,
                           hipStream_t stream);
+/* bevbert_layernorm_bwd with an addend: dz (and dx behind the dropout mask) = LayerNorm's input gradient + dz_add, the
+ * gradient that reaches z through its second consumer when z is also a module output (pre-norm residual stream of the
+ * panorama encoder, pretrain_src/model/transformer.py:170-182). */
+int bevbert_layernorm_bwd_add(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                              void* dz, void* dx, const void* dz_add, float* dgamma, float* dbeta, float* dbias,
+                              float* workspace, int rows, int H, int dtype, float drop_p, uint64_t seed, uint64_t offset,
+                              int accumulate, hipStream_t stream);
 int64_t bevbert_colsum_workspace_floats(int total_cols);
 /* Split form of the parameter-gradient reductions: bevbert_layernorm_bwd / bevbert_bias_gelu_bwd called with NULL
  * dgamma/dbeta/dbias leave per-block partial sums [bevbert_colsum_partial_rows(rows)][nwhich][C] (nwhich = 3 for

@@ -177,6 +177,48 @@ def test_layernorm_fwd_bwd(ops, dtype, with_res, p):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_prenorm_residual_layernorm_returns_the_stream_and_folds_its_gradient(ops, dtype, p):
+    """ops.bias_dropout_residual_prenorm: (LayerNorm(z), z) with z = residual + dropout(x + bias) -- the residual add of a
+    pre-norm block and the LayerNorm opening the next sub-layer in one launch (transformer.py:170-182); BOTH outputs are
+    used downstream, and the gradient arriving at z is added to LayerNorm's input gradient inside the backward kernel
+    (bevbert_layernorm_bwd_add).  Against the torch composition with the exported keep mask; the no-grad call gives the
+    same two tensors."""
+    torch.manual_seed(1)
+    rows, H = 389, 768
+    x = torch.randn(rows, H, device=DEV).to(dtype)
+    res = torch.randn(rows, H, device=DEV).to(dtype)
+    bias = (0.1 * torch.randn(H, device=DEV)).requires_grad_(True)
+    gam = (1 + 0.1 * torch.randn(H, device=DEV)).requires_grad_(True)
+    bet = (0.1 * torch.randn(H, device=DEV)).requires_grad_(True)
+    ops.RT.new_step(77)
+    xin, rin = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    y, z = ops.bias_dropout_residual_prenorm(xin, bias, rin, gam, bet, 1e-5, p, training=True)
+    keep = ops.dropout_keep_mask(rows * H, p, ops.RT.seed, 0, DEV).view(rows, H) if p > 0 else None
+    xr, rr = x.clone().float().requires_grad_(True), res.clone().float().requires_grad_(True)
+    bias_r, gam_r, bet_r = (t.detach().clone().requires_grad_(True) for t in (bias, gam, bet))
+    yr, zr = _ln_ref(xr, bias_r, rr, gam_r, bet_r, 1e-5, keep, p)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert float((y.float() - yr).detach().abs().max()) < tol and float((z.float() - zr).detach().abs().max()) < tol
+    dy, dz = torch.randn(rows, H, device=DEV), torch.randn(rows, H, device=DEV)
+    (y.float() * dy + z.float() * dz).sum().backward()
+    (yr * dy + zr * dz).sum().backward()
+    gt = 1e-3 if dtype == torch.float32 else 3e-2
+    for got, want in ((xin.grad, xr.grad), (rin.grad, rr.grad), (gam.grad, gam_r.grad), (bet.grad, bet_r.grad), (bias.grad, bias_r.grad)):
+        assert rel_err(got, want) < gt
+    ops.RT.new_step(77)
+    with torch.no_grad():
+        y2, z2 = ops.bias_dropout_residual_prenorm(x, bias, res, gam, bet, 1e-5, p, training=True)
+    assert torch.equal(y2, y.detach()) and torch.equal(z2, z.detach())
+    # only z used downstream: LayerNorm contributes nothing, the stream gradient passes (masked) to x and unchanged to residual
+    xin2, rin2 = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    ops.RT.new_step(77)
+    _, z3 = ops.bias_dropout_residual_prenorm(xin2, bias, rin2, gam, bet, 1e-5, p, training=True)
+    (z3.float() * dz).sum().backward()
+    assert rel_err(rin2.grad, dz.to(dtype)) < 1e-6 if dtype == torch.float32 else rel_err(rin2.grad, dz) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("two", [True, False])
 def test_layernorm_with_post_terms_equals_the_separate_adds(ops, dtype, two):
     """bevbert_layernorm_post_fwd: (LN(x + bias) + post1) + post2 in the LayerNorm's launch -- the embedding

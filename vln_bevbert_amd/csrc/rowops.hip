@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ gamma, T* __restrict__ dz_out,
                                                      T* __restrict__ dx_out, float* __restrict__ partials, int rows,
                                                      float drop_p, uint32_t drop_thr, uint32_t drop_key,
-                                                     const uint32_t* __restrict__ salt) {
+                                                     const uint32_t* __restrict__ salt, const T* __restrict__ dz_add) {
   constexpr int H = NV * 256;
   if (drop_p > 0.f) drop_key = bb_salted(drop_key, salt);
   __shared__ float4 s_red[3][4][NV * 64];  // [which][wave][lane-major float4]
@@ -160,6 +160,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       o.y = rs * (d[i].y - s1 - xh[i].y * s2);
       o.z = rs * (d[i].z - s1 - xh[i].z * s2);
       o.w = rs * (d[i].w - s1 - xh[i].w * s2);
+      if (dz_add != nullptr) {       // z has a second consumer (pre-norm residual stream): its gradient joins here
+        const float4 e = ld4<T>(dz_add + (size_t)row * H + col);
+        o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+      }
       if (dz_out != nullptr) st4<T>(dz_out + (size_t)row * H + col, o);
       if (drop_p > 0.f) {
         const uint32_t pr = ((uint32_t)row * H + col) >> 1;
@@ -782,17 +786,43 @@ BEVBERT_API int bevbert_colsum_finalize(const float* partials, int nblocks, int 
   return BB_OK;
 }
 
+static int layernorm_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                              void* dz, void* dx, const void* dz_add, float* dgamma, float* dbeta, float* dbias,
+                              float* workspace, int rows, int H, int dtype, float drop_p, uint64_t seed, uint64_t offset,
+                              int accumulate, hipStream_t stream);
+
 BEVBERT_API int bevbert_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd,
                                       const float* gamma, void* dz, void* dx, float* dgamma, float* dbeta,
                                       float* dbias, float* workspace, int rows, int H, int dtype, float drop_p,
                                       uint64_t seed, uint64_t offset, int accumulate, hipStream_t stream) {
+  return layernorm_bwd_impl(dy, z, mean, rstd, gamma, dz, dx, nullptr, dgamma, dbeta, dbias, workspace, rows, H, dtype,
+                            drop_p, seed, offset, accumulate, stream);
+}
+
+// The same with an addend: dz (and dx behind the dropout mask) receive LayerNorm's input gradient PLUS dz_add -- the
+// gradient that reaches z through its other consumer when z is also an output (the pre-norm residual stream of the
+// panorama encoder: src = src + dropout(sublayer(norm(src))), transformer.py:170-182).
+BEVBERT_API int bevbert_layernorm_bwd_add(const void* dy, const void* z, const float* mean, const float* rstd,
+                                          const float* gamma, void* dz, void* dx, const void* dz_add, float* dgamma,
+                                          float* dbeta, float* dbias, float* workspace, int rows, int H, int dtype,
+                                          float drop_p, uint64_t seed, uint64_t offset, int accumulate,
+                                          hipStream_t stream) {
+  return layernorm_bwd_impl(dy, z, mean, rstd, gamma, dz, dx, dz_add, dgamma, dbeta, dbias, workspace, rows, H, dtype,
+                            drop_p, seed, offset, accumulate, stream);
+}
+
+static int layernorm_bwd_impl(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                              void* dz, void* dx, const void* dz_add, float* dgamma, float* dbeta, float* dbias,
+                              float* workspace, int rows, int H, int dtype, float drop_p, uint64_t seed, uint64_t offset,
+                              int accumulate, hipStream_t stream) {
   BB_REQUIRE(H % 256 == 0, "layernorm_bwd: H=%d must be a multiple of 256", H);
   if (rows <= 0) return BB_OK;
   const int nb = partial_blocks(rows, 16);
   const uint32_t thr = bb_drop_threshold(drop_p);
 #define GO(T, N)                                                                                              \
   hipLaunchKernelGGL((ln_bwd_kernel<T, N>), dim3(nb), dim3(256), 0, stream, (const T*)dy, (const T*)z, mean, \
-                     rstd, gamma, (T*)dz, (T*)dx, workspace, rows, drop_p, thr, bb_site_key(seed, offset), bb_step_salt())
+                     rstd, gamma, (T*)dz, (T*)dx, workspace, rows, drop_p, thr, bb_site_key(seed, offset), bb_step_salt(), \
+                     (const T*)dz_add)
 #define SW(T)                                                                     \
   switch (H / 256) {                                                              \
     case 1: GO(T, 1); break;                                                      \

@@ -934,7 +934,7 @@ def use_param(p):
 # ----------------------------------------------------------------------------- K3 LayerNorm family
 class _BiasDropResLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bias, residual, gamma, beta, eps, drop_p, inplace_z, post1=None, post2=None):
+    def forward(ctx, x, bias, residual, gamma, beta, eps, drop_p, inplace_z, post1=None, post2=None, return_z=False):
         assert x.is_contiguous() and x.dim() >= 2
         H = x.shape[-1]
         rows = x.numel() // H
@@ -963,14 +963,27 @@ class _BiasDropResLN(torch.autograd.Function):
         ctx.params = (bias, gamma, beta)
         ctx.cfg = (rows, H, float(drop_p), RT.seed, off, residual is not None)
         ctx.posts = (post1 is not None, post2 is not None)
+        ctx.return_z = return_z
+        if return_z:
+            # pre-norm blocks (transformer.py:170-182): z = residual + dropout(x + bias) is the NEW residual stream and
+            # y = LayerNorm(z) feeds the next sub-layer; the gradient arriving at z is added to LayerNorm's input gradient
+            # inside the backward kernel (bevbert_layernorm_bwd_add)
+            assert need_grad and z is not None and z is not x
+            return y, z.view_as(z)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dz_in=None):
         z, mean, rstd = ctx.saved_tensors
         bias, gamma, beta = ctx.params
         rows, H, drop_p, seed, off, has_res = ctx.cfg
+        if dy is None:              # only z was used downstream: LayerNorm itself contributes nothing
+            dy = torch.zeros_like(z)
         dy = dy.contiguous()
+        add = None
+        if ctx.return_z and dz_in is not None:
+            add = dz_in.contiguous()
+            assert add.dtype == dy.dtype and add.shape == dy.shape
         dz = torch.empty_like(dy)
         dx = torch.empty_like(dy) if (drop_p > 0 and has_res) else None
         dev = dy.device
@@ -997,18 +1010,18 @@ class _BiasDropResLN(torch.autograd.Function):
             # the reduction joins the step's other pending reductions (ReduceQueue: one launch, off the critical path)
             nb = _partial_rows(rows)
             part = SCRATCH.alloc(nb * 3 * H * 4, dev)
-            call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz_ptr), ptr(dx),
-                 None, None, None, part, rows, H, dtype_code(dy), drop_p, seed, off, 1, stream())
+            call("bevbert_layernorm_bwd_add", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz_ptr), ptr(dx),
+                 ptr(add), None, None, None, part, rows, H, dtype_code(dy), drop_p, seed, off, 1, stream())
             ReduceQueue.add(part, nb, 3, H, (ptr(dg), ptr(db), ptr(dbi)))
         else:
-            call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz_ptr), ptr(dx),
-                 ptr(dg), ptr(db), ptr(dbi), ptr(ws), rows, H, dtype_code(dy), drop_p, seed, off, ag, stream())
+            call("bevbert_layernorm_bwd_add", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz_ptr), ptr(dx),
+                 ptr(add), ptr(dg), ptr(db), ptr(dbi), ptr(ws), rows, H, dtype_code(dy), drop_p, seed, off, ag, stream())
         gx = dx if dx is not None else dz
         gres = dz if has_res else None
         cast = lambda r, p: None if r is None else r.to(p.dtype)
         g1, g2 = (dy if has else None for has in ctx.posts)      # the post terms were added after the affine
         return (gx, cast(rbi, bias) if bias is not None else None, gres, cast(rg, gamma), cast(rb, beta), None, None, None,
-                g1, g2)
+                g1, g2, None)
 
 
 def bias_dropout_residual_layernorm(x, bias, residual, gamma, beta, eps, drop_p=0.0, training=False,
@@ -1016,6 +1029,25 @@ def bias_dropout_residual_layernorm(x, bias, residual, gamma, beta, eps, drop_p=
     """LayerNorm(dropout(x + bias) + residual)  -- vilmodel.py:150-154,189-193."""
     p = float(drop_p) if training else 0.0
     return _BiasDropResLN.apply(x, bias, residual, gamma, beta, eps, p, inplace_z, None, None)
+
+
+def bias_dropout_residual_prenorm(x, bias, residual, gamma, beta, eps, drop_p=0.0, training=False):
+    """(LayerNorm(z), z) with z = residual + dropout(x + bias): one launch for the residual add of a pre-norm block AND the
+    LayerNorm that opens the next sub-layer (transformer.py:170-182); backward likewise (the gradient reaching z from the
+    rest of the stream is folded into the LayerNorm backward kernel).  Inference / no-grad callers get the two tensors
+    from the same launch too."""
+    p = float(drop_p) if training else 0.0
+    if not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad)):
+        assert x.is_contiguous() and residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype
+        H = x.shape[-1]
+        rows = x.numel() // H
+        y, z = torch.empty_like(x), torch.empty_like(x)
+        off = RT.next_offset(x.numel()) if p > 0 else 0
+        call("bevbert_bias_dropout_residual_layernorm_fwd", ptr(x), ptr(_f32(bias)) if bias is not None else None,
+             ptr(residual), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(y), ptr(z), None, None, rows, H, float(eps),
+             dtype_code(x), p, RT.seed, off, stream())
+        return y, z
+    return _BiasDropResLN.apply(x, bias, residual, gamma, beta, eps, p, False, None, None, True)
 
 
 def bias_layernorm_plus(x, bias, gamma, beta, eps, post1, post2=None):

@@ -394,17 +394,26 @@ class TransformerEncoderLayer(nn.Module):
         self.attn_drop_p = dropout              # nn.MultiheadAttention keeps a float: set_dropout does not reach it
         self.dropout = nn.Dropout(dropout)      # transformer.py:142,146-147 dropout / dropout1 / dropout2 share p
 
-    def forward(self, src, key_mask):
+    def forward(self, src, key_mask, h, next_norm):
+        """``h``: norm1(src) if the previous block already computed it (None: compute it here); ``next_norm``: (weight,
+        bias, eps) of the LayerNorm that reads this layer's output (the next layer's norm1, or the encoder's final norm).
+        Returns (src_out, next_norm(src_out)).
+        The two residual adds of the block ride on the LayerNorm launches that follow them
+        (ops.bias_dropout_residual_prenorm): 2 row-kernel launches per block instead of 4, and no separate dropout /
+        gradient-add launches in backward."""
         tr, p = self.training, self.drop_p
-        h = ops.layernorm(src, self.norm1.weight, self.norm1.bias, 1e-5)
+        if h is None:
+            h = ops.layernorm(src, self.norm1.weight, self.norm1.bias, 1e-5)
         qkv = ops.linear(h, self.self_attn.in_proj_weight, self.self_attn.in_proj_bias)
         a = ops.attention_self(qkv, key_mask, None, self.nhead, self.attn_drop_p, tr)
-        o = ops.linear(a, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias)
-        src = ops.dropout(o, p, tr, residual=src)
-        h = ops.layernorm(src, self.norm2.weight, self.norm2.bias, 1e-5)
+        o = ops.linear(a, self.self_attn.out_proj.weight)                   # bias folded into the fused kernel below
+        h, src = ops.bias_dropout_residual_prenorm(o, self.self_attn.out_proj.bias, src, self.norm2.weight,
+                                                   self.norm2.bias, 1e-5, p, tr)
         f = ops.bias_gelu(ops.linear(h, self.linear1.weight), self.linear1.bias)
-        f = ops.linear(ops.dropout(f, p, tr), self.linear2.weight, self.linear2.bias)
-        return ops.dropout(f, p, tr, residual=src)
+        f = ops.linear(ops.dropout(f, p, tr), self.linear2.weight)
+        w, b, eps = next_norm
+        hn, src = ops.bias_dropout_residual_prenorm(f, self.linear2.bias, src, w, b, eps, p, tr)
+        return src, hn
 
 
 class TransformerEncoder(nn.Module):
@@ -420,9 +429,13 @@ class TransformerEncoder(nn.Module):
         if src_key_padding_mask is not None:      # boolean key_padding_mask -> -inf on padded keys (vilmodel.py:530-532)
             km = torch.zeros(src_key_padding_mask.shape, dtype=torch.float32, device=src.device)
             km = km.masked_fill(src_key_padding_mask, float("-inf")).contiguous()
-        for layer in self.layers:
-            src = layer(src, km)
-        return ops.layernorm(src, self.norm.weight, self.norm.bias, 1e-12)
+        src = src.contiguous()
+        h = None
+        for i, layer in enumerate(self.layers):
+            nxt = self.layers[i + 1].norm1 if i + 1 < len(self.layers) else self.norm
+            eps = 1e-5 if i + 1 < len(self.layers) else 1e-12
+            src, h = layer(src, km, h, (nxt.weight, nxt.bias, eps))
+        return h                     # = self.norm(src): computed by the last block's fused residual + LayerNorm
 
 
 def _small_k_linear(x, lin, out_dtype):
