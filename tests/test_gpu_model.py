@@ -496,7 +496,14 @@ def test_full_size_batch_properties(env, which):
         # data-parallel (TENSILE_STREAMK_DATA_PARALLEL=1)
         rel = float((g1 - g2).norm() / g1.norm())
         _record("rerun", f"{which} {task}", rel_l2=rel, differing=float((g1 != g2).float().mean()))
-        assert torch.equal(g1, g2), (task, rel)
+        if not torch.equal(g1, g2):          # say WHERE (the parameters and how many of their elements) before failing
+            where = []
+            for n, (o, k) in arena.slices.items():
+                c = int((g1[o:o + k] != g2[o:o + k]).sum())
+                if c:
+                    where.append(f"{n}: {c} of {k}")
+            raise AssertionError(f"{which} {task}: gradients of two identical backward passes differ (rel L2 {rel:.2e}) in "
+                                 + "; ".join(where[:12]))
         unused = {"sap": ("mlm_head.", "local_sem_head."), "mlm": ("global_sap_head.", "local_sap_head.", "local_sem_head.",
                                                                     "sap_fuse_linear."),
                   "masksem": ("mlm_head.predictions.transform", "global_sap_head.", "bert.global_encoder.")}[task]

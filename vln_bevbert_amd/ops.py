@@ -893,9 +893,33 @@ def _sink(param):
 
 
 def _mark_touched(param):
+    param = getattr(param, "table", param)          # RowOfTable: the parameter is the table
     arena = getattr(param, "arena", None)
     if arena is not None:
         arena.touch(param)
+
+
+class RowOfTable:
+    """Row ``r`` of an arena-resident embedding table used as the broadcast ``bias`` of a fused LayerNorm: the token-type
+    row that the reference adds to every panorama token (vilmodel.py:518-521 ``+ type_embed_layer(ones)``).  The
+    gradient of a broadcast term is the column sum of the LayerNorm's input gradient, i.e. exactly the kernel's dbias
+    output: it goes through the deterministic two-stage column reduction straight into the table's gradient row.  (As a
+    torch broadcast add its gradient was a torch ``sum`` over 11 520 rows -- whose result depended on what else the GPU
+    was running: the last source of run-to-run noise found in round 4.)"""
+
+    def __init__(self, table, r):
+        assert getattr(table, "main_grad", None) is not None or not table.requires_grad, \
+            "RowOfTable: the table must live in a ParamArena (its gradient row is written by the LayerNorm backward)"
+        self.table, self.r = table, int(r)
+        self.dtype, self.requires_grad = table.dtype, table.requires_grad
+
+    def detach(self):
+        return self.table.detach()[self.r]
+
+    @property
+    def main_grad(self):
+        mg = getattr(self.table, "main_grad", None)
+        return None if mg is None or not self.table.requires_grad else mg[self.r]
 
 
 def _compute(param):
@@ -992,6 +1016,8 @@ class _BiasDropResLN(torch.autograd.Function):
         for p in (gamma, beta, bias):
             if p is None:
                 outs.append((None, None, 0))
+            elif p is bias and not getattr(p, "requires_grad", True):
+                outs.append((None, None, None))          # a frozen bias (e.g. fix_lang_embedding): no gradient wanted
             elif _sink(p) is not None:
                 outs.append((_sink(p), None, 1))
                 _mark_touched(p)
@@ -999,7 +1025,7 @@ class _BiasDropResLN(torch.autograd.Function):
                 t = torch.empty(H, dtype=torch.float32, device=dev)
                 outs.append((t, t, 0))
         (dg, rg, ag), (db, rb, ab), (dbi, rbi, abi) = outs
-        assert ag == ab and (bias is None or abi == ag), "mixed arena / plain parameters in one LayerNorm"
+        assert ag == ab and (bias is None or abi is None or abi == ag), "mixed arena / plain parameters in one LayerNorm"
         # without a residual branch only dx is needed (it is the single input gradient)
         if not has_res and drop_p > 0:
             dx, dz_ptr = dz, None
@@ -1568,17 +1594,22 @@ class _EmbedLN(torch.autograd.Function):
         ws = RT.workspace(dy.device, 512 * 3 * H)
         sg, sb = _sink(gamma), _sink(beta)
         assert (sg is None) == (sb is None)
+        # the broadcast token-type row: its gradient is the column sum of dz = the kernel's third (dbias) output, through
+        # the deterministic two-stage reduction (a torch sum over the 5 120 rows would depend on the GPU's load)
+        styp = _sink(typ)[type_index] if (sg is not None and typ.requires_grad and _sink(typ) is not None) else None
         if sg is not None:
             _mark_touched(gamma); _mark_touched(beta)
+            if styp is not None:
+                _mark_touched(typ)
             if WgradStream.DEFER_FINALIZE:
                 nb = _partial_rows(rows)
                 part = SCRATCH.alloc(nb * 3 * H * 4, dy.device)
                 call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz), None,
                      None, None, None, part, rows, H, dtype_code(dy), 0.0, 0, 0, 1, stream())
-                ReduceQueue.add(part, nb, 3, H, (ptr(sg), ptr(sb), None))
+                ReduceQueue.add(part, nb, 3, H, (ptr(sg), ptr(sb), ptr(styp)))
             else:
                 call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz), None,
-                     ptr(sg), ptr(sb), None, ptr(ws), rows, H, dtype_code(dy), 0.0, 0, 0, 1, stream())
+                     ptr(sg), ptr(sb), ptr(styp), ptr(ws), rows, H, dtype_code(dy), 0.0, 0, 0, 1, stream())
             rg = rb = None
         else:
             rg = torch.empty(H, dtype=torch.float32, device=dy.device)
@@ -1598,6 +1629,8 @@ class _EmbedLN(torch.autograd.Function):
         for p, make in makers:
             if not p.requires_grad:
                 outs.append(None)
+            elif p is typ and styp is not None:
+                outs.append(None)              # written by the LayerNorm backward's column reduction above
             elif _sink(p) is not None:
                 _mark_touched(p)
                 deferred.append((make, _sink(p)))

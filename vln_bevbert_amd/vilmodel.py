@@ -23,6 +23,8 @@ from .arena import ParamArena
 from .config import BevBertConfig
 
 LN_EPS = 1e-12
+# captured steps (a side stream exists): the text-independent front of the map / BEV branches runs beside the text encoder
+EARLY_BEV = __import__("os").environ.get("BEVBERT_EARLY_BEV", "0") == "1"     # measured SLOWER (18.39 vs 18.23 ms): off
 
 
 def gen_seq_masks(seq_lens, max_len):
@@ -359,9 +361,11 @@ class CrossmodalEncoder(_Finalizable):
             img_embeds = layer(txt_embeds, tm, img_embeds, im, graph_sprels=graph_sprels, ctx_kv=kv)
         return img_embeds
 
-    def forward_lang2visn(self, txt_embeds, txt_key_mask, visn_feats, visn_key_mask):
-        """The MLM direction (vilmodel.py:790-800): text queries over fixed map / BEV tokens in every layer."""
-        kvs = self.hoist_kv(visn_feats)
+    def forward_lang2visn(self, txt_embeds, txt_key_mask, visn_feats, visn_key_mask, kvs=None):
+        """The MLM direction (vilmodel.py:790-800): text queries over fixed map / BEV tokens in every layer.  ``kvs``: the
+        hoisted K|V projections of ``visn_feats`` if the caller computed them ahead (they do not depend on the text)."""
+        if kvs is None:
+            kvs = self.hoist_kv(visn_feats)
         for layer, kv in zip(self.x_layers, kvs):
             txt_embeds = layer.forward_lang2visn(txt_embeds, txt_key_mask, visn_feats, visn_key_mask, ctx_kv=kv)
         return txt_embeds
@@ -502,9 +506,15 @@ class ImageEmbeddings(nn.Module):
         loc = _small_k_linear(loc_fts, self.loc_linear, cd)
         # ((e + LN(loc)) + nav_type) + token_type: the first two sums ride on the store of LN(loc)
         e = ops.bias_layernorm_plus(loc, self.loc_linear.bias, self.loc_layer_norm.weight, self.loc_layer_norm.bias, 1e-12,
-                                    e, embedding_lookup(self.nav_type_embedding, nav_types)) \
-            + embedding_lookup(type_embed_layer, torch.ones(1, 1, dtype=torch.long, device=e.device))
-        e = ops.layernorm(e, self.layer_norm.weight, self.layer_norm.bias, 1e-12)
+                                    e, embedding_lookup(self.nav_type_embedding, nav_types))
+        if getattr(type_embed_layer.weight, "main_grad", None) is not None or not type_embed_layer.weight.requires_grad:
+            # + token-type row 1 as the broadcast bias of the final LayerNorm (added in fp32 inside the kernel; its gradient
+            # is the kernel's deterministic column reduction: ops.RowOfTable)
+            e = ops.bias_dropout_residual_layernorm(e, ops.RowOfTable(type_embed_layer.weight, 1), None,
+                                                    self.layer_norm.weight, self.layer_norm.bias, 1e-12)
+        else:       # plain-tensor parameters (no arena): the torch composition
+            e = e + embedding_lookup(type_embed_layer, torch.ones(1, 1, dtype=torch.long, device=e.device))
+            e = ops.layernorm(e, self.layer_norm.weight, self.layer_norm.bias, 1e-12)
         e = ops.dropout(e, self.drop_p, self.training)
         masks = gen_seq_masks(lens, e.shape[1])
         if self.pano_encoder is not None:
@@ -587,8 +597,11 @@ class LocalBEVEncoder(nn.Module):
             bev_masks = torch.ones(bev_embeds.shape[:2], dtype=torch.bool, device=bev_embeds.device)
         return torch.cat([bev_embeds, obj_embeds], 1), torch.cat([bev_masks, obj_masks], 1)
 
-    def forward(self, txt_embeds, txt_masks, bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, obj_embeds, obj_masks):
-        bev_embeds = self.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
+    def forward(self, txt_embeds, txt_masks, bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, obj_embeds, obj_masks,
+                bev_in=None):
+        """``bev_in``: the input embedding if the caller has computed it already (on a side stream, beside the text
+        encoder: it does not depend on the text)."""
+        bev_embeds = bev_in if bev_in is not None else self.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
         x, m = self.with_objects(bev_embeds, bev_masks, obj_embeds, obj_masks)
         x = self.encoder(txt_embeds, txt_masks, x.contiguous(), m)
         K = self.bev_dim * self.bev_dim
@@ -759,7 +772,17 @@ class GlocalTextPathCMT(nn.Module):
                                   traj_vp_obj_lens, traj_view_dep_fts)
             tok_lens, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host,
                                                       obj_lens_host)
+        # ... and, behind it, the BEV input embedding (28 224-row GEMM + two LayerNorms): it does not depend on the text
+        # either, and the text encoder's 5 120-row kernels leave most of the chip idle (round-4 timeline: 1.3 busy queues
+        # on average during the first 4.3 ms of a step)
+        bev_in = None
+        if br.on and EARLY_BEV and not has_obj:
+            br.fork(bev_fts, bev_pos_fts, bev_nav_masks)
+            with br.side():
+                bev_in = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
         txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
+        if bev_in is not None:
+            br.join(bev_in)
         if has_obj:             # the object tokens feed the BEV branch: they are needed on the current stream
             br.join(traj)
             obj_embeds, obj_masks = self._obj_tokens(traj, traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens,
@@ -773,7 +796,8 @@ class GlocalTextPathCMT(nn.Module):
                                                   tok_lens, gmap_csr)
                 gmap_embeds = self.global_encoder(txt_embeds, txt_masks, g_in, g_masks, gmap_pair_dists)
         bev_embeds, obj_embeds = self.local_encoder(txt_embeds, txt_masks, bev_fts, bev_pos_fts,
-                                                    _all_ones_to_none(bev_masks), bev_nav_masks, obj_embeds, obj_masks)
+                                                    _all_ones_to_none(bev_masks), bev_nav_masks, obj_embeds, obj_masks,
+                                                    bev_in=bev_in)
         br.join(gmap_embeds)
         return gmap_embeds, bev_embeds, obj_embeds, obj_masks
 
@@ -784,21 +808,36 @@ class GlocalTextPathCMT(nn.Module):
                     gmap_csr=None, traj_view_dep_fts=None):
         br = ops.Branches(txt_ids.device)
         br.fork(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts, traj_vp_obj_lens,
-                traj_view_dep_fts)
+                traj_view_dep_fts, bev_fts, bev_pos_fts, bev_nav_masks, gmap_step_ids, gmap_pos_fts, gmap_lens)
+        tok_lens, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host, obj_lens_host)
+        early = br.on and EARLY_BEV and traj_obj_img_fts is None
+        g_in = g_masks = g_kvs = bev_in = bev_kvs = None
         with br.side():         # panorama encoder next to the text encoder
             traj = self._traj(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, traj_obj_img_fts,
                               traj_vp_obj_lens, traj_view_dep_fts)
+            if early:
+                # ... and everything else of the step that does not depend on the text: the map / BEV input embeddings and
+                # the K|V projections of all cross-attention layers over them (one 28 224 x 6 144 x 768 GEMM for the BEV):
+                # ~0.5 ms of large kernels beside the text encoder's small ones instead of behind them
+                g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
+                                                  gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens, gmap_csr)
+                g_kvs = self.global_encoder.encoder.hoist_kv(g_in)
+                bev_in = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks).contiguous()
+                bev_kvs = self.local_encoder.encoder.hoist_kv(bev_in)
         txt_embeds, txt_masks = self._text(txt_ids, txt_lens)
         tm = neg_key_mask(txt_masks)
-        tok_lens, ol_host = self._token_lens_host(traj_vp_view_lens, traj_vp_obj_lens, view_lens_host, obj_lens_host)
+        if early:
+            br.join(bev_in, *[t for t in bev_kvs if t is not None])
         # side stream: text queries over the global map;  current stream: text queries over the BEV (+ objects)
         br.fork(txt_embeds, tm, gmap_step_ids, gmap_pos_fts, gmap_lens)
         with br.side():
-            g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
-                                              gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens, gmap_csr)
+            if not early:
+                g_in, g_masks = self._gmap_inputs(traj, traj_step_lens, traj_vp_view_lens, traj_vpids, traj_cand_vpids,
+                                                  gmap_vpids, gmap_step_ids, gmap_pos_fts, gmap_lens, tok_lens, gmap_csr)
             gm = neg_key_mask(g_masks)
-            g_txt = self.global_encoder.encoder.forward_lang2visn(txt_embeds, tm, g_in, gm)
-        bev_in = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
+            g_txt = self.global_encoder.encoder.forward_lang2visn(txt_embeds, tm, g_in, gm, kvs=g_kvs)
+        if not early:
+            bev_in = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
         obj_embeds = obj_masks = None
         if traj_obj_img_fts is not None:
             br.join(traj)
@@ -807,7 +846,7 @@ class GlocalTextPathCMT(nn.Module):
                                                                 obj_masks)
         bev_in = bev_in.contiguous()
         bm = neg_key_mask(bev_obj_masks)
-        b_txt = self.local_encoder.encoder.forward_lang2visn(txt_embeds, tm, bev_in, bm)
+        b_txt = self.local_encoder.encoder.forward_lang2visn(txt_embeds, tm, bev_in, bm, kvs=bev_kvs)
         br.join(g_txt)
         return g_txt + b_txt
 
