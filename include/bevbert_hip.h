@@ -344,6 +344,16 @@ int bevbert_gm_nav_vars(const bevbert_gm_state* st, const int* node, const int* 
 int bevbert_gm_bev_select(const bevbert_gm_state* st, const int* cur, int order, int R, int* rows, uint8_t* live,
                           float* T_c2w, int* overflow, hipStream_t stream);
 
+/* agent.py:485-494 without gradients: embed_sum (B,N,H) / embed_cnt (B,N) running sums of the node embeddings (slot = node
+ * index): the current viewpoint's slot is rewritten with avg (B,H), every not-yet-visited candidate j < ncand[b] accumulates
+ * pano (B,V,H)[b, j].  live (B) bytes; cand (B,C) node indices (-1 = none). */
+int bevbert_gm_embed_update(const bevbert_gm_state* st, void* embed_sum, float* embed_cnt, const void* avg, const void* pano,
+                            const uint8_t* live, const int* cur, const int* ncand, const int* cand, int C, int V, int H,
+                            int dtype, hipStream_t stream);
+/* graph_utils.py:146-147 for the listed nodes: out (B,G,H), row 0 = [stop] = 0, row j = sum / count of node[b, j-1]. */
+int bevbert_gm_node_embeds(const bevbert_gm_state* st, const void* embed_sum, const float* embed_cnt, const int* node,
+                           const int* cnt, int G, int H, int dtype, void* out, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

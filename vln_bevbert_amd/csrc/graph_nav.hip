@@ -214,6 +214,65 @@ __global__ __launch_bounds__(64) void gm_bev_select_kernel(GmState s, const int*
   }
 }
 
+// agent.py:485-494 for inference rollouts: the current viewpoint's embedding slot is REWRITTEN with the panorama mean, every
+// not-yet-visited candidate ACCUMULATES the embedding of the view it was seen in (running mean = sum / count).  Slot = node
+// index.  grid (B, 1 + C): y = 0 -> the current viewpoint, y = j + 1 -> candidate j.  Sums are kept in the tensor's dtype
+// (bf16 sums round after every addition, exactly like the torch index_put path used when gradients are required).
+template <typename T>
+__global__ __launch_bounds__(256) void gm_embed_update_kernel(GmState s, T* __restrict__ embed_sum, float* __restrict__ embed_cnt,
+                                                              const T* __restrict__ avg, const T* __restrict__ pano,
+                                                              const uint8_t* __restrict__ live, const int* __restrict__ cur,
+                                                              const int* __restrict__ ncand, const int* __restrict__ cand,
+                                                              int C, int V, int H) {
+  const int b = blockIdx.x, j = (int)blockIdx.y - 1, N = s.N;
+  if (!live[b]) return;
+  if (j < 0) {
+    const int k = cur[b];
+    T* dst = embed_sum + ((size_t)b * N + k) * H;
+    for (int c = threadIdx.x * 4; c < H; c += 1024) st4<T>(dst + c, ld4<T>(avg + (size_t)b * H + c));
+    if (threadIdx.x == 0) embed_cnt[(size_t)b * N + k] = 1.f;
+    return;
+  }
+  if (j >= ncand[b] || j >= V) return;
+  const int m = cand[b * C + j];
+  if (m < 0 || s.visited[(size_t)b * N + m]) return;
+  T* dst = embed_sum + ((size_t)b * N + m) * H;
+  const T* src = pano + ((size_t)b * V + j) * H;
+  for (int c = threadIdx.x * 4; c < H; c += 1024) {
+    float4 a = ld4<T>(dst + c);
+    const float4 v = ld4<T>(src + c);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    st4<T>(dst + c, a);
+  }
+  if (threadIdx.x == 0) embed_cnt[(size_t)b * N + m] += 1.f;
+}
+
+// GraphMap.get_node_embed (graph_utils.py:146-147) for the listed nodes: out[b, 0] = 0 ([stop]), out[b, j] = sum / count of
+// node[b, j - 1] for j - 1 < cnt[b] (0 where nothing has been stored), padding rows 0.
+template <typename T>
+__global__ __launch_bounds__(256) void gm_node_embeds_kernel(GmState s, const T* __restrict__ embed_sum,
+                                                             const float* __restrict__ embed_cnt, const int* __restrict__ node,
+                                                             const int* __restrict__ cnt, int G, int H, T* __restrict__ out) {
+  const int b = blockIdx.x, j = blockIdx.y, N = s.N;
+  T* dst = out + ((size_t)b * G + j) * H;
+  float n = 0.f;
+  int m = 0;
+  if (j >= 1 && j - 1 < cnt[b]) {
+    m = node[(size_t)b * (G - 1) + j - 1];
+    n = embed_cnt[(size_t)b * N + m];
+  }
+  const T* src = embed_sum + ((size_t)b * N + m) * H;
+  for (int c = threadIdx.x * 4; c < H; c += 1024) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n > 0.f) {
+      a = ld4<T>(src + c);
+      // the torch path divides in the tensor's dtype by the count cast to that dtype: one rounding of the quotient
+      a.x = a.x / n; a.y = a.y / n; a.z = a.z / n; a.w = a.w / n;
+    }
+    st4<T>(dst + c, a);
+  }
+}
+
 static int gm_check(const GmState* st, const char* what) {
   BB_REQUIRE(st != nullptr && st->B > 0 && st->N > 0 && st->V > 0, "%s: empty graph-map state", what);
   BB_REQUIRE(st->pos && st->dis && st->point && st->hops && st->visited && st->step_ids, "%s: null state array", what);
@@ -252,5 +311,44 @@ BEVBERT_API int bevbert_gm_bev_select(const GmState* st, const int* cur, int ord
   BB_REQUIRE(st->pc_list && st->npc && st->node_row && st->node_T, "gm_bev_select: no visit list in the state");
   hipLaunchKernelGGL(gm_bev_select_kernel, dim3(st->B), dim3(64), 0, stream, *st, cur, order, R, rows, live, T_c2w, overflow);
   BB_CHECK_LAUNCH("gm_bev_select");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_gm_embed_update(const GmState* st, void* embed_sum, float* embed_cnt, const void* avg,
+                                        const void* pano, const uint8_t* live, const int* cur, const int* ncand,
+                                        const int* cand, int C, int V, int H, int dtype, hipStream_t stream) {
+  if (int rc = gm_check(st, "gm_embed_update")) return rc;
+  BB_REQUIRE(H % 4 == 0 && C >= 1 && V >= 1, "gm_embed_update: H=%d C=%d V=%d", H, C, V);
+  const dim3 grid(st->B, 1 + C);
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL(gm_embed_update_kernel<float>, grid, dim3(256), 0, stream, *st, (float*)embed_sum, embed_cnt,
+                       (const float*)avg, (const float*)pano, live, cur, ncand, cand, C, V, H);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL(gm_embed_update_kernel<bf16_raw>, grid, dim3(256), 0, stream, *st, (bf16_raw*)embed_sum, embed_cnt,
+                       (const bf16_raw*)avg, (const bf16_raw*)pano, live, cur, ncand, cand, C, V, H);
+  else {
+    bb_set_error("gm_embed_update: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("gm_embed_update");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_gm_node_embeds(const GmState* st, const void* embed_sum, const float* embed_cnt, const int* node,
+                                       const int* cnt, int G, int H, int dtype, void* out, hipStream_t stream) {
+  if (int rc = gm_check(st, "gm_node_embeds")) return rc;
+  BB_REQUIRE(H % 4 == 0 && G >= 1, "gm_node_embeds: H=%d G=%d", H, G);
+  const dim3 grid(st->B, G);
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL(gm_node_embeds_kernel<float>, grid, dim3(256), 0, stream, *st, (const float*)embed_sum, embed_cnt, node,
+                       cnt, G, H, (float*)out);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL(gm_node_embeds_kernel<bf16_raw>, grid, dim3(256), 0, stream, *st, (const bf16_raw*)embed_sum, embed_cnt,
+                       node, cnt, G, H, (bf16_raw*)out);
+  else {
+    bb_set_error("gm_node_embeds: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("gm_node_embeds");
   return BB_OK;
 }

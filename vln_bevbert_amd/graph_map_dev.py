@@ -172,11 +172,12 @@ class DeviceGraphMap:
         cand_dist = np.sqrt(d[..., 0] ** 2 + d[..., 1] ** 2 + d[..., 2] ** 2)
         arrays = {"live_g": live_g, "live_s": live_s, "cur": cur, "ncand": np.where(live_g > 0, ncand, 0).astype(np.int32),
                   "cand": np.maximum(cand, 0), "cur_pos": cur_pos, "cand_pos": cand_pos, "cand_dist": cand_dist,
-                  "n": self.n.copy()}
+                  "n": self.n.copy(), "ncand_all": ncand.astype(np.int32)}
         if store_rows is not None:
             arrays["row"] = np.where(live_s > 0, np.asarray(store_rows, dtype=np.int32), -1).astype(np.int32)
             arrays["T"] = self._poses(obs)
         up = self.feed(arrays)
+        self._last_up = (obs, up, C, live_s.copy())          # the step record stays on the device for update_node_embeds
         lib.call("bevbert_gm_update", self._st_ptr, up["live_g"].data_ptr(), up["live_s"].data_ptr(), up["cur"].data_ptr(),
                  up["ncand"].data_ptr(), up["cand"].data_ptr(), up["cur_pos"].data_ptr(), up["cand_pos"].data_ptr(),
                  up["cand_dist"].data_ptr(), up["n"].data_ptr(), C, int(step_id), up["row"].data_ptr() if store_rows is not None else None,
@@ -212,6 +213,24 @@ class DeviceGraphMap:
         """agent.py:485-494 for the whole batch (as GraphMapBatch.update_node_embeds; the slot of a node is its index)."""
         cur, cand, ncand = self._resolve(obs, False)
         live = self._live(ended).astype(bool)
+        if not (torch.is_grad_enabled() and (avg_pano_embeds.requires_grad or pano_embeds.requires_grad)):
+            # inference rollouts: one launch on the step record that is on the device already (the device's own visited
+            # flags decide which candidates accumulate); with gradients the functional index_put path below keeps the
+            # stored embeddings differentiable across steps like the reference's stored tensors
+            lu = getattr(self, "_last_up", None)
+            if lu is not None and lu[0] is obs and np.array_equal(lu[3].astype(bool), live):
+                up, C = lu[1], lu[2]
+                live_p, cur_p, nc_p, cand_p = up["live_s"], up["cur"], up["ncand_all"], up["cand"]
+            else:
+                C = cand.shape[1]
+                up = self.feed({"live": live.astype(np.uint8), "cur": cur, "ncand": ncand, "cand": cand})
+                live_p, cur_p, nc_p, cand_p = up["live"], up["cur"], up["ncand"], up["cand"]
+            avg = avg_pano_embeds.detach().to(self.dtype).contiguous()
+            pano = pano_embeds.detach().to(self.dtype).contiguous()
+            lib.call("bevbert_gm_embed_update", self._st_ptr, self.t["embed_sum"].data_ptr(), self.t["embed_cnt"].data_ptr(),
+                     avg.data_ptr(), pano.data_ptr(), live_p.data_ptr(), cur_p.data_ptr(), nc_p.data_ptr(), cand_p.data_ptr(),
+                     C, pano.shape[1], self.H, lib.dtype_code(self.t["embed_sum"]), lib.stream())
+            return
         rb = np.nonzero(live)[0]
         if not len(rb):
             return
@@ -277,7 +296,12 @@ class DeviceGraphMap:
                  pos.data_ptr(), gpos.data_ptr(), lib.stream())
         self._gpos = (obs, gpos)
         # running-mean node embeddings of the listed nodes ([stop] / padding rows = 0)
-        if G > 1:
+        if not (torch.is_grad_enabled() and self.t["embed_sum"].requires_grad):
+            embeds = torch.empty(B, G, self.H, dtype=self.dtype, device=dev)
+            lib.call("bevbert_gm_node_embeds", self._st_ptr, self.t["embed_sum"].data_ptr(), self.t["embed_cnt"].data_ptr(),
+                     up["node"].data_ptr(), up["cnt"].data_ptr(), G, self.H, lib.dtype_code(embeds), embeds.data_ptr(),
+                     lib.stream())
+        elif G > 1:
             nd = up["node"].long()
             bt = torch.arange(B, device=dev)[:, None].expand(-1, G - 1)
             c = self.t["embed_cnt"][bt, nd]
@@ -319,13 +343,18 @@ class DeviceGraphMap:
         K = bev_dim * bev_dim
         cand_vpids = [[None] + [c["viewpointId"] for c in ob["candidate"]] for ob in obs]
         cells = GraphMapBatch.cand_cells_batch(obs, bev_dim, bev_res)
-        C = 1 + max(len(c) for c in cells)
+        counts = np.fromiter((len(c) for c in cells), dtype=np.int64, count=B)
+        C = 1 + int(counts.max())
         cand_np = np.zeros((B, C), dtype=np.int64)
         cand_np[:, 0] = (K - 1) // 2                                  # [stop]: the centre cell (agent.py:318)
         nav_masks = np.zeros((B, K), dtype=bool)
-        for i, c in enumerate(cells):
-            cand_np[i, 1:1 + len(c)] = c
-            nav_masks[i, cand_np[i, :1 + len(c)]] = True
+        nav_masks[:, (K - 1) // 2] = True
+        if counts.sum():
+            bi = np.repeat(np.arange(B), counts)
+            ji = np.arange(int(counts.sum())) - np.repeat(np.cumsum(counts) - counts, counts)
+            flat = np.concatenate(cells)
+            cand_np[bi, 1 + ji] = flat
+            nav_masks[bi, flat] = True
         up = self.feed({"cur": cur, "T_w2c": pose_matrix(xyzhe), "S": S, "nav_masks": nav_masks, "cand": cand_np})
         dev = self.device
         rows = torch.empty(B, R, dtype=torch.int32, device=dev)
