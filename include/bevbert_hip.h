@@ -161,8 +161,8 @@ int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const 
 
 /* backward of the word-embedding gather of BertEmbeddings (vilmodel.py:50,67): table_grad[t, :] += sum of d[r, :] over
  * the rows with ids[r] == t, rows with ids[r] == padding_idx skipped (nn.Embedding(padding_idx=0); -1: none).  No
- * atomics: the first row of every id sums its id's rows in ascending row order (four contiguous quarters, folded
- * pairwise), so the result is a pure function of the inputs.  H % 4 == 0, H <= 1024. */
+ * atomics: the first row of every id sums its id's rows in ascending row order (four waves, one contiguous quarter of
+ * the row range each, folded pairwise), so the result is a pure function of the inputs.  H % 4 == 0, H <= 1024. */
 int bevbert_embedding_grad(const int64_t* ids, const void* d, float* table_grad, int rows, int H, int padding_idx,
                            int dtype, hipStream_t stream);
 

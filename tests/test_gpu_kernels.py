@@ -336,7 +336,8 @@ def test_small_table_embedding_grad_sliced(ops, table_rows, rows, dtype):
 def test_word_embedding_grad_is_deterministic_and_honours_padding_idx(ops, rows, V, H, dtype):
     """bevbert_embedding_grad (backward of BertEmbeddings' word lookup, vilmodel.py:50,67): equals index_add_ with the
     padding row left alone, accumulates into the sink, and gives the SAME BITS on every run -- no atomics.  (5120, 9):
-    ~570 rows per id, (3000, 40) with a 1 700-row run of one id: list batches beyond 1 024 entries are drained in turn."""
+    ~570 rows per id; (3000, 40) with 1 700 rows of one id spread over the whole range: every wave of the leader finds
+    hundreds of matches in its quarter."""
     from vln_bevbert_amd.lib import call, dtype_code, ptr, stream
     torch.manual_seed(11)
     ids = torch.randint(0, V, (rows,), device=DEV)

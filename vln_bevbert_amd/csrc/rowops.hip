@@ -432,17 +432,17 @@ __global__ __launch_bounds__(256) void multi_accum_kernel(const AccumTask* __res
 // table_grad[t] += sum of d[r] over the rows r with ids[r] == t, WITHOUT atomics and in a fixed order (training runs are
 // bit-reproducible; the reference's index_add is not).  One workgroup per gradient row r: it returns at once unless r
 // is the FIRST row carrying its id (and the id is not padding_idx: nn.Embedding(padding_idx=0) gives the padding row no
-// lookup gradient, vilmodel.py:50); the leader then collects the later rows with the same id in ascending order
-// (wave ballots -> ordered compaction into an LDS list), its four waves sum contiguous quarters of each list batch in
-// row order, the four partial sums are folded as (w0 + w1) + (w2 + w3), and the leader alone read-modify-writes the
-// table row.  rows^2 / 256 id comparisons per launch (5 120 rows: the id vector stays in L2).
-#define EG_LIST 1024
+// lookup gradient, vilmodel.py:50).  The leader's four waves each scan one contiguous quarter of the rows [r, rows) for
+// the same id -- 64 ids per ballot, four ballots' loads in flight -- and add the matching rows of d in ascending row
+// order, every lane owning its columns (no LDS list, no barrier inside the scan); the four partial sums are folded as
+// (w0 + w1) + (w2 + w3) and the leader alone read-modify-writes the table row.  The result is a pure function of (ids, d).
+// rows^2 / 256 id comparisons per launch (5 120 rows: the id vector stays in L2).
 #define EG_MAXJ 4          // float4 column groups per lane: H <= 64 lanes * 4 floats * EG_MAXJ = 1024
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_grad_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d,
                                                              float* __restrict__ table_grad, int rows, int H,
                                                              int padding_idx) {
-  __shared__ int s_flag, s_wc[4], s_list[EG_LIST];
+  __shared__ int s_flag;
   __shared__ float s_part[4][256 * EG_MAXJ];
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t id = ids[r];
@@ -457,41 +457,30 @@ __global__ __launch_bounds__(256) void embedding_grad_kernel(const int64_t* __re
   float4 acc[EG_MAXJ];
 #pragma unroll
   for (int j = 0; j < EG_MAXJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  int cnt = 0;                              // uniform: every thread derives it from the same LDS counts
-  for (int base = r; base < rows; base += 256) {
-    const int i = base + tid;
-    const bool m = i < rows && ids[i] == id;
-    const unsigned long long bal = __ballot(m);
-    if (lane == 0) s_wc[wave] = __popcll(bal);
-    __syncthreads();
-    int before = cnt;
-    for (int w = 0; w < wave; ++w) before += s_wc[w];
-    const int tot = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
-    if (m) s_list[before + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-    cnt += tot;
-    __syncthreads();
-    if (cnt > EG_LIST - 256 || base + 256 >= rows) {        // drain the list: wave w sums its quarter in row order
-      const int q = (cnt + 3) >> 2, lo = wave * q, hi = min(cnt, lo + q);
-      for (int k = lo; k < hi; k += 4) {
-        float4 v[4][EG_MAXJ];
+  const int span = rows - r, q = (span + 3) >> 2;
+  const int lo = r + wave * q, hi = min(rows, lo + q);
+  for (int base = lo; base < hi; base += 256) {
+    unsigned long long bal[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int row = s_list[min(k + u, hi - 1)];
+    for (int u = 0; u < 4; ++u) {           // four independent loads, then four ballots
+      const int i = base + 64 * u + lane;
+      bal[u] = __ballot(i < hi && ids[i] == id);
+    }
 #pragma unroll
-          for (int j = 0; j < EG_MAXJ; ++j) {
-            const int c = (lane + 64 * j) * 4;
-            v[u][j] = (k + u < hi && c < H) ? ld4<T>(d + (size_t)row * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 4; ++u) {
+      unsigned long long b = bal[u];
+      while (b) {                           // wave-uniform: the matching rows of these 64, in ascending order
+        const int row = base + 64 * u + (__ffsll((long long)b) - 1);
+        b &= b - 1;
+#pragma unroll
+        for (int j = 0; j < EG_MAXJ; ++j) {
+          const int c = (lane + 64 * j) * 4;
+          if (c < H) {
+            const float4 v = ld4<T>(d + (size_t)row * H + c);
+            acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
           }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int j = 0; j < EG_MAXJ; ++j) {
-            acc[j].x += v[u][j].x; acc[j].y += v[u][j].y; acc[j].z += v[u][j].z; acc[j].w += v[u][j].w;
-          }
       }
-      cnt = 0;
-      __syncthreads();
     }
   }
 #pragma unroll
