@@ -430,6 +430,44 @@ def _obj_grads(ref, cfg, tasks, B, seed):
     return out
 
 
+def merge_autocast_errors(ref, tag, outputs, grads=None):
+    """gen_autocast_errors for the configurations that are generated by their own functions / processes (RxR vocabulary,
+    CE fork): ``outputs()`` / ``grads()`` return {name: tensor} / {name: sub-sampled array}; the per-tensor errors of the
+    reference's autocast-bf16 run against its fp32 run are MERGED into tests/golden/ref_autocast_errors.npz."""
+    print(f"reference autocast-bf16 vs fp32, per tensor [{tag}]")
+    path = os.path.join(OUT, "ref_autocast_errors.npz")
+    arrs = dict(np.load(path)) if os.path.exists(path) else {}
+    orig = ref.lift_splat
+
+    def lift_fp32(batch):
+        with torch.autocast("cpu", enabled=False):
+            return orig(batch)
+    want = outputs()
+    want_g = grads() if grads else {}
+    ref.lift_splat = lift_fp32
+    try:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            got = outputs()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            got_g = grads() if grads else {}
+    finally:
+        del ref.lift_splat
+    for k, w in want.items():
+        w, gt = npy(w.float()).astype(np.float64), npy(got[k].float()).astype(np.float64)
+        fin = np.isfinite(w) & np.isfinite(gt)
+        scale = max(1e-6, np.abs(w[fin]).max())
+        err = np.abs(w[fin] - gt[fin])
+        arrs[f"{tag}::{k}::max_rel"] = np.float64(err.max() / scale)
+        arrs[f"{tag}::{k}::mean_rel"] = np.float64(err.mean() / scale)
+        print(f"   {k:28s} max-abs/absmax {err.max() / scale:.3e}  mean-abs/absmax {err.mean() / scale:.3e}")
+    for k, w in want_g.items():
+        w, gt = np.asarray(w, dtype=np.float64), np.asarray(got_g[k], dtype=np.float64)
+        l2 = np.linalg.norm(gt - w) / max(1e-12, np.linalg.norm(w))
+        arrs[f"{tag}::{k}::rel_l2"] = np.float64(l2)
+        print(f"   {k:60s} rel-L2 {l2:.3e}")
+    save("ref_autocast_errors", **arrs)
+
+
 def gen_autocast_errors(ref, cfg, tag, B, seed, ragged, arrs, obj_tasks=None):
     """The yardstick of the bf16 parity gates: how far the REFERENCE's own autocast-bf16 run
     (train_r2r.py:256-258 torch.cuda.amp.autocast; bf16 per BASELINE.json) sits from its fp32 run, per compared tensor --
@@ -684,6 +722,30 @@ def gen_ce():
                 arrs[f"{task}_grad::{k}"] = sub(p.grad, 97 if p.numel() > 4096 else 1)
     save("tasks_tiny_ce", **arrs)
 
+    def outputs():
+        out = {}
+        with torch.no_grad():
+            for task in ("mlm", "sap"):
+                b = synthetic.make_batch(cfg, task, B, seed=seed, ragged=True)
+                out[f"{task}_loss"] = ref(dict(b), task, True)
+                o = ref(dict(b), task, False)
+                if task == "sap":
+                    out["sap_fused"] = o[2]
+        return out
+
+    def grads():
+        out = {}
+        for task in ("mlm", "sap"):
+            ref.zero_grad(set_to_none=True)
+            b = synthetic.make_batch(cfg, task, B, seed=seed, ragged=True)
+            ref(dict(b), task, True).mean().backward()
+            for k, p in ref.named_parameters():
+                if p.grad is not None and k in CE_GRAD_KEYS:
+                    out[f"{task}_grad::{k}"] = sub(p.grad.float(), 97 if p.numel() > 4096 else 1)
+        ref.zero_grad(set_to_none=True)
+        return out
+    merge_autocast_errors(ref, "tiny_ce", outputs, grads)
+
 
 CE_GRAD_KEYS = {
     "bert.img_embeddings.dep_linear.weight", "bert.img_embeddings.dep_layer_norm.bias",
@@ -714,6 +776,21 @@ def gen_rxr():
         else:
             arrs.update(sap_global=npy(outs[0]), sap_local=npy(outs[1]), sap_fused=npy(outs[2]))
     save("tasks_tiny_rxr", **arrs)
+
+    def outputs():
+        out = {}
+        with torch.no_grad():
+            b = synthetic.make_batch(cfg, "mlm", B, seed=seed, txt_len=160, ragged=True)
+            out["rxr mlm_loss"] = ref(dict(b), "mlm", True)
+            sc = ref(dict(b), "mlm", False)
+            out["rxr mlm_scores"] = torch.from_numpy(sub(sc, 4099).copy())
+            out["rxr mlm_rowmax"] = sc.max(1).values
+            b = synthetic.make_batch(cfg, "sap", B, seed=seed, txt_len=160, ragged=True)
+            out["rxr sap_loss"] = ref(dict(b), "sap", True)
+            o = ref(dict(b), "sap", False)
+            out.update({"rxr sap_global": o[0], "rxr sap_local": o[1], "rxr sap_fused": o[2]})
+        return out
+    merge_autocast_errors(ref, "tiny_rxr", outputs)
 
 
 def gen_graph():

@@ -29,9 +29,10 @@ FP32_TOL = 1e-3          # north_star: "within 1e-3 fp32"
 # and 82 gradient comparisons of this suite (profiles/r04_bf16_errors_vs_reference_autocast.txt): median 1.10 / 1.06, worst
 # 2.6 (the global-map embeddings of the full R2R model: 1.26e-2 against the reference's 0.48e-2) / 2.1.  3 = twice the
 # roundings plus the sampling noise of a maximum over a few hundred entries.  An fp32 residual stream would close the gap
-# at ~1.5 ms per training step of extra LayerNorm traffic and was not built.  Tensors of
-# configurations without a reference autocast vector (RxR vocabulary, CE fork, fine-tune API) fall back to the
-# reference's WORST own error over all recorded tensors x the same factor.
+# at ~1.5 ms per training step of extra LayerNorm traffic and was not built.  The golden covers
+# the tiny (ragged / fixed), object-token (REVERIE, separate obj_linear), RxR-vocabulary, CE-fork and full-R2R batches;
+# a tensor without an entry (the fine-tune API's three modes) falls back to the reference's WORST own error over all
+# recorded tensors x the same factor.
 BF16_MEAN_TOL = 1e-2
 REF_FACTOR = 3.0
 BF16_GRAD_FLOOR = 0.05
@@ -428,7 +429,7 @@ def test_rxr_vocabulary_tasks_gpu(env, dtype):
         if fp32:
             assert max_abs(got, ref) < FP32_TOL, (what, max_abs(got, ref))
         else:
-            bf16_close(got, ref, what)
+            bf16_close(got, ref, what, "tiny_rxr")
 
     with torch.no_grad():
         b = synthetic.batch_to(synthetic.make_batch(cfg, "mlm", B, seed=seed, txt_len=L, ragged=True), DEV)
