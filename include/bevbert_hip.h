@@ -344,6 +344,11 @@ int bevbert_gm_nav_vars(const bevbert_gm_state* st, const int* node, const int* 
 int bevbert_gm_bev_select(const bevbert_gm_state* st, const int* cur, int order, int R, int* rows, uint8_t* live,
                           float* T_c2w, int* overflow, hipStream_t stream);
 
+/* agent.py:150-156,168-176: the stored views of the selected nodes, out[i] = live[i] ? store[rows[i]] : 0 for i < n_out;
+ * store / out rows are row_bytes bytes (V x h x w depths of any element type). */
+int bevbert_gm_gather_views(const void* store, const int* rows, const uint8_t* live, void* out, int n_out, int64_t row_bytes,
+                            hipStream_t stream);
+
 /* agent.py:485-494 without gradients: embed_sum (B,N,H) / embed_cnt (B,N) running sums of the node embeddings (slot = node
  * index): the current viewpoint's slot is rewritten with avg (B,H), every not-yet-visited candidate j < ncand[b] accumulates
  * pano (B,V,H)[b, j].  live (B) bytes; cand (B,C) node indices (-1 = none). */

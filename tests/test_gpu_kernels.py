@@ -830,6 +830,26 @@ def test_splat_reads_store_rows_in_place(ops):
     assert a.shape == (B, dim * dim, C) and float(a.float().abs().sum()) > 0
 
 
+@pytest.mark.parametrize("dtype,V,hw", [(torch.float32, 12, 14), (torch.float16, 12, 14), (torch.float16, 3, 3),
+                                        (torch.uint8, 3, 3), (torch.float32, 1, 1)])
+def test_gather_views_of_selected_nodes(ops, dtype, V, hw):
+    """bevbert_gm_gather_views == index_select + zeroed padding slots (agent.py:150-156), for every word width the launch
+    picks (16 / 4 / 2 / 1 bytes by the row size and the alignment), rows repeated, slots dead."""
+    from vln_bevbert_amd import lib
+    g = torch.Generator().manual_seed(5)
+    N, n_out = 11, 23
+    store = (torch.rand(N + 1, V, hw, hw, generator=g) * 200).to(DEV).to(dtype)
+    rows = torch.randint(0, N, (n_out,), generator=g).to(DEV, torch.int32)
+    live = (torch.rand(n_out, generator=g) < 0.7).to(DEV)
+    for view in (store[:N], store[1:]):                       # the second start is aligned to the element size only
+        out = torch.full((n_out, V, hw, hw), 7, dtype=dtype, device=DEV)
+        lib.call("bevbert_gm_gather_views", view.data_ptr(), rows.data_ptr(), live.data_ptr(), out.data_ptr(), n_out,
+                 V * hw * hw * view.element_size(), lib.stream())
+        ref = view.index_select(0, rows.long()) * live.to(dtype)[:, None, None, None]
+        assert torch.equal(out, ref)
+    lib.call("bevbert_gm_gather_views", store.data_ptr(), rows.data_ptr(), live.data_ptr(), out.data_ptr(), 0, 4, lib.stream())
+
+
 def test_lt_gemm_tuning_table_round_trip(ops, tmp_path):
     """The choices of autotuned plans can be exported and re-imported (bevbert_gemm_tuning_export / _import)."""
     g = torch.Generator().manual_seed(9)

@@ -603,14 +603,18 @@ def test_bucket_manager_never_refills_a_buffer_set_the_consumer_still_holds():
 
 
 def test_host_feed_cpu_fallback_and_bucket_padding():
-    """graph_map.HostFeed on a CPU device is the plain per-array conversion (the packed pinned ring is for the GPU);
-    nav_static pads the node / candidate axes to multiples of the bucket step."""
+    """graph_map.HostFeed on a CPU device packs like on the GPU (without pinning): typed views of one buffer, addresses for
+    kernel arguments without a view; nav_static pads the node / candidate axes to multiples of the bucket step."""
     from vln_bevbert_amd.graph_map import HostFeed
     from vln_bevbert_amd.nav_static import _pad_to
     arrays = {"a": np.arange(6, dtype=np.int64).reshape(2, 3)[:, ::2], "m": np.array([True, False]), "e": np.zeros((0, 4), np.float32)}
     out = HostFeed("cpu")(arrays)
     for k, v in arrays.items():
         assert torch.equal(out[k], torch.from_numpy(np.ascontiguousarray(v))), k
+    sh = HostFeed("cpu", slots=2).ship(arrays)
+    for k, v in arrays.items():
+        assert (sh.ptr(k) == sh[k].data_ptr() or v.size == 0) and sh.ptr(k) % 16 == 0 and k in sh
+        assert torch.equal(sh[k], torch.from_numpy(np.ascontiguousarray(v))) and sh[k].shape == v.shape
     assert HostFeed.shared("cpu") is HostFeed.shared("cpu")
     assert [_pad_to(n, 8) for n in (1, 2, 8, 9, 16, 17)] == [8, 8, 8, 16, 16, 24]
 

@@ -314,6 +314,42 @@ BEVBERT_API int bevbert_gm_bev_select(const GmState* st, const int* cur, int ord
   return BB_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// views of the selected nodes out of the feature store: out[i] = live[i] ? store[rows[i]] : 0, rows of `row_bytes` bytes
+// (agent.py:150-156 pads the point clouds of a batch with empty views; one launch for index_select + mask)
+template <typename W>
+__global__ __launch_bounds__(256) void gm_gather_views_kernel(const W* __restrict__ store, const int* __restrict__ rows,
+                                                              const uint8_t* __restrict__ live, W* __restrict__ out,
+                                                              int words, int chunks) {
+  const int o = blockIdx.x / chunks, c = blockIdx.x % chunks;
+  const bool ok = live[o] != 0;
+  const W* s = store + (size_t)rows[o] * words;
+  W* d = out + (size_t)o * words;
+  const int per = (words + chunks - 1) / chunks, lo = c * per, hi = min(words, lo + per);
+  W zero;
+  __builtin_memset(&zero, 0, sizeof(W));
+  for (int i = lo + threadIdx.x; i < hi; i += 256) d[i] = ok ? s[i] : zero;
+}
+
+BEVBERT_API int bevbert_gm_gather_views(const void* store, const int* rows, const uint8_t* live, void* out, int n_out,
+                                        int64_t row_bytes, hipStream_t stream) {
+  BB_REQUIRE(store && rows && live && out, "gm_gather_views: null pointer");
+  BB_REQUIRE(n_out >= 0 && row_bytes > 0, "gm_gather_views: n_out=%d row_bytes=%lld", n_out, (long long)row_bytes);
+  if (n_out == 0) return BB_OK;
+  const int chunks = (int)std::min<int64_t>(8, (row_bytes + 4095) / 4096);      // >= 4 KiB per workgroup
+  const uintptr_t bits = (uintptr_t)store | (uintptr_t)out | (uintptr_t)row_bytes;   // widest word that divides all three
+#define GATHER(W)                                                                                                        \
+  hipLaunchKernelGGL(gm_gather_views_kernel<W>, dim3(n_out * chunks), dim3(256), 0, stream, (const W*)store, rows, live, \
+                     (W*)out, (int)(row_bytes / sizeof(W)), chunks)
+  if (bits % 16 == 0) GATHER(uint4);
+  else if (bits % 4 == 0) GATHER(uint32_t);
+  else if (bits % 2 == 0) GATHER(uint16_t);
+  else GATHER(uint8_t);
+#undef GATHER
+  BB_CHECK_LAUNCH("gm_gather_views");
+  return BB_OK;
+}
+
 BEVBERT_API int bevbert_gm_embed_update(const GmState* st, void* embed_sum, float* embed_cnt, const void* avg,
                                         const void* pano, const uint8_t* live, const int* cur, const int* ncand,
                                         const int* cand, int C, int V, int H, int dtype, hipStream_t stream) {

@@ -86,15 +86,23 @@ class HostFeed:
         return f
 
     def __call__(self, arrays):
-        if not self.cuda:
-            return {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.device) for k, v in arrays.items()}
+        """{name: device tensor} of the packed arrays (typed views of one device buffer)."""
+        sh = self.ship(arrays)
+        return {k: sh[k] for k in arrays}
+
+    def ship(self, arrays):
+        """As ``__call__`` but returns a ``Shipped``: device addresses for kernel arguments (``ptr(name)``) without a
+        tensor view per array -- three torch calls each, the larger part of a call with a dozen small arrays -- and
+        tensor views made on first use (``[name]``) for the arrays a caller hands on."""
         with self._lock:
-            return self._ship({k: np.ascontiguousarray(v) for k, v in arrays.items()})
+            return self._ship(arrays)
 
     def _ship(self, arrays):
-        offs, total = {}, 0
+        meta, total = {}, 0
         for k, v in arrays.items():
-            offs[k] = total
+            if not v.flags.c_contiguous:
+                v = np.ascontiguousarray(v)
+            meta[k] = (total, v.nbytes, v.dtype, v.shape, v)
             total += (v.nbytes + 15) // 16 * 16
         total = max(total, 16)
         slot = self.ring[self.i]
@@ -102,19 +110,51 @@ class HostFeed:
         if slot["ev"] is not None:
             slot["ev"].synchronize()
         if slot["buf"] is None or slot["buf"].numel() < total:
-            slot["buf"] = torch.empty(max(2 * total, 1 << 20), dtype=torch.uint8).pin_memory()
-        host = slot["buf"].numpy()
-        for k, v in arrays.items():
-            host[offs[k]:offs[k] + v.nbytes] = v.reshape(-1).view(np.uint8)
+            buf = torch.empty(max(2 * total, 1 << 20), dtype=torch.uint8)
+            slot["buf"] = buf.pin_memory() if self.cuda else buf
+            slot["np"] = slot["buf"].numpy()
+        host = slot["np"]
+        for off, n, _, _, v in meta.values():
+            if n:
+                host[off:off + n] = v.reshape(-1).view(np.uint8)
         devbuf = torch.empty(total, dtype=torch.uint8, device=self.device)
         devbuf.copy_(slot["buf"][:total], non_blocking=True)
-        slot["ev"] = torch.cuda.Event()
-        slot["ev"].record(torch.cuda.current_stream(self.device))
-        out = {}
-        for k, v in arrays.items():
-            tdt = torch.from_numpy(np.empty(0, dtype=v.dtype)).dtype
-            out[k] = devbuf[offs[k]:offs[k] + v.nbytes].view(tdt).view(v.shape)
-        return out
+        if self.cuda:
+            if slot["ev"] is None:
+                slot["ev"] = torch.cuda.Event()
+            slot["ev"].record(torch.cuda.current_stream(self.device))
+        return Shipped(devbuf, meta)
+
+
+_TORCH_DTYPES = {}
+
+
+def _torch_dtype(np_dtype):
+    t = _TORCH_DTYPES.get(np_dtype)
+    if t is None:
+        t = _TORCH_DTYPES[np_dtype] = torch.from_numpy(np.empty(0, dtype=np_dtype)).dtype
+    return t
+
+
+class Shipped:
+    """The arrays of one HostFeed call, on the device in one buffer."""
+    __slots__ = ("buf", "base", "meta", "_views")
+
+    def __init__(self, buf, meta):
+        self.buf, self.base, self.meta, self._views = buf, buf.data_ptr(), meta, {}
+
+    def ptr(self, name):
+        return self.base + self.meta[name][0]
+
+    def __contains__(self, name):
+        return name in self.meta
+
+    def __getitem__(self, name):
+        v = self._views.get(name)
+        if v is None:
+            off, n, dt, shape, _ = self.meta[name]
+            v = self._views[name] = self.buf[off:off + n].view(_torch_dtype(dt)).view(shape)
+        return v
 
 
 class FloydGraph:
@@ -576,25 +616,35 @@ class GraphMapBatch:
     def cand_cells_batch(obs, bev_dim, bev_res):
         """cand_cells for every sample: one pass of numpy over all candidates of the batch; only the 4-term products stay
         per-sample numpy matmuls (same BLAS path, hence the same roundings, as the reference's np.dot)."""
-        counts = [len(ob["candidate"]) for ob in obs]
-        total = sum(counts)
-        if total == 0:
+        counts = np.fromiter((len(ob["candidate"]) for ob in obs), dtype=np.int64, count=len(obs))
+        if counts.sum() == 0:
             return [np.zeros(0, dtype=np.int64) for _ in obs]
-        xyzhe = np.zeros((len(obs), 5))
-        xyzhe[:, 3] = [-ob["heading"] for ob in obs]
-        T = pose_matrix(xyzhe)
-        flip = np.array([1, 1, -1], dtype=np.float32)
-        S = np.asarray([ob["position"] for ob in obs], dtype=np.float32)[:, [0, 2, 1]] * flip
-        P = np.asarray([c["position"] for ob in obs for c in ob["candidate"]], dtype=np.float32)[:, [0, 2, 1]] * flip
-        P = P - np.repeat(S, counts, axis=0)
-        p1 = np.concatenate([P, np.ones((total, 1), dtype=np.float32)], -1)
+        cells = GraphMapBatch.cand_cells_flat(
+            np.array([ob["position"] for ob in obs], dtype=np.float64).reshape(len(obs), 3),
+            np.array([ob["heading"] for ob in obs], dtype=np.float64),
+            np.array([c["position"] for ob in obs for c in ob["candidate"]], dtype=np.float64),
+            counts, np.repeat(np.arange(len(obs)), counts), bev_dim, bev_res)
         ends = np.cumsum(counts)
+        return [cells[ends[i] - n:ends[i]] for i, n in enumerate(counts)]
+
+    @staticmethod
+    def cand_cells_flat(pos, heading, cand_pos, counts, sample, bev_dim, bev_res, T=None):
+        """cand_cells for the candidates of a whole batch, flattened: ``pos`` (B, 3) / ``heading`` (B,) of the agents,
+        ``cand_pos`` (sum(counts), 3), ``sample`` = the batch index of each candidate (all float64, as the simulator's)."""
+        if T is None:                        # ``T``: pose_matrix of heading -h per sample, when the caller has it already
+            xyzhe = np.zeros((len(pos), 5))
+            xyzhe[:, 3] = -heading
+            T = pose_matrix(xyzhe)
+        flip = np.array([1, 1, -1], dtype=np.float32)
+        S = pos.astype(np.float32)[:, [0, 2, 1]] * flip
+        P = cand_pos.astype(np.float32)[:, [0, 2, 1]] * flip
+        P = P - S[sample]
+        p1 = np.concatenate([P, np.ones((len(P), 1), dtype=np.float32)], -1)
         # one stacked (1 x 4) @ (4 x 4) product per candidate: the same BLAS path per row as the reference's per-sample
         # np.dot, hence the same roundings (checked bit for bit against the per-sample loop: tests/test_host_logic.py)
-        q = np.matmul(p1[:, None, :], T[np.repeat(np.arange(len(obs)), counts)])[:, 0]           # see cand_cells
+        q = np.matmul(p1[:, None, :], T[sample])[:, 0]                                            # see cand_cells
         c = np.clip(np.round(q[:, [0, 2]] / bev_res) + (bev_dim - 1) // 2, 0, bev_dim - 1).astype(np.int64)
-        cells = c[:, 1] * bev_dim + c[:, 0]
-        return [cells[ends[i] - n:ends[i]] for i, n in enumerate(counts)]
+        return c[:, 1] * bev_dim + c[:, 0]
 
     @staticmethod
     def cand_cells(ob, bev_dim, bev_res):

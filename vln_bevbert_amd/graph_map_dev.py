@@ -18,6 +18,7 @@ bit-equal to ``GraphMapBatch`` (hence to the reference's GraphMap, golden graph_
 position features come from the device math library (<= 2 ulp).
 """
 import ctypes
+from itertools import chain
 
 import numpy as np
 import torch
@@ -32,26 +33,34 @@ class _GmState(ctypes.Structure):
                                                 "node_row", "node_T")] + [(n, ctypes.c_int) for n in ("B", "N", "V", "pad")]
 
 
+class _Digest:
+    __slots__ = ("pos", "heading", "elevation", "counts", "total", "cands", "C", "bi", "ji", "cand_pos", "cand_ids",
+                 "T_views", "T_w2c", "T_neg")
+
+
 class DeviceGraphMap:
     """Drop-in for GraphMapBatch in the rollout loop (scripts/bench_nav.py, the agent): same calls, same outputs."""
+    _dig = _last = _last_up = _gpos = _feed = None      # per-step caches, keyed by the identity of the step's ``obs`` list
 
     def __init__(self, start_vps, hidden_size, device, dtype=torch.float32, node_capacity=64, views=12):
-        self.B, self.H, self.device, self.dtype = len(start_vps), hidden_size, torch.device(device), dtype
-        if self.device.type != "cuda":
+        device = torch.device(device)
+        if device.type != "cuda":
             raise lib.BevBertHipError("DeviceGraphMap keeps the maps in device memory: it needs the MI355X "
                                       "(graph_map.GraphMapBatch is the host-side form)")
+        self._setup(start_vps, hidden_size, device, dtype, node_capacity, views)
+
+    def _setup(self, start_vps, hidden_size, device, dtype, node_capacity, views):
+        self.B, self.H, self.device, self.dtype = len(start_vps), hidden_size, device, dtype
         self.V = views
         self.start_vps = list(start_vps)
         self.index = [{} for _ in range(self.B)]          # viewpoint id -> node index (registration order)
         self.names = [[] for _ in range(self.B)]
-        self.adj = [{} for _ in range(self.B)]            # node -> set of nodes it was observed next to
         self.n = np.zeros(self.B, dtype=np.int32)
         self.N = 0
         self._alloc(node_capacity)
         for b, vp in enumerate(self.start_vps):           # node 0 of every episode: its start viewpoint (GraphMap.__init__)
             self._node(b, vp)
         self._overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._last = None                                 # (obs object, resolved arrays) of the latest _resolve
         self._point_host = None
 
     # -- storage -------------------------------------------------------------------------------------------------------
@@ -72,6 +81,7 @@ class DeviceGraphMap:
             "embed_cnt": torch.zeros(B, N, dtype=torch.float32, device=dev),
         }
         vis_host = np.zeros((B, N), dtype=bool)
+        adj_host = np.zeros((B, N, N), dtype=bool)        # "was observed next to" (an upper bound for bev_inputs' gather)
         if old:                                           # growth (rare: capacity 64 covers 15-step R2R episodes)
             for k in ("dis", "point", "hops"):
                 new[k][:, :old, :old] = self.t[k]
@@ -79,7 +89,8 @@ class DeviceGraphMap:
                 new[k][:, :old] = self.t[k]
             new["npc"].copy_(self.t["npc"])
             vis_host[:, :old] = self.visited_host
-        self.t, self.N, self.visited_host = new, N, vis_host
+            adj_host[:, :old, :old] = self.adj_host
+        self.t, self.N, self.visited_host, self.adj_host = new, N, vis_host, adj_host
         st = _GmState()
         for k in ("pos", "dis", "point", "hops", "visited", "step_ids", "pc_list", "npc", "node_row", "node_T"):
             setattr(st, k, new[k].data_ptr())
@@ -92,7 +103,10 @@ class DeviceGraphMap:
 
     @property
     def feed(self):
-        return HostFeed.shared(self.device)
+        f = self._feed
+        if f is None:
+            f = self._feed = HostFeed.shared(self.device)
+        return f
 
     # -- viewpoint ids -> node indices (the only per-sample Python) -----------------------------------------------------
     def _node(self, b, vp):
@@ -104,6 +118,32 @@ class DeviceGraphMap:
             self.n[b] = i + 1
         return i
 
+    def _digest(self, obs):
+        """The numbers of a step's observation dicts, read once per step: positions, headings, candidate lists flattened
+        over the batch (``bi`` / ``ji``: sample and slot of each candidate)."""
+        d = self._dig
+        if d is not None and d[0] is obs:
+            return d[1]
+        B = self.B
+        cands = [ob["candidate"] for ob in obs]
+        counts = np.fromiter(map(len, cands), dtype=np.int64, count=B)
+        tot = int(counts.sum())
+        flat = [c for cc in cands for c in cc]
+        g = _Digest()
+        g.pos = np.array([ob["position"] for ob in obs], dtype=np.float64).reshape(B, 3)
+        g.heading = np.array([ob["heading"] for ob in obs], dtype=np.float64)
+        g.elevation = np.array([ob["elevation"] for ob in obs], dtype=np.float64)
+        g.counts, g.total, g.cands = counts, tot, cands
+        g.C = max(1, int(counts.max())) if B else 1
+        g.bi = np.repeat(np.arange(B), counts)
+        g.ji = np.arange(tot) - np.repeat(np.cumsum(counts) - counts, counts)
+        g.cand_pos = np.fromiter(chain.from_iterable([c["position"] for c in flat]), dtype=np.float64,
+                                 count=3 * tot).reshape(tot, 3)
+        g.cand_ids = [c["viewpointId"] for c in flat]
+        g.T_views = g.T_w2c = g.T_neg = None
+        self._dig = (obs, g)
+        return g
+
     def _resolve(self, obs, register, ended=None):
         """(cur (B,), cand (B,C) node indices padded with -1, ncand (B,)) of a step's observations.  ``register``: new
         ids of live samples become nodes (update_graph); otherwise unknown candidate ids resolve to -1."""
@@ -111,28 +151,26 @@ class DeviceGraphMap:
         last = self._last
         if last is not None and last[0] is obs and not register:
             return last[1]
-        C = max(1, max(len(ob["candidate"]) for ob in obs))
-        cur = np.zeros(B, dtype=np.int32)
-        cand = np.full((B, C), -1, dtype=np.int32)
-        ncand = np.zeros(B, dtype=np.int32)
+        g = self._digest(obs)
+        cur_l, cand_l, ids, k0 = [0] * B, [], g.cand_ids, 0
+        counts = g.counts.tolist()
         for b, ob in enumerate(obs):
-            live = register and not (ended is not None and ended[b])
-            idx = self.index[b]
-            if live:
-                k = cur[b] = self._node(b, ob["viewpoint"])
-                cc = ob["candidate"]
-                ncand[b] = len(cc)
-                a = self.adj[b].setdefault(k, set())
-                for j, c in enumerate(cc):
-                    m = cand[b, j] = self._node(b, c["viewpointId"])
-                    a.add(m)
-                    self.adj[b].setdefault(m, set()).add(k)
+            idx, nb = self.index[b], counts[b]
+            if register and not (ended is not None and ended[b]):
+                cur_l[b] = self._node(b, ob["viewpoint"])
+                for vp in ids[k0:k0 + nb]:
+                    i = idx.get(vp)
+                    cand_l.append(self._node(b, vp) if i is None else i)
             else:
-                cur[b] = idx[ob["viewpoint"]]
-                cc = ob["candidate"]
-                ncand[b] = len(cc)
-                for j, c in enumerate(cc):
-                    cand[b, j] = idx.get(c["viewpointId"], -1)
+                cur_l[b] = idx[ob["viewpoint"]]
+                get = idx.get
+                cand_l.extend([get(vp, -1) for vp in ids[k0:k0 + nb]])
+            k0 += nb
+        cur = np.array(cur_l, dtype=np.int32)
+        cand = np.full((B, g.C), -1, dtype=np.int32)
+        if g.total:
+            cand[g.bi, g.ji] = cand_l
+        ncand = g.counts.astype(np.int32)
         out = (cur, cand, ncand)
         self._last = (obs, out)
         return out
@@ -146,42 +184,49 @@ class DeviceGraphMap:
         cur, cand, ncand = self._resolve(obs, True, ended)
         if int(self.n.max()) > self.N:
             self._alloc(max(2 * self.N, int(self.n.max())))
-        live_g = np.ones(B, dtype=np.uint8) if ended is None else (~np.asarray(ended, dtype=bool)).astype(np.uint8)
-        self.visited_host[np.nonzero(live_g)[0], cur[live_g.astype(bool)]] = True
+        lv = np.ones(B, dtype=bool) if ended is None else ~np.asarray(ended, dtype=bool)
+        live_g = lv.view(np.uint8)
+        self.visited_host[np.nonzero(lv)[0], cur[lv]] = True
+        g = self._digest(obs)
+        if g.total:
+            lc = lv[g.bi]
+            b_ = g.bi[lc]
+            k_, m_ = cur[b_], cand[b_, g.ji[lc]]
+            self.adj_host[b_, k_, m_] = True
+            self.adj_host[b_, m_, k_] = True
         self._point_host = None
         self._launch_update(obs, cur, cand, ncand, live_g, np.zeros(B, dtype=np.uint8) if step_id <= 0 else
                             self._live(step_ended), step_id, store_rows)
 
     @staticmethod
     def _live_of(ended, B):
-        return np.ones(B, dtype=np.uint8) if ended is None else (~np.asarray(ended, dtype=bool)).astype(np.uint8)
+        return np.ones(B, dtype=np.uint8) if ended is None else (~np.asarray(ended, dtype=bool)).view(np.uint8)
 
     def _live(self, ended):
         return self._live_of(ended, self.B)
 
     def _launch_update(self, obs, cur, cand, ncand, live_g, live_s, step_id, store_rows):
         B, C = cand.shape
-        cur_pos = np.asarray([ob["position"] for ob in obs], dtype=np.float64).reshape(B, 3)
+        g = self._digest(obs)
+        cur_pos = g.pos
         cand_pos = np.zeros((B, C, 3), dtype=np.float64)
-        flat = [c["position"] for ob in obs for c in ob["candidate"]]
-        if flat:
-            bi = np.repeat(np.arange(B), [len(ob["candidate"]) for ob in obs])
-            ji = np.concatenate([np.arange(len(ob["candidate"])) for ob in obs])
-            cand_pos[bi, ji] = np.asarray(flat, dtype=np.float64)
-        d = cand_pos - cur_pos[:, None]             # edge lengths in float64, the reference's arithmetic (graph_utils.py:8-13)
-        cand_dist = np.sqrt(d[..., 0] ** 2 + d[..., 1] ** 2 + d[..., 2] ** 2)
+        cand_dist = np.zeros((B, C), dtype=np.float64)
+        if g.total:
+            cand_pos[g.bi, g.ji] = g.cand_pos
+            d = g.cand_pos - cur_pos[g.bi]          # edge lengths in float64, the reference's arithmetic (graph_utils.py:8-13)
+            cand_dist[g.bi, g.ji] = np.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2 + d[:, 2] ** 2)
         arrays = {"live_g": live_g, "live_s": live_s, "cur": cur, "ncand": np.where(live_g > 0, ncand, 0).astype(np.int32),
                   "cand": np.maximum(cand, 0), "cur_pos": cur_pos, "cand_pos": cand_pos, "cand_dist": cand_dist,
-                  "n": self.n.copy(), "ncand_all": ncand.astype(np.int32)}
+                  "n": self.n.copy(), "ncand_all": ncand}
         if store_rows is not None:
             arrays["row"] = np.where(live_s > 0, np.asarray(store_rows, dtype=np.int32), -1).astype(np.int32)
             arrays["T"] = self._poses(obs)
-        up = self.feed(arrays)
+        up = self.feed.ship(arrays)
         self._last_up = (obs, up, C, live_s.copy())          # the step record stays on the device for update_node_embeds
-        lib.call("bevbert_gm_update", self._st_ptr, up["live_g"].data_ptr(), up["live_s"].data_ptr(), up["cur"].data_ptr(),
-                 up["ncand"].data_ptr(), up["cand"].data_ptr(), up["cur_pos"].data_ptr(), up["cand_pos"].data_ptr(),
-                 up["cand_dist"].data_ptr(), up["n"].data_ptr(), C, int(step_id), up["row"].data_ptr() if store_rows is not None else None,
-                 up["T"].data_ptr() if store_rows is not None else None, lib.stream())
+        lib.call("bevbert_gm_update", self._st_ptr, up.ptr("live_g"), up.ptr("live_s"), up.ptr("cur"), up.ptr("ncand"),
+                 up.ptr("cand"), up.ptr("cur_pos"), up.ptr("cand_pos"), up.ptr("cand_dist"), up.ptr("n"), C, int(step_id),
+                 up.ptr("row") if store_rows is not None else None, up.ptr("T") if store_rows is not None else None,
+                 lib.stream())
 
     def set_step_ids(self, obs, t, ended=None):
         """agent.py:471-474 as its own call (the rollout loop of the reference sets them at the top of a step)."""
@@ -191,15 +236,23 @@ class DeviceGraphMap:
 
     def _poses(self, obs):
         """agent.py:114-126: the 12 camera-to-world matrices of a panorama -- position (x, z, -y), heading
-        -(k * 30 deg + heading), elevation pi -- in float64, cast to fp32 like the agent's."""
-        V = self.V
-        xyzhe = np.zeros((self.B, V, 5))
-        p = np.asarray([ob["position"] for ob in obs], dtype=np.float64)
-        xyzhe[:, :, 0], xyzhe[:, :, 1], xyzhe[:, :, 2] = p[:, None, 0], p[:, None, 2], -p[:, None, 1]
-        hd = np.asarray([ob["heading"] for ob in obs], dtype=np.float64)
-        xyzhe[:, :, 3] = -(np.arange(V)[None] * np.radians(30) + hd[:, None])
-        xyzhe[:, :, 4] = np.pi
-        return pose_matrix(xyzhe.reshape(-1, 5)).reshape(self.B, V * 16).astype(np.float32)
+        -(k * 30 deg + heading), elevation pi -- in float64, cast to fp32 like the agent's.  The two per-sample matrices of
+        the step's BEV inputs (heading h: agent.py:306-311; heading -h: agent.py:284-287) come out of the same
+        ``pose_matrix`` call (it is element-wise: stacking the rows changes no value)."""
+        g = self._digest(obs)
+        if g.T_views is None:
+            B, V = self.B, self.V
+            xyzhe = np.zeros((B * (V + 2), 5))
+            views = xyzhe[:B * V].reshape(B, V, 5)
+            p, hd = g.pos, g.heading
+            views[:, :, 0], views[:, :, 1], views[:, :, 2] = p[:, None, 0], p[:, None, 2], -p[:, None, 1]
+            views[:, :, 3] = -(np.arange(V)[None] * np.radians(30) + hd[:, None])
+            views[:, :, 4] = np.pi
+            xyzhe[B * V:B * V + B, 3] = hd
+            xyzhe[B * V + B:, 3] = -hd
+            T = pose_matrix(xyzhe)
+            g.T_views, g.T_w2c, g.T_neg = T[:B * V].reshape(B, V * 16), T[B * V:B * V + B], T[B * V + B:]
+        return g.T_views
 
     def remember_views(self, obs, store_keys, store, ended=None, views=12):
         """GraphMap.update_node_pc's bookkeeping (agent.py:488): a visited node keeps its feature-store row and poses."""
@@ -220,15 +273,15 @@ class DeviceGraphMap:
             lu = getattr(self, "_last_up", None)
             if lu is not None and lu[0] is obs and np.array_equal(lu[3].astype(bool), live):
                 up, C = lu[1], lu[2]
-                live_p, cur_p, nc_p, cand_p = up["live_s"], up["cur"], up["ncand_all"], up["cand"]
+                live_p, cur_p, nc_p, cand_p = up.ptr("live_s"), up.ptr("cur"), up.ptr("ncand_all"), up.ptr("cand")
             else:
                 C = cand.shape[1]
-                up = self.feed({"live": live.astype(np.uint8), "cur": cur, "ncand": ncand, "cand": cand})
-                live_p, cur_p, nc_p, cand_p = up["live"], up["cur"], up["ncand"], up["cand"]
+                up = self.feed.ship({"live": live.astype(np.uint8), "cur": cur, "ncand": ncand, "cand": cand})
+                live_p, cur_p, nc_p, cand_p = up.ptr("live"), up.ptr("cur"), up.ptr("ncand"), up.ptr("cand")
             avg = avg_pano_embeds.detach().to(self.dtype).contiguous()
             pano = pano_embeds.detach().to(self.dtype).contiguous()
             lib.call("bevbert_gm_embed_update", self._st_ptr, self.t["embed_sum"].data_ptr(), self.t["embed_cnt"].data_ptr(),
-                     avg.data_ptr(), pano.data_ptr(), live_p.data_ptr(), cur_p.data_ptr(), nc_p.data_ptr(), cand_p.data_ptr(),
+                     avg.data_ptr(), pano.data_ptr(), live_p, cur_p, nc_p, cand_p,
                      C, pano.shape[1], self.H, lib.dtype_code(self.t["embed_sum"]), lib.stream())
             return
         rb = np.nonzero(live)[0]
@@ -277,12 +330,13 @@ class DeviceGraphMap:
         if enc_full_graph and G > 1:
             visited[:, 1:] = vis[np.arange(B)[:, None], node] & real
         names = self.names
-        vpids = [[None] + [names[b][k] for k in node[b, :cnt[b]]] for b in range(B)]
+        node_l, cnt_l = node.tolist(), cnt.tolist()
+        vpids = [[None] + [nb[k] for k in row[:c]] for nb, row, c in zip(names, node_l, cnt_l)]
         start = np.zeros(B, dtype=np.int32)      # the start viewpoint is the first node every episode registers
-        up = self.feed({"node": np.ascontiguousarray(node, dtype=np.int32) if G > 1 else np.zeros((B, 1), np.int32),
-                        "cnt": cnt.astype(np.int32), "cur": cur, "start": start,
-                        "heading": np.asarray([ob["heading"] for ob in obs], dtype=np.float64),
-                        "elevation": np.asarray([ob["elevation"] for ob in obs], dtype=np.float64)})
+        g = self._digest(obs)
+        up = self.feed.ship({"node": node.astype(np.int32) if G > 1 else np.zeros((B, 1), np.int32),
+                             "cnt": cnt.astype(np.int32), "cur": cur, "start": start,
+                             "heading": g.heading, "elevation": g.elevation})
         dev = self.device
         step_ids = torch.empty(B, G, dtype=torch.int64, device=dev)
         vis_t = torch.empty(B, G, dtype=torch.bool, device=dev)
@@ -290,8 +344,8 @@ class DeviceGraphMap:
         pair = torch.empty(B, G, G, dtype=torch.float32, device=dev)
         pos = torch.empty(B, G, 7, dtype=torch.float32, device=dev)
         gpos = torch.empty(B, 7, dtype=torch.float32, device=dev)
-        lib.call("bevbert_gm_nav_vars", self._st_ptr, up["node"].data_ptr(), up["cnt"].data_ptr(), up["cur"].data_ptr(),
-                 up["start"].data_ptr(), up["heading"].data_ptr(), up["elevation"].data_ptr(), G, int(enc_full_graph),
+        lib.call("bevbert_gm_nav_vars", self._st_ptr, up.ptr("node"), up.ptr("cnt"), up.ptr("cur"),
+                 up.ptr("start"), up.ptr("heading"), up.ptr("elevation"), G, int(enc_full_graph),
                  int(act_visited_nodes), step_ids.data_ptr(), vis_t.data_ptr(), masks.data_ptr(), pair.data_ptr(),
                  pos.data_ptr(), gpos.data_ptr(), lib.stream())
         self._gpos = (obs, gpos)
@@ -299,7 +353,7 @@ class DeviceGraphMap:
         if not (torch.is_grad_enabled() and self.t["embed_sum"].requires_grad):
             embeds = torch.empty(B, G, self.H, dtype=self.dtype, device=dev)
             lib.call("bevbert_gm_node_embeds", self._st_ptr, self.t["embed_sum"].data_ptr(), self.t["embed_cnt"].data_ptr(),
-                     up["node"].data_ptr(), up["cnt"].data_ptr(), G, self.H, lib.dtype_code(embeds), embeds.data_ptr(),
+                     up.ptr("node"), up.ptr("cnt"), G, self.H, lib.dtype_code(embeds), embeds.data_ptr(),
                      lib.stream())
         elif G > 1:
             nd = up["node"].long()
@@ -324,46 +378,41 @@ class DeviceGraphMap:
             return 1
         if order > 1:
             return max(1, int(self.visited_host.sum(1).max()))
-        r = 1
-        for b in range(self.B):
-            vh = self.visited_host[b]
-            r = max(r, 1 + sum(1 for m in self.adj[b].get(int(cur[b]), ()) if vh[m]))
-        return r
+        return 1 + int((self.adj_host[np.arange(self.B), cur] & self.visited_host).sum(1).max())
 
     def bev_inputs(self, obs, store, pc_order=1, bev_dim=21, bev_res=0.5):
         """agent.py:143-192,282-337 as inputs of the fused lift / splat kernels (see GraphMapBatch.bev_inputs): the choice
         of the visited neighbours, their store rows and poses come from the device-resident map."""
         B, V = self.B, self.V
         cur, _, _ = self._resolve(obs, False)
+        g = self._digest(obs)
         R = min(64, self._neighbour_bound(cur, pc_order))
-        P = np.asarray([ob["position"] for ob in obs], dtype=np.float32)
+        P = g.pos.astype(np.float32)
         S = np.stack([P[:, 0], P[:, 2], -P[:, 1]], 1)
-        xyzhe = np.zeros((B, 5))
-        xyzhe[:, 3] = [ob["heading"] for ob in obs]
+        self._poses(obs)
         K = bev_dim * bev_dim
-        cand_vpids = [[None] + [c["viewpointId"] for c in ob["candidate"]] for ob in obs]
-        cells = GraphMapBatch.cand_cells_batch(obs, bev_dim, bev_res)
-        counts = np.fromiter((len(c) for c in cells), dtype=np.int64, count=B)
-        C = 1 + int(counts.max())
+        ids, ends = g.cand_ids, np.cumsum(g.counts).tolist()
+        cand_vpids = [[None] + ids[e - n:e] for e, n in zip(ends, g.counts.tolist())]
+        C = 1 + int(g.counts.max())
         cand_np = np.zeros((B, C), dtype=np.int64)
         cand_np[:, 0] = (K - 1) // 2                                  # [stop]: the centre cell (agent.py:318)
         nav_masks = np.zeros((B, K), dtype=bool)
         nav_masks[:, (K - 1) // 2] = True
-        if counts.sum():
-            bi = np.repeat(np.arange(B), counts)
-            ji = np.arange(int(counts.sum())) - np.repeat(np.cumsum(counts) - counts, counts)
-            flat = np.concatenate(cells)
-            cand_np[bi, 1 + ji] = flat
-            nav_masks[bi, flat] = True
-        up = self.feed({"cur": cur, "T_w2c": pose_matrix(xyzhe), "S": S, "nav_masks": nav_masks, "cand": cand_np})
+        if g.total:
+            flat = GraphMapBatch.cand_cells_flat(g.pos, g.heading, g.cand_pos, g.counts, g.bi, bev_dim, bev_res, T=g.T_neg)
+            cand_np[g.bi, 1 + g.ji] = flat
+            nav_masks[g.bi, flat] = True
+        up = self.feed.ship({"cur": cur, "T_w2c": g.T_w2c, "S": S, "nav_masks": nav_masks, "cand": cand_np})
         dev = self.device
         rows = torch.empty(B, R, dtype=torch.int32, device=dev)
         live = torch.empty(B, R, dtype=torch.bool, device=dev)
         T_c2w = torch.empty(B, R * V, 4, 4, dtype=torch.float32, device=dev)
-        lib.call("bevbert_gm_bev_select", self._st_ptr, up["cur"].data_ptr(), int(pc_order), R, rows.data_ptr(),
+        lib.call("bevbert_gm_bev_select", self._st_ptr, up.ptr("cur"), int(pc_order), R, rows.data_ptr(),
                  live.data_ptr(), T_c2w.data_ptr(), self._overflow.data_ptr(), lib.stream())
-        depths = store.depths.index_select(0, rows.reshape(-1).long()).reshape(B, R * V, store.hw, store.hw)
-        depths = depths * live.repeat_interleave(V, 1)[..., None, None]                              # padding: no depth
+        sd = store.depths                                                    # (rows, V, h, w), contiguous
+        depths = torch.empty(B, R * V, store.hw, store.hw, dtype=sd.dtype, device=dev)
+        lib.call("bevbert_gm_gather_views", sd.data_ptr(), rows.data_ptr(), live.data_ptr(), depths.data_ptr(), B * R,
+                 V * store.hw * store.hw * sd.element_size(), lib.stream())       # padding slots: no depth
         g = getattr(self, "_gpos", None)
         if g is None or g[0] is not obs:       # position features of the start viewpoint come with nav_gmap_variable's launch
             self.nav_gmap_variable(obs)

@@ -106,6 +106,7 @@ _PROTOS = {
     "bevbert_gm_update": [_P] * 10 + [_I, _I, _P, _P, _P],
     "bevbert_gm_nav_vars": [_P] * 7 + [_I, _I, _I] + [_P] * 7,
     "bevbert_gm_bev_select": [_P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "bevbert_gm_gather_views": [_P, _P, _P, _P, _I, _I64, _P],
     "bevbert_gm_embed_update": [_P] * 9 + [_I, _I, _I, _I, _P],
     "bevbert_gm_node_embeds": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "bevbert_sap_loss_fwd": [_P] * 15 + [_I, _I, _I, _I, _I, _P],
