@@ -635,3 +635,87 @@ def test_nav_graph_runner_clears_stale_padding_after_a_full_width_fill():
         assert float(got["gmap_pair_dists"][:, :G, :G].min()) == G
         assert float(got["gmap_pair_dists"][:, G:].abs().max() if G < 8 else 0.0) == 0.0
         assert float(got["gmap_pair_dists"][:, :, G:].abs().max() if G < 8 else 0.0) == 0.0
+
+
+def test_device_graph_map_host_side_against_the_host_map(monkeypatch):
+    """graph_map_dev.DeviceGraphMap without the device: its host half (observation digest, id -> node lookups, node order,
+    what it ships to the kernels) on CPU tensors with the C-ABI launches recorded instead of run, against
+    graph_map.GraphMapBatch (pinned to the reference's GraphMap by tests/golden/graph_nav.npz).  The kernels' half is
+    tests/test_gpu_model.py::test_device_graph_map_equals_the_host_graph_map."""
+    from vln_bevbert_amd import graph_map_dev, lib
+    from vln_bevbert_amd.graph_map import GraphMapBatch
+    B, T, H, n_nodes, V = 6, 9, 8, 14, 12
+    calls = []
+    monkeypatch.setattr(lib, "call", lambda name, *a: calls.append((name, a)))
+    monkeypatch.setattr(lib, "stream", lambda: 0)
+
+    class HostSide(graph_map_dev.DeviceGraphMap):
+        def __init__(self, start_vps):
+            self._setup(start_vps, H, torch.device("cpu"), torch.float32, 8, V)       # capacity 8: exercises growth
+
+    class Store:
+        hw = 14
+        row = {f"scan{i}_e{i}_v{n}": i * n_nodes + n for i in range(B) for n in range(n_nodes)}
+        depths = torch.zeros(B * n_nodes, V, 14, 14)
+    Store.V = V
+    obs_all, ended_all = synthetic.make_nav_episodes(B, T, seed=31, n_nodes=n_nodes)
+    start = [ob["viewpoint"] for ob in obs_all[0]]
+    host, dev = GraphMapBatch(start, H, "cpu"), HostSide(start)
+    host.update_graph(obs_all[0])
+    g = torch.Generator().manual_seed(0)
+    saw_dead = False
+    for t in range(T):
+        obs, ended = obs_all[t], ended_all[t]
+        keys = [f"{ob['scan']}_{ob['viewpoint']}" for ob in obs]
+        avg, pano = torch.randn(B, H, generator=g), torch.randn(B, 36, H, generator=g)
+        if t > 0:
+            host.update_graph(obs, ended_all[t - 1])
+        host.set_step_ids(obs, t, ended)
+        host.remember_views(obs, keys, Store, ended)
+        calls.clear()
+        dev.update_graph(obs, None if t == 0 else ended_all[t - 1], step_id=t + 1, step_ended=ended,
+                         store_rows=[Store.row[k] for k in keys])
+        assert [c[0] for c in calls] == ["bevbert_gm_update"] and calls[0][1][10:12] == (dev._last_up[2], t + 1)
+        up = dev._last_up[1]
+        live_g = np.ones(B, bool) if t == 0 else ~np.asarray(ended_all[t - 1], dtype=bool)
+        live_s = ~np.asarray(ended, dtype=bool)
+        saw_dead |= not live_g.all()
+        assert np.array_equal(up["live_g"].numpy().astype(bool), live_g) and np.array_equal(up["live_s"].numpy().astype(bool), live_s)
+        assert np.array_equal(dev.n, host.n) and dev.names == [ep.names for ep in host.eps]
+        nm = int(host.n.max())
+        assert dev.N >= nm and np.array_equal(dev.visited_host[:, :nm], host.visited[:, :nm])
+        cur, cand, nc, dist = (up[k].numpy() for k in ("cur", "cand", "ncand", "cand_dist"))
+        for b in range(B):
+            ep, ob = host.eps[b], obs[b]
+            assert ep.names[cur[b]] == ob["viewpoint"]
+            assert nc[b] == (len(ob["candidate"]) if live_g[b] else 0) and up["ncand_all"][b] == len(ob["candidate"])
+            for j, c in enumerate(ob["candidate"]):
+                assert ep.names[cand[b, j]] == c["viewpointId"]
+                if live_g[b]:         # a direct edge is the shortest path between two viewpoints: the map holds its length
+                    assert dist[b, j] == ep.distance(ob["viewpoint"], c["viewpointId"]), (t, b, j)
+            if live_s[b]:
+                row, Tm = ep.pc_nodes[ob["viewpoint"]]
+                assert int(up["row"][b]) == row and np.array_equal(up["T"][b].numpy().reshape(V, 4, 4), Tm)
+            else:
+                assert int(up["row"][b]) == -1
+        cand_vpids = [[c["viewpointId"] for c in ob["candidate"]] for ob in obs]
+        host.update_node_embeds(obs, cand_vpids, avg, pano, ended)
+        calls.clear()
+        dev.update_node_embeds(obs, cand_vpids, avg, pano, ended)
+        assert [c[0] for c in calls] == ["bevbert_gm_embed_update"]
+        assert calls[0][1][5:9] == (up.ptr("live_s"), up.ptr("cur"), up.ptr("ncand_all"), up.ptr("cand"))   # the step record
+        calls.clear()
+        hn, dn = host.nav_gmap_variable(obs), dev.nav_gmap_variable(obs)
+        assert [c[0] for c in calls] == ["bevbert_gm_nav_vars", "bevbert_gm_node_embeds"]
+        assert dn["gmap_vpids"] == hn["gmap_vpids"] and dn["no_vp_left"] == hn["no_vp_left"]
+        assert torch.equal(dn["gmap_visited_masks_cpu"], hn["gmap_visited_masks_cpu"])
+        assert tuple(dn["gmap_pair_dists"].shape) == tuple(hn["gmap_pair_dists"].shape)
+        calls.clear()
+        hb, db = host.bev_inputs(obs, Store, pc_order=1), dev.bev_inputs(obs, Store, pc_order=1)
+        assert [c[0] for c in calls] == ["bevbert_gm_bev_select", "bevbert_gm_gather_views"]
+        assert tuple(db["grid_rows"].shape) == tuple(hb["grid_rows"].shape)             # the neighbour bound is tight
+        assert calls[1][1][4:6] == (B * hb["grid_rows"].shape[1], V * 14 * 14 * 4)
+        for k in ("T_w2c", "S_w2c", "bev_nav_masks", "bev_cand_idxs"):
+            assert torch.equal(db[k], hb[k]), (t, k)
+        assert db["bev_cand_vpids"] == hb["bev_cand_vpids"]
+    assert saw_dead and dev.N > 8
