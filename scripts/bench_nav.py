@@ -123,7 +123,8 @@ def main():
             pe, pm = runner.panorama(pano[t]) if use_graphs[0] else model("panorama", pano[t])
             avg = (pe * pm[..., None]).sum(1) / pm.sum(1, keepdim=True)                       # agent.py:478-479
             h0 = time.perf_counter()
-            gm.update_node_embeds(obs, [[c["viewpointId"] for c in ob["candidate"]] for ob in obs], avg, pe, ended)
+            gm.update_node_embeds(obs, None if on_device else [[c["viewpointId"] for c in ob["candidate"]] for ob in obs],
+                                  avg, pe, ended)          # the device map reads the candidate ids from the observations
             if not on_device:
                 gm.remember_views(obs, keys, store, ended)
             nav = gm.nav_gmap_variable(obs)

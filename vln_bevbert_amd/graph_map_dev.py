@@ -40,7 +40,7 @@ class _Digest:
 
 class DeviceGraphMap:
     """Drop-in for GraphMapBatch in the rollout loop (scripts/bench_nav.py, the agent): same calls, same outputs."""
-    _dig = _last = _last_up = _gpos = _feed = None      # per-step caches, keyed by the identity of the step's ``obs`` list
+    _dig = _last = _last_up = _nav_up = _bev_args = _feed = None      # per-step caches, keyed by the identity of the step's ``obs`` list
 
     def __init__(self, start_vps, hidden_size, device, dtype=torch.float32, node_capacity=64, views=12):
         device = torch.device(device)
@@ -334,9 +334,13 @@ class DeviceGraphMap:
         vpids = [[None] + [nb[k] for k in row[:c]] for nb, row, c in zip(names, node_l, cnt_l)]
         start = np.zeros(B, dtype=np.int32)      # the start viewpoint is the first node every episode registers
         g = self._digest(obs)
-        up = self.feed.ship({"node": node.astype(np.int32) if G > 1 else np.zeros((B, 1), np.int32),
-                             "cnt": cnt.astype(np.int32), "cur": cur, "start": start,
-                             "heading": g.heading, "elevation": g.elevation})
+        arrays = {"node": node.astype(np.int32) if G > 1 else np.zeros((B, 1), np.int32), "cnt": cnt.astype(np.int32),
+                  "cur": cur, "start": start, "heading": g.heading, "elevation": g.elevation}
+        bev_args, bev_vpids = self._bev_args, None
+        if bev_args is not None:         # bev_inputs follows on the same observations: its arrays ride in this transfer
+            bev, bev_vpids = self._bev_host(obs, *bev_args)
+            arrays.update(bev)
+        up = self.feed.ship(arrays)
         dev = self.device
         step_ids = torch.empty(B, G, dtype=torch.int64, device=dev)
         vis_t = torch.empty(B, G, dtype=torch.bool, device=dev)
@@ -348,7 +352,7 @@ class DeviceGraphMap:
                  up.ptr("start"), up.ptr("heading"), up.ptr("elevation"), G, int(enc_full_graph),
                  int(act_visited_nodes), step_ids.data_ptr(), vis_t.data_ptr(), masks.data_ptr(), pair.data_ptr(),
                  pos.data_ptr(), gpos.data_ptr(), lib.stream())
-        self._gpos = (obs, gpos)
+        self._nav_up = (obs, up, bev_args, bev_vpids, gpos)
         # running-mean node embeddings of the listed nodes ([stop] / padding rows = 0)
         if not (torch.is_grad_enabled() and self.t["embed_sum"].requires_grad):
             embeds = torch.empty(B, G, self.H, dtype=self.dtype, device=dev)
@@ -380,13 +384,10 @@ class DeviceGraphMap:
             return max(1, int(self.visited_host.sum(1).max()))
         return 1 + int((self.adj_host[np.arange(self.B), cur] & self.visited_host).sum(1).max())
 
-    def bev_inputs(self, obs, store, pc_order=1, bev_dim=21, bev_res=0.5):
-        """agent.py:143-192,282-337 as inputs of the fused lift / splat kernels (see GraphMapBatch.bev_inputs): the choice
-        of the visited neighbours, their store rows and poses come from the device-resident map."""
-        B, V = self.B, self.V
-        cur, _, _ = self._resolve(obs, False)
+    def _bev_host(self, obs, bev_dim, bev_res):
+        """The host's share of bev_inputs: world->ego transform of the current pose, candidate cells, nav masks."""
+        B = self.B
         g = self._digest(obs)
-        R = min(64, self._neighbour_bound(cur, pc_order))
         P = g.pos.astype(np.float32)
         S = np.stack([P[:, 0], P[:, 2], -P[:, 1]], 1)
         self._poses(obs)
@@ -402,7 +403,27 @@ class DeviceGraphMap:
             flat = GraphMapBatch.cand_cells_flat(g.pos, g.heading, g.cand_pos, g.counts, g.bi, bev_dim, bev_res, T=g.T_neg)
             cand_np[g.bi, 1 + g.ji] = flat
             nav_masks[g.bi, flat] = True
-        up = self.feed.ship({"cur": cur, "T_w2c": g.T_w2c, "S": S, "nav_masks": nav_masks, "cand": cand_np})
+        return {"bev_T_w2c": g.T_w2c, "bev_S": S, "bev_nav_masks": nav_masks, "bev_cand": cand_np}, cand_vpids
+
+    def bev_inputs(self, obs, store, pc_order=1, bev_dim=21, bev_res=0.5):
+        """agent.py:143-192,282-337 as inputs of the fused lift / splat kernels (see GraphMapBatch.bev_inputs): the choice
+        of the visited neighbours, their store rows and poses come from the device-resident map.  The host arrays of this
+        call travel with nav_gmap_variable's (the agent builds both from the same observations, agent.py:455-470; the
+        position features of the start viewpoint come out of that launch too)."""
+        B, V = self.B, self.V
+        cur, _, _ = self._resolve(obs, False)
+        R = min(64, self._neighbour_bound(cur, pc_order))
+        args = self._bev_args = (bev_dim, bev_res)
+        nu = self._nav_up
+        if nu is None or nu[0] is not obs:
+            self.nav_gmap_variable(obs)
+            nu = self._nav_up
+        if nu[2] == args:
+            up, cand_vpids = nu[1], nu[3]
+        else:                  # nav_gmap_variable ran on these observations before it knew the BEV geometry: own transfer
+            bev, cand_vpids = self._bev_host(obs, *args)
+            bev["cur"] = cur
+            up = self.feed.ship(bev)
         dev = self.device
         rows = torch.empty(B, R, dtype=torch.int32, device=dev)
         live = torch.empty(B, R, dtype=torch.bool, device=dev)
@@ -413,13 +434,9 @@ class DeviceGraphMap:
         depths = torch.empty(B, R * V, store.hw, store.hw, dtype=sd.dtype, device=dev)
         lib.call("bevbert_gm_gather_views", sd.data_ptr(), rows.data_ptr(), live.data_ptr(), depths.data_ptr(), B * R,
                  V * store.hw * store.hw * sd.element_size(), lib.stream())       # padding slots: no depth
-        g = getattr(self, "_gpos", None)
-        if g is None or g[0] is not obs:       # position features of the start viewpoint come with nav_gmap_variable's launch
-            self.nav_gmap_variable(obs)
-            g = self._gpos
-        return {"grid_rows": rows, "depths": depths, "T_c2w": T_c2w, "T_w2c": up["T_w2c"][:, None],
-                "S_w2c": up["S"][:, None], "bev_nav_masks": up["nav_masks"], "bev_cand_idxs": up["cand"],
-                "bev_cand_vpids": cand_vpids, "bev_gpos_fts": g[1][:, None]}
+        return {"grid_rows": rows, "depths": depths, "T_c2w": T_c2w, "T_w2c": up["bev_T_w2c"][:, None],
+                "S_w2c": up["bev_S"][:, None], "bev_nav_masks": up["bev_nav_masks"], "bev_cand_idxs": up["bev_cand"],
+                "bev_cand_vpids": cand_vpids, "bev_gpos_fts": nu[4][:, None]}
 
     def check_overflow(self):
         """True if a bev_inputs call ever met more neighbours than its host-side bound (one D2H sync: call it once per
