@@ -10,8 +10,8 @@ this replaces: the features are converted ONCE into a few large safetensors shar
     index.json                {"keys": [...], "shard_of": [...], "row_of": [...], "shape": {...}}
 
 that are read sequentially (one big read per shard, no decompression) straight into the device-resident
-``feature_store.GridFeatureStore``.  ``convert_hdf5`` needs h5py (not part of this image: it raises a clear error);
-``write_shards`` / ``load_store`` are format-complete without it and are what the tests exercise.
+``feature_store.GridFeatureStore``.  ``convert_hdf5`` reads the HDF5 files with h5py or, where that is missing, through
+libhdf5 itself (``hdf5_reader``); ``write_shards`` / ``load_store`` need neither.
 """
 import json
 import os
@@ -155,16 +155,19 @@ def load_store(cache_dir, device, keys=None, stats=None):
     return GridFeatureStore(out_keys, rgbs, depths, sems, device)
 
 
-def convert_hdf5(rgb_file, depth_file, sem_file, out_dir, shard_size=512):
-    """One-off conversion of the reference's three HDF5 stores (dataset.py:110-118 reads them per sample)."""
-    try:
-        import h5py
-    except ImportError as e:
-        raise ImportError("convert_hdf5 needs h5py to read the reference's HDF5 feature files; it is the only step "
-                          "that does -- training and the cache reader never import it") from e
+def convert_hdf5(rgb_file, depth_file, sem_file, out_dir, shard_size=512, reader=None):
+    """One-off conversion of the reference's three HDF5 stores (dataset.py:110-118 reads them per sample) into the sharded
+    cache.  The files are opened with h5py when it is importable, otherwise through libhdf5's C API
+    (``hdf5_reader``: same keys, same element values -- tests/test_host_logic.py checks it on files written by h5py with
+    the reference's own ``create_dataset`` calls).  ``reader``: a callable path -> file object, to force one of the two."""
+    from . import hdf5_reader
+    opener = reader or hdf5_reader.open_file
 
     def items():
-        with h5py.File(rgb_file, "r") as fr, h5py.File(depth_file, "r") as fd, h5py.File(sem_file, "r") as fs:
+        with opener(rgb_file) as fr, opener(depth_file) as fd, opener(sem_file) as fs:
             for key in fr.keys():
+                for name, f in (("depth", fd), ("semantic", fs)):
+                    if key not in f:
+                        raise KeyError(f"viewpoint {key} of {rgb_file} is missing from the {name} file")
                 yield key, fr[key][...], fd[key][...], fs[key][...]
     return write_shards(items(), out_dir, shard_size)
