@@ -457,6 +457,48 @@ def test_rxr_vocabulary_tasks_gpu(env, dtype):
     assert int((gw.abs().sum(1) > 0).sum()) > 1000          # the decoder side touches every vocabulary row
 
 
+def test_backward_through_many_forwards_spills_into_further_scratch_buffers(env, monkeypatch):
+    """A fine-tune rollout differentiates through all its navigation steps in ONE backward pass
+    (map_nav_src/r2r/agent.py:339-420): the partial sums of every step's column reductions are queued until that pass ends.
+    Six forwards of the tiny model, one backward, with a scratch ring sized below one forward's needs -- it has to continue
+    in further buffers -- against the same pass with the default ring: identical gradients, and the next pass reuses the
+    buffers (addresses repeat)."""
+    from vln_bevbert_amd import ops
+    from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    cfg = BevBertConfig.tiny()
+    torch.manual_seed(0)
+    model = GlocalTextPathCMTPreTraining(cfg)
+    arena = model.finalize(DEV, torch.float32)
+    model.train()
+    batches = [synthetic.batch_to(synthetic.make_batch(cfg, t, 3, seed=50 + i, ragged=True), DEV)
+               for i, t in enumerate(["sap", "mlm", "sap", "mlm", "sap", "mlm"])]
+
+    def long_backward():
+        ops.RT.new_step(7)
+        arena.zero_grad()
+        loss = sum(model(b, t).mean() for b, t in zip(batches, ["sap", "mlm"] * 3))
+        loss.backward()
+        arena.sync()
+        torch.cuda.synchronize()
+        return float(loss), arena.grads.clone()
+    sizes, real_alloc = [], ops.SCRATCH.alloc
+    monkeypatch.setattr(ops.SCRATCH, "alloc", lambda n, d: (sizes.append((int(n) + 255) & ~255), real_alloc(n, d))[1])
+    l0, g0 = long_backward()
+    need = sum(sizes)
+    assert need > 0 and ops.SCRATCH.ci == 0
+    small = ops.ScratchRing(max(max(sizes), need // 5 // 256 * 256), max_total=1 << 30)
+    monkeypatch.setattr(ops.ScratchRing, "INITIAL", 1 << 14)
+    monkeypatch.setattr(ops, "SCRATCH", small)
+    ops.ReduceQueue._tables.clear(); ops.ReduceQueue._accum_tables.clear()
+    l1, g1 = long_backward()
+    assert len(small._chunks) >= 3, (need, small.nbytes, len(small._chunks))
+    n_chunks = len(small._chunks)
+    assert l1 == l0 and torch.equal(g1, g0)
+    l2, g2 = long_backward()                           # buffers of the previous pass, same order: nothing new allocated
+    assert len(small._chunks) == n_chunks and l2 == l0 and torch.equal(g2, g0)
+    ops.ReduceQueue._tables.clear(); ops.ReduceQueue._accum_tables.clear()
+
+
 # ----------------------------------------------------------------------------- BASELINE configs[1] at full batch
 @pytest.mark.parametrize("which", ["r2r_b64", "rxr_b32_len160"])
 def test_full_size_batch_properties(env, which):

@@ -756,3 +756,38 @@ def test_device_graph_map_host_side_against_the_host_map(monkeypatch):
             assert torch.equal(db[k], hb[k]), (t, k)
         assert db["bev_cand_vpids"] == hb["bev_cand_vpids"]
     assert saw_dead and dev.N > 8
+
+
+def test_scratch_ring_continues_in_further_buffers_while_reductions_are_queued(monkeypatch):
+    """ops.ScratchRing: the first buffer grows up to its size; a backward pass that queues more partial sums than that
+    before its reductions are issued (the fine-tune rollout differentiates through 15 navigation steps at once) continues
+    in further buffers, which later passes reuse in the same order -- the addresses repeat after reset(); with nothing
+    queued the ring starts over instead; the total is bounded."""
+    from vln_bevbert_amd import lib, ops
+    monkeypatch.setattr(ops.ScratchRing, "INITIAL", 1024)
+    ring = ops.ScratchRing(4096, max_total=3 * 4096)
+    dev = torch.device("cpu")
+    monkeypatch.setattr(ops.ReduceQueue, "jobs", [("queued",)])
+
+    def one_pass(n):
+        ring.reset()
+        return [ring.alloc(1000, dev) for _ in range(n)]
+    one_pass(4)                                          # grows 1024 -> 2048 -> 4096: the first buffer
+    assert ring.ci == 0 and ring.size == 4096 and len(ring._old) == 2
+    a = one_pass(10)                                     # 4 allocations (of 1024) per buffer: three buffers
+    assert ring.ci == 2 and len(ring._chunks) == 3 and ring.total_bytes() == 3 * 4096
+    assert len(set(a)) == 10
+    for i, p in enumerate(a):                            # inside the buffer the allocation order says
+        buf, base, size = ring._chunks[i // 4]
+        assert base <= p and p + 1000 <= base + size
+    assert one_pass(10) == a and one_pass(3) == a[:3]    # addresses repeat from pass to pass (task tables hold pointers)
+    t = ring.tensor((5, 7), torch.float32, dev)
+    assert t.shape == (5, 7) and t.data_ptr() == a[3]
+    with pytest.raises(lib.BevBertHipError, match="BEVBERT_SCRATCH_MAX_MB"):
+        one_pass(13)
+    with pytest.raises(lib.BevBertHipError, match="buffer size"):
+        ring.alloc(5000, dev)
+    monkeypatch.setattr(ops.ReduceQueue, "jobs", [])     # nothing queued: the ring starts over rather than growing
+    ring.reset()
+    b = [ring.alloc(1000, dev) for _ in range(14)]
+    assert b[:12] == a[:10] + b[10:12] and b[12:] == a[:2] and len(ring._chunks) == 3

@@ -387,34 +387,47 @@ class WgradStream:
 
 
 class ScratchRing:
-    """Bump allocator over one device buffer for the short-lived fp32 partial sums of the two-stage column reductions.
-    ``reset()`` at the start of every step makes the addresses REPEAT from step to step (same task -> same sequence of
-    allocations), which is what lets ReduceQueue keep its task tables -- they hold raw pointers -- in device memory
-    instead of rebuilding and re-uploading them every step.  Wraps around when full (capacity >> one step's needs)."""
+    """Bump allocator over device buffers for the short-lived fp32 partial sums of the two-stage column reductions.
+    ``reset()`` at the start of every step (and at the end of every backward pass: arena._publish) makes the addresses
+    REPEAT from step to step (same task -> same sequence of allocations), which is what lets ReduceQueue keep its task
+    tables -- they hold raw pointers -- in device memory instead of rebuilding and re-uploading them every step.
+
+    The first buffer grows to what a training step needs, up to ``nbytes`` (BEVBERT_SCRATCH_MB).  A backward pass that
+    queues more than that before its reductions are issued -- a fine-tune rollout differentiates through all its
+    navigation steps at once (map_nav_src/r2r/agent.py:339-420) -- continues in further buffers of the same size, kept and
+    reused in the same order by the following passes (up to BEVBERT_SCRATCH_MAX_MB in total)."""
 
     INITIAL = 256 << 20
 
-    def __init__(self, nbytes=1 << 30):
-        self.nbytes = nbytes            # cap (BEVBERT_SCRATCH_MB)
-        self.size = 0                   # bytes allocated so far: the ring GROWS to what a step needs, up to the cap
+    def __init__(self, nbytes=1 << 30, max_total=64 << 30):
+        self.nbytes = nbytes            # size of one buffer (BEVBERT_SCRATCH_MB)
+        self.max_total = max(max_total, nbytes)
+        self.size = 0                   # bytes of the current buffer: the first one GROWS to what a step needs
         self.buf = None
         self.base = 0
         self.off = 0
+        self.ci = 0                     # index of the current buffer
+        self._chunks = []               # [buf, base, size] per buffer; [0] is the growing one
         self._old = []                  # outgrown buffers are NEVER freed: queued records of the running step and steps
         #                                 captured before the growth (another task's hipGraph) keep pointing into them
 
     def reset(self):
-        self.off = 0
+        self.off = self.ci = 0
+        if self._chunks:
+            self.buf, self.base, self.size = self._chunks[0]
+
+    def total_bytes(self):
+        return sum(c[2] for c in self._chunks)
 
     def alloc(self, nbytes, device):
         n = (int(nbytes) + 255) & ~255
         if n > self.nbytes:
-            raise lib.BevBertHipError(f"scratch ring: {n} bytes requested, capacity {self.nbytes}")
+            raise lib.BevBertHipError(f"scratch ring: {n} bytes requested, buffer size {self.nbytes} (BEVBERT_SCRATCH_MB)")
         if self.off + n > self.size:
-            if self.size < self.nbytes:
+            if self.ci == 0 and self.size < self.nbytes:
                 # grow (warm-up steps): a new, larger buffer; from the next reset on every allocation of the step lives
                 # in it, so the addresses repeat again -- which the cached task tables and captured steps rely on
-                if torch.cuda.is_current_stream_capturing():
+                if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
                     raise lib.BevBertHipError("scratch ring would have to grow during graph capture: run one more "
                                               "eager step first, or start larger (BEVBERT_SCRATCH_INITIAL_MB)")
                 new = min(self.nbytes, max(2 * self.size, self.off + n, self.INITIAL))
@@ -422,16 +435,30 @@ class ScratchRing:
                     self._old.append(self.buf)
                 self.buf = torch.empty(new, dtype=torch.uint8, device=device)
                 self.base, self.size, self.off = self.buf.data_ptr(), new, 0
+                self._chunks[:1] = [[self.buf, self.base, self.size]]
+            elif self.ci + 1 < len(self._chunks):
+                self._enter(self.ci + 1)                # a buffer an earlier pass of this length left behind
+            elif not (ReduceQueue.jobs or ReduceQueue.accum_jobs):
+                self._enter(0)                          # nothing queued points into the buffers: start over
             else:
-                # at the cap: wrap around -- only legal when nothing queued still points into the ring
-                if ReduceQueue.jobs or ReduceQueue.accum_jobs:
+                # reductions of this pass are still queued: their partial sums must stay where they are
+                if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+                    raise lib.BevBertHipError("scratch ring would need another buffer during graph capture: run one more "
+                                              "eager step first, or raise BEVBERT_SCRATCH_MB")
+                if self.total_bytes() + self.nbytes > self.max_total:
                     raise lib.BevBertHipError(
-                        f"scratch ring ({self.nbytes >> 20} MB) is full while reductions of this step are still queued: "
-                        "their partial sums would be overwritten -- raise BEVBERT_SCRATCH_MB")
-                self.off = 0
+                        f"one backward pass queued more than {self.total_bytes() >> 20} MB of partial sums for its column "
+                        "reductions: raise BEVBERT_SCRATCH_MAX_MB if that is intended")
+                buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+                self._chunks.append([buf, buf.data_ptr(), self.nbytes])
+                self._enter(len(self._chunks) - 1)
         p = self.base + self.off
         self.off += n
         return p
+
+    def _enter(self, ci):
+        self.ci, self.off = ci, 0
+        self.buf, self.base, self.size = self._chunks[ci]
 
     def tensor(self, shape, dtype, device):
         """A tensor view of freshly bumped ring memory (for operands that go through tensor-typed call paths)."""
@@ -441,7 +468,8 @@ class ScratchRing:
         return self.buf[o:o + nbytes].view(dtype).view(shape)
 
 
-SCRATCH = ScratchRing(int(_os.environ.get("BEVBERT_SCRATCH_MB", "6144")) << 20)      # ~2.5 GB / step at batch 64
+SCRATCH = ScratchRing(int(_os.environ.get("BEVBERT_SCRATCH_MB", "6144")) << 20,       # ~2.5 GB / step at batch 64
+                      int(_os.environ.get("BEVBERT_SCRATCH_MAX_MB", "65536")) << 20)
 ScratchRing.INITIAL = int(_os.environ.get("BEVBERT_SCRATCH_INITIAL_MB", "256")) << 20
 
 
