@@ -491,7 +491,7 @@ def test_backward_through_many_forwards_spills_into_further_scratch_buffers(env,
     monkeypatch.setattr(ops, "SCRATCH", small)
     ops.ReduceQueue._tables.clear(); ops.ReduceQueue._accum_tables.clear()
     l1, g1 = long_backward()
-    assert len(small._chunks) >= 3, (need, small.nbytes, len(small._chunks))
+    assert len(small._chunks) >= 2, (need, small.nbytes, len(small._chunks))
     n_chunks = len(small._chunks)
     assert l1 == l0 and torch.equal(g1, g0)
     l2, g2 = long_backward()                           # buffers of the previous pass, same order: nothing new allocated
