@@ -551,7 +551,10 @@ def side_configs(a):
             # the same rollout with the agent's action feedback: logits read back and argmaxed on the host every step
             ("finetune_rollout_b32_15steps_infer_feedback", [sys.executable, os.path.join(ROOT, "scripts", "bench_nav.py"),
                                                              "--batch", "32", "--steps", "15", "--iters", "4", "--warmup", "3",
-                                                             "--mode", "infer", "--feedback"])]
+                                                             "--mode", "infer", "--feedback"]),
+            # training rollout: 15 forwards, ONE backward through all of them, clip + AdamW (agent.py:339-420); eager issue
+            ("finetune_rollout_b32_15steps_train", [sys.executable, os.path.join(ROOT, "scripts", "bench_nav.py"), "--batch", "32",
+                                                    "--steps", "15", "--iters", "3", "--warmup", "2", "--mode", "train"])]
     res = {}
     for name, cmd in jobs:
         if time.perf_counter() - T_START > budget_s:

@@ -480,22 +480,24 @@ def test_backward_through_many_forwards_spills_into_further_scratch_buffers(env,
         loss.backward()
         arena.sync()
         torch.cuda.synchronize()
-        return float(loss), arena.grads.clone()
+        return float(loss.detach()), arena.grads.clone()
     sizes, real_alloc = [], ops.SCRATCH.alloc
     monkeypatch.setattr(ops.SCRATCH, "alloc", lambda n, d: (sizes.append((int(n) + 255) & ~255), real_alloc(n, d))[1])
     l0, g0 = long_backward()
     need = sum(sizes)
     assert need > 0 and ops.SCRATCH.ci == 0
-    small = ops.ScratchRing(max(max(sizes), need // 5 // 256 * 256), max_total=1 << 30)
+    small = ops.ScratchRing(max(max(sizes), need // 5 // 256 * 256), max_total=4 * need + (1 << 20))
     monkeypatch.setattr(ops.ScratchRing, "INITIAL", 1 << 14)
     monkeypatch.setattr(ops, "SCRATCH", small)
     ops.ReduceQueue._tables.clear(); ops.ReduceQueue._accum_tables.clear()
-    l1, g1 = long_backward()
-    assert len(small._chunks) >= 2, (need, small.nbytes, len(small._chunks))
-    n_chunks = len(small._chunks)
+    l1, g1 = long_backward()                           # the first buffer grows during this pass (warm-up)
     assert l1 == l0 and torch.equal(g1, g0)
-    l2, g2 = long_backward()                           # buffers of the previous pass, same order: nothing new allocated
-    assert len(small._chunks) == n_chunks and l2 == l0 and torch.equal(g2, g0)
+    l2, g2 = long_backward()
+    n_chunks = len(small._chunks)
+    assert n_chunks >= 3, (need, small.nbytes, n_chunks)
+    assert l2 == l0 and torch.equal(g2, g0)
+    l3, g3 = long_backward()                           # buffers of the previous pass, same order: nothing new allocated
+    assert len(small._chunks) == n_chunks and l3 == l0 and torch.equal(g3, g0)
     ops.ReduceQueue._tables.clear(); ops.ReduceQueue._accum_tables.clear()
 
 
