@@ -25,7 +25,9 @@ bash scripts/gpu_pmc_attn2.sh r04${T} 64 441 441 0.1 > /dev/null 2>&1
 bash scripts/gpu_pmc_traffic.sh > /dev/null 2>&1
 cd "$ROOT"
 cat gpurun_out/pmc_traffic/attn_traffic.json | head -20
-for args in "--map device" "--map device --feedback" "--map host" "--map host --feedback"; do
+rm -f gpurun_out/r04${T}_nav.jsonl
+for args in "--map device" "--map device --feedback" "--map host" "--map host --feedback" \
+            "--map device --mode train --iters 3 --warmup 2" "--map host --mode train --iters 3 --warmup 2"; do
   timeout 300 python scripts/bench_nav.py --steps 15 --iters 6 --warmup 4 $args 2>&1 | tail -1 >> gpurun_out/r04${T}_nav.jsonl
 done
 cut -c1-420 gpurun_out/r04${T}_nav.jsonl
