@@ -181,6 +181,7 @@ class DeviceGraphMap:
         same launch when asked, agent.py:471-474 (``step_id`` = t + 1 for the samples not in ``step_ended``) and the
         bookkeeping of GraphMap.update_node_pc (``store_rows``: feature-store row of each sample's viewpoint)."""
         B = self.B
+        self._dig = self._last = None        # a new step: the per-step caches are keyed by the identity of ``obs`` only
         cur, cand, ncand = self._resolve(obs, True, ended)
         if int(self.n.max()) > self.N:
             self._alloc(max(2 * self.N, int(self.n.max())))
