@@ -241,6 +241,7 @@ def main():
                       "ms_per_episode_batch": round(dt * 1e3, 2), "ms_per_nav_step": round(dt * 1e3 / T, 2),
                       "episodes_per_s": round(B / dt, 1), "nav_steps_per_s": round(B * T / dt, 1),
                       "host_map_bookkeeping_ms_per_nav_step": round(t_book[0] / a.iters / T * 1e3, 2),
+                      "text_kv_cache": bool(use_graphs[0] and runner.text_cache and any("g_kv" in v for v in runner.shared.values())),
                       "step_launch": ("hipGraph replay per mode and shape bucket (%d graphs, %d replays, %d eager calls)"
                                       % (runner.captured_graphs(), runner.stats["replays"], runner.stats["eager"]))
                       if use_graphs[0] else "eager",

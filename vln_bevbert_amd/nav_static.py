@@ -44,18 +44,24 @@ class NavGraphRunner:
         self.graph_error = None
         self.pool = None
         self.feed = None
+        import os
+        self.text_cache = os.environ.get("BEVBERT_NAV_TEXT_CACHE", "1") == "1"      # A/B knob: 0 = K|V GEMMs in every step
+        self.shared = {}            # episode-constant static inputs (instruction states, masks, their K|V projections)
+        self._text_src = None       # weak reference + version of the txt_embeds tensor the shared inputs were built from
 
     # ------------------------------------------------------------------------------------------------ plumbing
-    def _run(self, key, feeds, fn, shapes=None):
+    def _run(self, key, feeds, fn, shapes=None, static=None):
         """Copy ``feeds`` (name -> tensor) into the bucket's static inputs -- ``shapes`` names the (padded) buffer shape
         of the tensors that are smaller than their buffer; the padding is zero -- run ``fn(static inputs)`` eagerly or
-        replay its graph, return its (static) outputs."""
+        replay its graph, return its (static) outputs.  ``static``: name -> buffer the caller keeps up to date itself
+        (shared by every bucket: the instruction's tensors change once per episode, not per step)."""
         assert not self.model.training, "NavGraphRunner serves inference rollouts (model.eval())"
         shapes = shapes or {}
         b = self.buckets.get(key)
         if b is None:
             b = self.buckets[key] = _Bucket()
             b.inputs = {k: torch.zeros(shapes.get(k, v.shape), dtype=v.dtype, device=v.device) for k, v in feeds.items()}
+            b.inputs.update(static or {})         # buffers that are filled elsewhere (once per episode), not per call
         for k, v in feeds.items():
             buf = b.inputs[k]
             if v.shape == buf.shape:
@@ -127,27 +133,58 @@ class NavGraphRunner:
         if self.feed is None:
             self.feed = HostFeed.shared(dev)
         idx = self.feed({"src": src, "vis_c": vis_c})
-        names = ("txt_embeds", "txt_masks", "gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_masks",
+        names = ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_masks",
                  "gmap_pair_dists", "gmap_visited_masks", "bev_fts", "bev_pos_fts", "bev_nav_masks", "bev_cand_idxs")
         feeds = {k: nav[k] for k in names}
+        static = self._text_inputs(nav["txt_embeds"], nav["txt_masks"])
         feeds.update(src=idx["src"], vis_c=idx["vis_c"])
         shapes = {"gmap_img_embeds": (B, Gp, nav["gmap_img_embeds"].shape[2]), "gmap_step_ids": (B, Gp),
                   "gmap_pos_fts": (B, Gp, nav["gmap_pos_fts"].shape[2]), "gmap_masks": (B, Gp),
                   "gmap_pair_dists": (B, Gp, Gp), "gmap_visited_masks": (B, Gp), "bev_cand_idxs": (B, Cp)}
         key = ("navigation", B, Gp, Cp, nav["txt_embeds"].shape[1], nav["bev_fts"].shape[1])
-        out = self._run(key, feeds, self._navigation_device, shapes)
+        out = self._run(key, feeds, self._navigation_device, shapes, static)
         return {"gmap_embeds": out["gmap_embeds"][:, :G], "global_logits": out["global_logits"][:, :G],
                 "local_logits": out["local_logits"][:, :C], "fused_logits": out["fused_logits"][:, :G],
                 "obj_logits": None}
+
+    def _text_inputs(self, txt_embeds, txt_masks):
+        """Static buffers of the instruction: its states and mask, and their K|V projections for every cross-attention
+        layer of the two map encoders (vilmodel.CrossmodalEncoder.packed_kv) -- written when a NEW txt_embeds tensor
+        arrives (the agent encodes the instruction once per episode, map_nav_src/r2r/agent.py:426-431, and hands the same
+        tensor to every navigation step), shared by all shape buckets; the captured steps read them in place."""
+        import weakref
+        key = (tuple(txt_embeds.shape), txt_embeds.dtype, txt_embeds.device)
+        bufs = self.shared.get(key)
+        src = self._text_src
+        if bufs is not None and src is not None and src[0]() is txt_embeds and src[1] == txt_embeds._version \
+                and src[2]() is txt_masks and src[3] == txt_masks._version and src[4] == key:
+            return bufs
+        net = self.net
+        with torch.no_grad():
+            kv = {"g_kv": net.global_encoder.encoder.packed_kv(txt_embeds) if self.text_cache else None,
+                  "b_kv": net.local_encoder.encoder.packed_kv(txt_embeds) if self.text_cache else None}
+            if bufs is None:
+                bufs = self.shared[key] = {"txt_embeds": torch.empty_like(txt_embeds), "txt_masks": torch.empty_like(txt_masks)}
+                bufs.update({k: torch.empty_like(v) for k, v in kv.items() if v is not None})
+            bufs["txt_embeds"].copy_(txt_embeds)
+            bufs["txt_masks"].copy_(txt_masks)
+            for k, v in kv.items():
+                if v is not None:
+                    bufs[k].copy_(v)
+        self._text_src = (weakref.ref(txt_embeds), txt_embeds._version, weakref.ref(txt_masks), txt_masks._version, key)
+        return bufs
 
     def _navigation_device(self, x):
         """The device half of GlocalTextPathNavCMT.forward_navigation_per_step (nav_model.py) on static inputs."""
         net = self.net
         cd = x["txt_embeds"].dtype
         g_in = net.global_encoder.pos_step_embedding(x["gmap_img_embeds"].to(cd), x["gmap_step_ids"], x["gmap_pos_fts"])
-        gmap_embeds = net.global_encoder(x["txt_embeds"], x["txt_masks"], g_in, x["gmap_masks"], x["gmap_pair_dists"])
+        g_kvs = net.global_encoder.encoder.split_kv(x["g_kv"]) if "g_kv" in x else None      # cached per episode
+        b_kvs = net.local_encoder.encoder.split_kv(x["b_kv"]) if "b_kv" in x else None
+        gmap_embeds = net.global_encoder(x["txt_embeds"], x["txt_masks"], g_in, x["gmap_masks"], x["gmap_pair_dists"],
+                                         txt_kvs=g_kvs)
         bev_embeds, _ = net.local_encoder(x["txt_embeds"], x["txt_masks"], x["bev_fts"], x["bev_pos_fts"], None,
-                                          x["bev_nav_masks"], None, None)
+                                          x["bev_nav_masks"], None, None, txt_kvs=b_kvs)
         if net.sap_fuse_linear is None:
             fuse_weights = 0.5
         else:

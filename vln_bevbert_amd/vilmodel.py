@@ -354,9 +354,23 @@ class CrossmodalEncoder(_Finalizable):
             return [None] * self.num_x_layers
         return ops.hoisted_kv(context, self.kv_pw, self.kv_pb, self.num_x_layers)
 
-    def forward(self, txt_embeds, txt_masks, img_embeds, img_masks, graph_sprels=None):
+    def packed_kv(self, context):
+        """Inference only: the (B, Lk, layers * 2H) tensor ``hoist_kv`` slices, or None when hoisting is off.  A rollout
+        computes it once per episode for the instruction (the text states are never updated in the map encoders,
+        vilmodel.py:383-398) and hands it back through ``forward(..., kvs=split_kv(packed))`` at every navigation step."""
+        if not ops.HOIST_KV or self.kv_pw is None or self.num_x_layers < 2:
+            return None
+        with torch.no_grad():
+            return ops._linear_fwd(context, self.kv_pw.compute, self.kv_pb.compute)
+
+    def split_kv(self, packed):
+        w = packed.shape[-1] // self.num_x_layers
+        return [packed[..., i * w:(i + 1) * w] for i in range(self.num_x_layers)]
+
+    def forward(self, txt_embeds, txt_masks, img_embeds, img_masks, graph_sprels=None, kvs=None):
         tm, im = neg_key_mask(txt_masks), neg_key_mask(img_masks)
-        kvs = self.hoist_kv(txt_embeds)
+        if kvs is None:
+            kvs = self.hoist_kv(txt_embeds)
         for layer, kv in zip(self.x_layers, kvs):
             img_embeds = layer(txt_embeds, tm, img_embeds, im, graph_sprels=graph_sprels, ctx_kv=kv)
         return img_embeds
@@ -598,12 +612,12 @@ class LocalBEVEncoder(nn.Module):
         return torch.cat([bev_embeds, obj_embeds], 1), torch.cat([bev_masks, obj_masks], 1)
 
     def forward(self, txt_embeds, txt_masks, bev_fts, bev_pos_fts, bev_masks, bev_nav_masks, obj_embeds, obj_masks,
-                bev_in=None):
+                bev_in=None, txt_kvs=None):
         """``bev_in``: the input embedding if the caller has computed it already (on a side stream, beside the text
-        encoder: it does not depend on the text)."""
+        encoder: it does not depend on the text).  ``txt_kvs``: CrossmodalEncoder.split_kv of a cached packed_kv."""
         bev_embeds = bev_in if bev_in is not None else self.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
         x, m = self.with_objects(bev_embeds, bev_masks, obj_embeds, obj_masks)
-        x = self.encoder(txt_embeds, txt_masks, x.contiguous(), m)
+        x = self.encoder(txt_embeds, txt_masks, x.contiguous(), m, kvs=txt_kvs)
         K = self.bev_dim * self.bev_dim
         if obj_embeds is None:
             return x, None
@@ -679,8 +693,9 @@ class GlobalMapEncoder(nn.Module):
         w, b = ops.use_param(self.sprel_linear.weight).view(()), ops.use_param(self.sprel_linear.bias).view(())
         return (gmap_pair_dists.float() * w + b).contiguous()          # (B, G, G) fp32 additive bias
 
-    def forward(self, txt_embeds, txt_masks, gmap_embeds, gmap_masks, gmap_pair_dists):
-        return self.encoder(txt_embeds, txt_masks, gmap_embeds, gmap_masks, graph_sprels=self.sprels(gmap_pair_dists))
+    def forward(self, txt_embeds, txt_masks, gmap_embeds, gmap_masks, gmap_pair_dists, txt_kvs=None):
+        return self.encoder(txt_embeds, txt_masks, gmap_embeds, gmap_masks, graph_sprels=self.sprels(gmap_pair_dists),
+                            kvs=txt_kvs)
 
 
 def _host_list(x):
