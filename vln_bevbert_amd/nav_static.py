@@ -45,7 +45,10 @@ class NavGraphRunner:
         self.pool = None
         self.feed = None
         import os
-        self.text_cache = os.environ.get("BEVBERT_NAV_TEXT_CACHE", "1") == "1"      # A/B knob: 0 = K|V GEMMs in every step
+        # 1 = the K|V projections of the instruction are computed once per episode instead of inside every captured step.
+        # Measured (profiles/r04ae_nav_text_kv_cache_ab.txt): 3.23 / 3.58 ms per navigation step with, 3.21 / 3.53 without
+        # (no feedback / feedback) -- the two GEMMs hide behind the panorama branch.  Off.
+        self.text_cache = os.environ.get("BEVBERT_NAV_TEXT_CACHE", "0") == "1"
         self.shared = {}            # episode-constant static inputs (instruction states, masks, their K|V projections)
         self._text_src = None       # weak reference + version of the txt_embeds tensor the shared inputs were built from
 
