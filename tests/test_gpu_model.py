@@ -885,18 +885,21 @@ def test_grid_feature_cache_to_resident_store_to_static_batch(env, tmp_path):
         assert abs(float(from_cache) - float(want)) < FP32_TOL, task
 
 
-def test_finetune_rollout_full_size_properties(env):
+@pytest.mark.parametrize("text_cache", ["0", "1"])
+def test_finetune_rollout_full_size_properties(env, text_cache):
     """BASELINE.json configs[4] at its real size: batch 32, 15 navigation steps (scripts/ft_r2r.bash:37
     --max_action_len 15), bf16, the whole per-step chain (panorama encoder, map bookkeeping, lift + splat out of the
     resident store, navigation mode).  Size-independent checks run by scripts/bench_nav.py --check, which also
     compares the captured navigation steps (nav_static.NavGraphRunner: node / candidate axes padded to shape buckets,
-    static buffers, hipGraph replay) with the eager forwards on the same observations."""
+    static buffers, hipGraph replay) with the eager forwards on the same observations.  ``text_cache`` = 1: the instruction's
+    K|V projections come from the per-episode cache instead of GEMMs inside the captured step (off by default)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "bench_nav.py"), "--batch", "32", "--steps", "15",
-                        "--check"], capture_output=True, text=True, timeout=600)
+                        "--check"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, BEVBERT_NAV_TEXT_CACHE=text_cache))
     assert p.returncode == 0, p.stderr[-2000:]
     assert '"check": "ok"' in p.stdout, p.stdout[-500:]
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
