@@ -102,7 +102,9 @@ class _Runtime:
         return p
 
 
-_LT_WS_BYTES = 32 << 20
+# hipBLASLt workspace per launching stream: solutions that need more (split-K / stream-K partial tiles of the wide problems)
+# are not candidates.  BEVBERT_LT_WS_MB raises it (a choice table made with a larger workspace needs it at run time too).
+_LT_WS_BYTES = int(_os.environ.get("BEVBERT_LT_WS_MB", "32")) << 20
 
 
 class _AttnBitsPlanner:
