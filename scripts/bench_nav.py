@@ -152,6 +152,8 @@ def main():
                 loss = loss + (F.cross_entropy(out["fused_logits"].float(), tgt, reduction="none") * live).sum()
         return loss
 
+    last_loss = [None]
+
     def iteration(i):
         ops.RT.new_step(1000 + i)
         if a.mode == "infer":
@@ -159,8 +161,10 @@ def main():
                 episode()
         else:
             arena.zero_grad()
-            (episode() / B).backward()
+            loss = episode() / B
+            loss.backward()
             arena.clip_and_step(1e-5, max_norm=40.0)
+            last_loss[0] = loss.detach()
 
     if a.check:
         runs = []
@@ -241,6 +245,7 @@ def main():
                       "ms_per_episode_batch": round(dt * 1e3, 2), "ms_per_nav_step": round(dt * 1e3 / T, 2),
                       "episodes_per_s": round(B / dt, 1), "nav_steps_per_s": round(B * T / dt, 1),
                       "host_map_bookkeeping_ms_per_nav_step": round(t_book[0] / a.iters / T * 1e3, 2),
+                      "final_loss": None if last_loss[0] is None else round(float(last_loss[0]), 5),
                       "text_kv_cache": bool(use_graphs[0] and runner.text_cache and any("g_kv" in v for v in runner.shared.values())),
                       "step_launch": ("hipGraph replay per mode and shape bucket (%d graphs, %d replays, %d eager calls)"
                                       % (runner.captured_graphs(), runner.stats["replays"], runner.stats["eager"]))

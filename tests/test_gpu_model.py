@@ -907,6 +907,25 @@ def test_finetune_rollout_full_size_properties(env, text_cache):
     assert rec["graphs_vs_eager_max_rel_diff"] <= 3e-2, rec
 
 
+@pytest.mark.parametrize("which", ["device", "host"])
+def test_training_rollout_backward_through_all_steps(env, which):
+    """map_nav_src/r2r/agent.py:339-420: a training rollout keeps the autograd graph of every navigation step and runs ONE
+    backward through all of them, then clip + optimiser step.  scripts/bench_nav.py --mode train does that on either map
+    (the node embeddings stay differentiable across steps: the functional index_put path of update_node_embeds); the
+    column reductions of all steps stay queued until the pass ends (ops.ScratchRing continues in further buffers)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "bench_nav.py"), "--batch", "8", "--steps", "6", "--iters", "2",
+                        "--warmup", "1", "--mode", "train", "--map", which], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, BEVBERT_SCRATCH_MB="256"))      # a small ring: the pass needs several buffers
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["map"] == which and rec["step_launch"] == "eager" and rec["ms_per_nav_step"] > 0, rec
+    assert rec["final_loss"] is not None and np.isfinite(rec["final_loss"]) and rec["final_loss"] > 0, rec
+
+
 def test_host_feed_ships_a_step_of_host_arrays_in_one_copy(env):
     """graph_map.HostFeed: arrays of mixed dtype / shape (empty ones included) packed into a pinned ring slot, one
     non-blocking copy, typed device views -- equal to the per-array copies, also when the ring wraps around."""
