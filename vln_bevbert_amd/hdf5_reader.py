@@ -68,6 +68,11 @@ def _lib():
         "H5Tclose": (I, [_hid]),
         "H5Eset_auto2": (I, [_hid, P, P]),
     }
+    if not hasattr(L, "H5Literate"):        # HDF5 >= 1.12 exports the versioned names only; the callback ignores the info struct
+        for alt in ("H5Literate2", "H5Literate1"):
+            if hasattr(L, alt):
+                L.H5Literate = getattr(L, alt)
+                break
     for name, (res, args) in protos.items():
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
