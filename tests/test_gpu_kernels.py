@@ -620,7 +620,7 @@ def test_attention_single_pass_backward_equals_two_kernel_backward(ops, B, Lq, L
 @pytest.mark.parametrize("B,Lq,Lk", [(2, 441, 441), (1, 100, 140), (2, 80, 36), (1, 33, 448)])
 def test_attention_keep_bit_workspace_holds_the_exported_mask_in_both_layouts(ops, B, Lq, Lk):
     """bevbert_attn_drop_bits: the forward-layout words (bit l = query 16 q16 + (l & 15), key 64 k64 + 16 t + 4 (l >> 4) + r)
-    and the backward-layout words (bit l = query 32 q32 + 16 tt + 4 (l >> 4) + r, key 16 k16 + (l & 15)) both decode to
+    and the backward-layout words (bit l = query 32 q32 + 16 tt + 4 (l >> 4) + r, key 64 k64 + 16 t + (l & 15)) both decode to
     the mask of the element-indexed stream every other dropout consumer uses."""
     nh, p = 12, 0.1
     ops.RT.new_step(77)
@@ -642,10 +642,11 @@ def test_attention_keep_bit_workspace_holds_the_exported_mask_in_both_layouts(op
     assert np.array_equal(got[:, ok], want[:, ok]), "forward layout"
     if not 256 < Lk <= 448:          # the backward layout is only produced for the shapes the 7+1-wave backward takes
         return
-    bw = bits[half:].reshape(B * nh, nq16 // 2, nk64 * 4, 2, 4)
-    q = (np.arange(nq16 // 2)[:, None, None, None, None] * 32 + np.arange(2)[None, None, :, None, None] * 16
-         + (lanes >> 4) * 4 + np.arange(4)[None, None, None, :, None])
-    k = np.arange(nk64 * 4)[None, :, None, None, None] * 16 + (lanes & 15)
+    bw = bits[half:].reshape(B * nh, nq16 // 2, nk64, 2, 4, 4)                           # (bh, q32, k64, tt, t, r)
+    q = (np.arange(nq16 // 2)[:, None, None, None, None, None] * 32 + np.arange(2)[None, None, :, None, None, None] * 16
+         + (lanes >> 4) * 4 + np.arange(4)[None, None, None, None, :, None])
+    k = (np.arange(nk64)[None, :, None, None, None, None] * 64 + np.arange(4)[None, None, None, :, None, None] * 16
+         + (lanes & 15))
     got = ((bw[..., None] >> lanes.astype(np.uint64)) & np.uint64(1)).astype(bool)
     ok = (q < Lq) & (k < Lk)
     qq, kk = np.broadcast_arrays(np.minimum(q, Lq - 1), np.minimum(k, Lk - 1))

@@ -36,8 +36,8 @@ struct AttnArgs {
   // read one bit per score element instead of hashing again.  Word / bit of element (q, k) of batch-head bh:
   //   word = ((((bh * nq16 + (q >> 4)) * nk64 + (k >> 6)) * 4 + ((k >> 4) & 3)) * 4 + (k & 3)),  bit = 16 * ((k >> 2) & 3) + (q & 15)
   uint64_t* drop_bits; // B * nh * nq16 * nk64 * 16 words, or null (backward then regenerates the mask from the hash)
-  // The same bits with lanes <-> keys (attn_bwd2.hip): word ((((bh * (nq16/2) + (q >> 5)) * 4 nk64 + (k >> 4)) * 2 + ((q >> 4) & 1)) * 4
-  // + (q & 3)), bit = 16 * ((q >> 2) & 3) + (k & 15).  Both are written by attn_drop_bits_kernel (attn_fwd2.hip).
+  // The same bits with lanes <-> keys (attn_bwd2.hip): word ((((bh * (nq16/2) + (q >> 5)) * nk64 + (k >> 6)) * 2 + ((q >> 4) & 1)) * 16
+  // + 4 * ((k >> 4) & 3) + (q & 3)), bit = 16 * ((q >> 2) & 3) + (k & 15).  Both are written by attn_drop_bits_kernel (attn_fwd2.hip).
   uint64_t* drop_bits_b;
   int nq16, nk64;      // nq16 = 8 * ceil(Lq / 128), nk64 = ceil(Lk / 64)
   // backward only

@@ -248,13 +248,235 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd2_kernel(AttnArgs a) {
   }
 }
 
+// Round 5: the same kernel on a further diet (see the comments inside): fused multiply-add before the maximum, select
+// before the packed conversion, keep-bit words of a whole tile requested in front of the tile barrier.
+template <int NW, bool DROP>
+__global__ __launch_bounds__(64 * NW, 4) void attn_fwd3_kernel(AttnArgs a) {
+  constexpr int QT = 2;                      // 16-query tiles per wave
+  constexpr int NT = 64 * NW;
+  constexpr int CPT = (512 + NT - 1) / NT;   // 16-byte chunks of a [64][64] bf16 tile per thread
+  __shared__ __attribute__((aligned(16))) bf16_raw s_k[2][F2_TILE];
+  __shared__ __attribute__((aligned(16))) bf16_raw s_v[2][F2_TILE];
+  __shared__ __attribute__((aligned(16))) float s_mask[2][TK];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int blk, h, b;
+  attn_decode_block(a, blk, h, b);
+  const int qbase = blk * (16 * QT * NW) + w * (16 * QT);
+  const bf16_raw* qp = (const bf16_raw*)a.q + (size_t)b * a.bsq + h * ATTN_D;
+  const bf16_raw* kp = (const bf16_raw*)a.k + (size_t)b * a.bsk + h * ATTN_D;
+  const bf16_raw* vp = (const bf16_raw*)a.v + (size_t)b * a.bsv + h * ATTN_D;
+  const float sc2 = a.scale * LOG2E;
+  const float inv_scale = 1.0f / a.scale;
+
+  bf16x8 qf[QT][2];
+  int qrow[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qrow[qt] = qbase + qt * 16 + c;
+    const int r = qrow[qt] < a.Lq ? qrow[qt] : a.Lq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = as_bf16x8(ld_frag_global(qp, a.ldq, r, ks * 32 + g * 8));
+  }
+  // keep-bit words of this wave's query tiles: 16 words (t, r) per (query tile, 64-key tile), 64-key tiles contiguous
+  bb_cu64p wq[QT];
+  if (DROP) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      int q16 = (qbase >> 4) + qt;
+      q16 = q16 < a.nq16 ? q16 : a.nq16 - 1;       // query tiles past the end: any valid words will do
+      wq[qt] = (bb_cu64p)(uintptr_t)(a.drop_bits + ((size_t)(b * a.nh + h) * a.nq16 + q16) * a.nk64 * 16);
+    }
+  }
+  f32x4 oacc[QT][4];
+  float m_run[QT], nm[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = -INFINITY;     // running maximum (log2 domain) shared by the four lanes of a query
+    nm[qt] = 0.f;              // -(m_run), 0 while m_run is still -inf
+    l_run[qt] = 0.f;           // this lane's share of the row sum
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // additive key mask of a tile in raw-score units (the C operand of Q K^T), one key per thread; -inf beyond Lk
+  auto mask_of = [&](int kv0) -> float {
+    const int key = kv0 + tid;
+    if (tid >= TK || key >= a.Lk) return -INFINITY;
+    return a.key_mask ? a.key_mask[(size_t)b * a.Lk + key] * inv_scale : 0.f;
+  };
+  uint4 kreg[CPT], vreg[CPT];
+  float mreg;
+  auto stage_load = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int ch = tid + i * NT, row = ch >> 3, d0 = (ch & 7) * 8;
+      kreg[i] = vreg[i] = make_uint4(0, 0, 0, 0);                  // rows past the end are zero filled
+      if (ch < 512 && kv0 + row < a.Lk) {
+        kreg[i] = ld_frag_global(kp, a.ldk, kv0 + row, d0);
+        vreg[i] = ld_frag_global(vp, a.ldv, kv0 + row, d0);
+      }
+    }
+    mreg = mask_of(kv0);
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int ch = tid + i * NT, row = ch >> 3, d0 = (ch & 7) * 8;
+      if (ch < 512) {
+        *reinterpret_cast<uint4*>(s_k[buf] + f2_off(row, ch & 7)) = kreg[i];
+        *reinterpret_cast<uint4*>(s_v[buf] + f2_off(row, ch & 7)) = vreg[i];
+      }
+    }
+    if (tid < TK) s_mask[buf][tid] = mreg;
+  };
+  stage_load(0);
+  stage_store(0);
+  if (TK < a.Lk) stage_load(TK);
+  __syncthreads();
+
+  // keep-bit words of a whole 64-key tile (2 query tiles x 16 words (t, r)) in 64 scalar registers, requested right in
+  // front of the barrier that closes the previous tile: scalar loads share lgkmcnt with LDS and return out of order, so
+  // any LDS wait behind an outstanding scalar load waits for it too (every word is read once: an L2 / HBM round trip)
+  uint64_t kw[QT][16];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kw[qt][i] = DROP ? wq[qt][i] : 0;
+  for (int kv0 = 0, cur = 0; kv0 < a.Lk; kv0 += TK, cur ^= 1) {
+    const bf16_raw* ck = s_k[cur];
+    const bf16_raw* cv = s_v[cur];
+    const float* cmask = s_mask[cur];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {       // halves of 32 keys: key tiles t = 2 hh, 2 hh + 1
+      // ---- S^T = K Q^T + mask
+      f32x4 sacc[QT][2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * hh + tt;
+        const float4 mk = *reinterpret_cast<const float4*>(&cmask[t * 16 + g * 4]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) sacc[qt][tt] = (f32x4){mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 kf = f2_frag_rows(ck, t, ks, lane);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) sacc[qt][tt] = mfma16(kf, qf[qt][ks], sacc[qt][tt]);
+        }
+      }
+      // ---- first half: stage tile j+1 into the other buffer (its last readers passed the barrier that closed
+      //      iteration j-1) and start the global loads of tile j+2; both overlap the arithmetic below
+      if (hh == 0 && kv0 + TK < a.Lk) {
+        stage_store(cur ^ 1);
+        if (kv0 + 2 * TK < a.Lk) stage_load(kv0 + 2 * TK);
+      }
+      // ---- t = s * scale * log2e - m_stale for every element first (the fused multiply-add the exponential needs anyway;
+      //      its results are canonical numbers, so the maximum below needs no canonicalising v_max per matrix result)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[qt][tt][r] = fmaf(sacc[qt][tt][r], sc2, nm[qt]);
+      // ---- lazy running maximum (decision before this half's P exists): a rescale only when some t exceeds FWD2_THR
+      float lm[QT];
+      bool grow = false;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const f32x4 s0 = sacc[qt][0], s1 = sacc[qt][1];
+        lm[qt] = max3f(max3f(s0[0], s0[1], s0[2]), max3f(s0[3], s1[0], s1[1]), fmaxf(s1[2], s1[3]));
+        grow |= (lm[qt] > FWD2_THR) | ((m_run[qt] == -INFINITY) & (lm[qt] > -INFINITY));   // no maximum yet: any finite score sets it
+      }
+      if (__any(grow)) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          const float m_new = fmaxf(m_run[qt], quad_max(lm[qt]) - nm[qt]);      // lm is relative to the stale maximum
+          const float nm_new = (m_new == -INFINITY) ? 0.f : -m_new;
+          const float alpha = fast_exp2(m_run[qt] + nm_new);  // exp2(m_old - m_new); first update: exp2(-inf) = 0, O = l = 0
+          const float shift = nm_new - nm[qt];
+          m_run[qt] = m_new;
+          nm[qt] = nm_new;
+          l_run[qt] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[qt][tt][r] += shift;
+        }
+      }
+      // ---- P = exp2(t); row sums before dropout; keep bits straight from scalar registers; the empty asm pins the
+      //      select in front of the bf16 conversion (the compiler otherwise converts each element alone, selects on the
+      //      16-bit halves and merges them with v_perm: 2.5 instead of 1.5 vector instructions per element)
+      bf16x8 pb[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float psum = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = fast_exp2(sacc[qt][tt][r]);
+            psum += p;
+            if (DROP) {
+              p = drop_select(p, kw[qt][(2 * hh + tt) * 4 + r]);
+              asm("" : "+v"(p));
+            }
+            sacc[qt][tt][r] = p;
+          }
+        l_run[qt] += psum;
+        pb[qt] = pack_pair(sacc[qt][0], sacc[qt][1]);
+      }
+      // ---- O^T += V^T P^T over this half's 32 keys: k-slot (g, j) <-> key 32 hh + 16 (j >> 2) + 4 g + (j & 3)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 vf = f2_frag_tr(cv, 32 * hh + 4 * g, 32 * hh + 16 + 4 * g, dt * 16, lane);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = mfma16(vf, pb[qt], oacc[qt][dt]);
+      }
+
+    }
+    // one barrier per tile: buffer `cur` is free again, buffer `cur^1` is complete.  This wave's LDS traffic has landed
+    // (the pointer operand ties the scalar loads below to this point), the next tile's words are requested, then the
+    // bare barrier: no fence, which would wait for the scalar loads -- and for the global loads of tile j + 2 -- first.
+    __builtin_amdgcn_sched_barrier(0);
+    if (DROP) {
+      const int kvn = kv0 + TK < a.Lk ? kv0 + TK : kv0;
+      bb_cu64p w0 = wq[0] + (kvn >> 6) * 16, w1 = wq[1] + (kvn >> 6) * 16;
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w0), "+s"(w1) : : "memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { kw[0][i] = w0[i]; kw[1][i] = w1[i]; }
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" : : : "memory");
+  }
+
+  // ---- epilogue: normalise (dropout scaling folded in), store O[q][h*64 + dt*16 + g*4 .. +3] and the log-sum-exp
+  const float ks = DROP ? a.keep_scale : 1.0f;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const float l = quad_sum(l_run[qt]);
+    const float inv = ks / l;
+    if (qrow[qt] < a.Lq) {
+      bf16_raw* op = (bf16_raw*)a.o + (size_t)b * a.bso + (size_t)qrow[qt] * a.ldo + h * ATTN_D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        st4<bf16_raw>(op + dt * 16 + g * 4, make_float4(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv,
+                                                         oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv));
+      if (a.lse && g == 0) a.lse[((size_t)b * a.nh + h) * a.Lq + qrow[qt]] = (log2f(l) - nm[qt]) * LN2;
+    }
+  }
+}
+
 // =============================================================================================
 // Keep-bit matrices of one attention call.  keep(q, k) = bits(hash(pair index ^ site key)) >= threshold with the
 // element index ((b*nh + h)*Lq + q)*Lk2 + k -- the stream every other consumer (exact kernels, the test hook) uses.
 //   F layout (forward, and the nibble reader of attn_bwd1): word (bh, q16, k64, t, r), bit l = keep(q = 16 q16 + (l & 15),
 //            key = 64 k64 + 16 t + 4 (l >> 4) + r)                                   -- attn_common.h
-//   B layout (single-pass backward, lanes <-> keys): word (bh, q32, k16, tt, r), bit l = keep(q = 32 q32 + 16 tt +
-//            4 (l >> 4) + r, key = 16 k16 + (l & 15)); nq32 = nq16 / 2 query blocks, nk16 = 4 nk64 key tiles.
+//   B layout (single-pass backward, lanes <-> keys): word (bh, q32, k64, tt, t, r), bit l = keep(q = 32 q32 + 16 tt +
+//            4 (l >> 4) + r, key = 64 k64 + 16 t + (l & 15)); nq32 = nq16 / 2 query blocks.
 // One wave per (bh, q16, k64): 8 hashes per lane give the 16 F words as wave-wide compare masks; the B words are the
 // same bits transposed inside the wave (4 ds_bpermute of the lane's 16-bit mask + 16 compares), not hashed again.
 // =============================================================================================
@@ -316,10 +538,11 @@ __global__ __launch_bounds__(256) void attn_drop_bits_kernel(AttnArgs a, uint64_
                                         __ballot((got[2] >> (4 * T)) & 1u), __ballot((got[3] >> (4 * T)) & 1u));
       BB_B_WORDS(0) BB_B_WORDS(1) BB_B_WORDS(2) BB_B_WORDS(3)
 #undef BB_B_WORDS
-      // word (bh, q32 = q16 >> 1, k16 = 4 k64 + t, tt = q16 & 1, r')
+      // word (bh, q32 = q16 >> 1, k64, tt = q16 & 1, t, r'): the 16 words of one 16-query tile against the 64 keys of a
+      // key wave are contiguous (two s_load_dwordx16 fetch a wave's 32 words of a step)
       if (lane < 16) {
         const int t = lane >> 2, rp = lane & 3;
-        const size_t wi = ((((size_t)bh * (a.nq16 >> 1) + (q16 >> 1)) * (a.nk64 * 4) + (k64 * 4 + t)) * 2 + (q16 & 1)) * 4 + rp;
+        const size_t wi = ((((size_t)bh * (a.nq16 >> 1) + (q16 >> 1)) * a.nk64 + k64) * 2 + (q16 & 1)) * 16 + t * 4 + rp;
         bits_b[wi] = ((uint64_t)bhi << 32) | blo;
       }
     }
@@ -346,8 +569,15 @@ static int launch_fwd2(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   a.nblk = (a.Lq + 32 * NW - 1) / (32 * NW);
   const dim3 grid((unsigned)a.nblk * a.nh * a.B);
-  if (a.drop_p > 0.f) hipLaunchKernelGGL((attn_fwd2_kernel<NW, true>), grid, dim3(64 * NW), 0, st, a);
-  else hipLaunchKernelGGL((attn_fwd2_kernel<NW, false>), grid, dim3(64 * NW), 0, st, a);
+  // BEVBERT_FWD_VAR=0: the round-3 kernel (A/B measurements, on-GPU cross-check)
+  static const int var = [] { const char* v = getenv("BEVBERT_FWD_VAR"); return v ? atoi(v) : 1; }();
+  if (var == 0) {
+    if (a.drop_p > 0.f) hipLaunchKernelGGL((attn_fwd2_kernel<NW, true>), grid, dim3(64 * NW), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd2_kernel<NW, false>), grid, dim3(64 * NW), 0, st, a);
+  } else {
+    if (a.drop_p > 0.f) hipLaunchKernelGGL((attn_fwd3_kernel<NW, true>), grid, dim3(64 * NW), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd3_kernel<NW, false>), grid, dim3(64 * NW), 0, st, a);
+  }
   BB_CHECK_LAUNCH("attn_fwd(mfma, gen 2)");
   return BB_OK;
 }
