@@ -46,7 +46,8 @@ def cls(name):
     n = name.lower()
     if any(k in n for k in ("attn_", "ln_fwd", "ln_bwd", "bev_", "colwise", "colsum", "bias_gelu", "gather_wsum",
                             "adamw", "sumsq", "clip_coef", "cast_f32", "keep_mask", "accum_partials", "dropout_add",
-                            "embedding_grad")):
+                            "embedding_grad", "multi_accum", "multi_finalize", "sap_loss", "ce_fwd", "ce_bwd", "gm_",
+                            "colsum_finalize")):
         return "custom"
     if any(k in n for k in ("cijk", "gemm", "tensile", "hipblaslt", "rocblas")):
         return "gemm"
@@ -75,17 +76,26 @@ print(f"{'class':7s} {'calls/step':>10s} {'ms/step':>9s} {'avg_us':>9s} {'%':>6s
 for n, (c, t) in sorted(by_k.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"{cls(n):7s} {c / K:10.1f} {t / 1e6 / K:9.3f} {t / 1e3 / c:9.2f} {100 * t / tot:6.2f}  {n[:110]}")
 
-# the attention kernels per problem size: one launch grid = one (B, heads, Lq | Lk).  With B = 64 samples and 12 heads
-# the forward / dQ kernels launch ceil(Lq / 128) * 12 * B workgroups and the dK/dV kernel ceil(Lk / 64) * 12 * B, e.g. the
-# 441 x 441 BEV self-attention = 3072 / 3072 / 5376 workgroups -- the rows to compare with bench.py's
-# roofline.avg_launch_us (bevbert_attn_bwd[Lq=441,Lk=441] = its dQ launch + its dK/dV launch)
+# The hand-written kernels per PROBLEM: one kernel symbol serves several shapes of a step (attn_bwd2_kernel: the 441 x 441
+# BEV self-attention and the 80 x 441 text <- BEV cross-attention share a symbol AND a launch grid).  The kernel trace
+# carries no kernel arguments, so launches are keyed by (symbol, grid) and then split into duration clusters (sorted
+# durations, a new cluster wherever the next one is more than 1.35 x the previous): each line is one problem size, its
+# in-step duration is the figure to hold against bench.py's roofline (isolated launches between HIP events).
 print()
-print("attention kernels by launch grid (workgroups):")
+print("hand-written kernels by (symbol, launch grid, duration cluster): calls/step, avg / min / max us in the step")
 by_g = {}
 for s, e, n, _, g in win:
-    if "attn_mfma" in n:
-        c = by_g.setdefault((n.split("(")[0], g), [0, 0])
-        c[0] += 1
-        c[1] += e - s
-for (n, g), (c, t) in sorted(by_g.items(), key=lambda kv: -kv[1][1]):
-    print(f"  {c / K:6.1f} calls/step {t / 1e3 / c:9.2f} us avg  grid {g:6d}  {n[:80]}")
+    if cls(n) == "custom":
+        by_g.setdefault((n.split("(")[0], g), []).append((e - s) / 1e3)
+rows = []
+for (n, g), ds in by_g.items():
+    ds.sort()
+    cl = [[ds[0]]]
+    for d_ in ds[1:]:
+        if d_ > 1.35 * cl[-1][-1] and d_ - cl[-1][-1] > 3.0:
+            cl.append([])
+        cl[-1].append(d_)
+    for c in cl:
+        rows.append((sum(c), n, g, len(c), c))
+for t, n, g, c, ds in sorted(rows, reverse=True)[:60]:
+    print(f"  {c / K:6.1f} calls/step {t / c:9.2f} us avg {ds[0]:9.2f} min {ds[-1]:9.2f} max  {t / K / 1e3:7.3f} ms/step  grid {g:6d}  {n[:70]}")

@@ -22,25 +22,7 @@
 //   * without an additive key mask the scores need no mask term at all (keys beyond Lk are zero rows of the K image).
 //
 // Covers 256 < Lk <= 448 without a per-element bias (the BEV encoder's 441 cells); everything else stays on attn_bwd1.
-#include "attn_mfma_common.h"
-
-#define B2_LDS_DS 36                      // row stride (bf16) of the dS image: 32 queries + 4 (conflict-free 8-byte writes)
-#define B2_NKEYW 7                        // key waves
-#define B2_NK (64 * B2_NKEYW)             // keys covered: 448
-
-struct B2Lds {
-  static constexpr int k_off = 0;                                   // [448][LDT] bf16   K, row-major, whole kernel
-  static constexpr int ds_off = k_off + B2_NK * LDT * 2;            // [2][448][36] bf16 dS of a 32-query step
-  static constexpr int q_off = ds_off + 2 * B2_NK * B2_LDS_DS * 2;  // [2][32][LDT] bf16 Q tile
-  static constexpr int do_off = q_off + 2 * 32 * LDT * 2;           // [2][32][LDT] bf16 dO tile
-  static constexpr int stat_off = do_off + 2 * 32 * LDT * 2;        // [2][2][32] float  lse (log2 domain), delta / ks
-  static constexpr int bytes = stat_off + 2 * 2 * 32 * 4;
-};
-
-typedef const __attribute__((address_space(4))) uint64_t* bb_cu64p;
-__device__ __forceinline__ float keep_select(float p, uint64_t lane_mask) {
-  return __builtin_amdgcn_inverse_ballot_w64(lane_mask) ? p : 0.f;     // one v_cndmask_b32 with an SGPR-pair condition
-}
+#include "attn_bwd7p1.h"
 
 // BEVBERT_B2_TRACE=1 (bench_attn_shape.py passes a scratch buffer as dbias): workgroup 0 stamps s_memtime per wave, step
 // and phase into it -- the phase timeline of profiles/r03*_bwd2_timeline*.txt.  Compiled out otherwise.
@@ -50,17 +32,7 @@ __device__ __forceinline__ float keep_select(float p, uint64_t lane_mask) {
       reinterpret_cast<unsigned long long*>(a.dbias)[(w * 16 + (step)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
-// sum over the 8 lanes that share a tile row (lanes 8 j .. 8 j + 7) on the DPP network: no LDS round trip
-template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float sum8(float v) {
-  v += dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]
-  v += dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]
-  return v + dpp_f32<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of its half row
-}
-
-template <bool DROP, bool KMASK, bool TRACE, int VAR>
+template <bool DROP, bool KMASK, bool TRACE>
 __global__ __launch_bounds__(512, 2) void attn_bwd2_kernel(AttnArgs a) {
   typedef B2Lds L;
   extern __shared__ __attribute__((aligned(16))) unsigned char b2_smem[];
@@ -115,15 +87,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd2_kernel(AttnArgs a) {
     const bf16_raw* dolane = dop + dcol;
     const bf16_raw* olane = op + dcol;
     const int ldq = (int)a.ldq, ldo = (int)a.ldo;           // 32-bit element offsets: a (batch, head) slice is far below 2^31 elements
-    // the key waves' keep-bit words of a step are 32 B2_NKEYW contiguous words (1 792 bytes, 14 lines of 128 bytes): one
-    // vector load per step pulls the lines of the step after the next into L2 ahead of the key waves' scalar loads
-    uint32_t bits_touch = 0;
-    const uint32_t* bits_lines = DROP ? reinterpret_cast<const uint32_t*>(a.drop_bits_b + (size_t)bh * (a.nq16 >> 1) * ((size_t)a.nk64 * 32)) : nullptr;
     auto tile_issue = [&](int q0) __attribute__((always_inline)) {      // loads only: nothing here may consume a loaded value (that would wait for all of them)
-      if (DROP && VAR == 1 && lane < (a.nk64 * 32 * 8 + 127) / 128) {
-        const int blk = (q0 >> 5) + 1 < (a.nq16 >> 1) ? (q0 >> 5) + 1 : (q0 >> 5);
-        bits_touch = bits_lines[(size_t)blk * a.nk64 * 64 + lane * 32];
-      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int row = q0 + row0 + 8 * i;
@@ -160,7 +124,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd2_kernel(AttnArgs a) {
         if ((lane & 7) == 0) st[32 + row] = dsum * inv_ks;
       }
       if (lane < 32) st[lane] = lreg * LOG2E;
-      if (DROP && VAR == 1) asm volatile("" : : "v"(bits_touch));      // keeps the touching load alive
     };
     // dQ^T[64 d][32 q] += K^T dS^T over all 448 key rows of the images (rows beyond Lk are zero in both), 14 k-steps of
     // 32 keys.  One wave has nobody to hide its LDS round trips behind and gets a fraction of the LDS issue rate
@@ -218,7 +181,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd2_kernel(AttnArgs a) {
       }
     };
 
-    if (VAR == 1) __builtin_amdgcn_s_setprio(3);       // one wave does 1/5 of the matrix work: it is the pole of a step
     tile_issue(0);
     tile_commit(0);
     __syncthreads();                                   // K image and tile 0 visible
@@ -280,148 +242,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd2_kernel(AttnArgs a) {
       reinterpret_cast<uint2*>(s_ds + (B2_NK + key0) * B2_LDS_DS)[i] = make_uint2(0u, 0u);
     }
   }
-  // softmax backward of one (key tile, 16-query tile): 4 score elements per lane, P / dS stay in their lanes
-  auto soft_bwd = [&](const f32x4& sacc, const f32x4& dpacc, const float (&nl)[4], const f32x4& ndl, float mk,
-                      const uint64_t* bwords, uint2& dsu, uint2& pdu) __attribute__((always_inline)) {
-    float dsv[4], pdv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float off = KMASK ? mk + nl[r] : nl[r];
-      const float p = fast_exp2(fmaf(sacc[r], sc2, off));
-      if (DROP) {
-        const float pd = keep_select(p, bwords[r]);
-        dsv[r] = fmaf(pd, dpacc[r], p * ndl[r]);            // P keep dP - P delta / ks
-        pdv[r] = pd;
-      } else {
-        dsv[r] = p * dpacc[r];                              // dP' = dP - delta came out of the matrix unit
-        pdv[r] = p;
-      }
-    }
-    dsu = make_uint2(pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3]));
-    pdu = make_uint2(pack_bf16x2(pdv[0], pdv[1]), pack_bf16x2(pdv[2], pdv[3]));
-  };
-
-  if (VAR == 1) {
-    // ---------------------------------------------------------------------------------------------------
-    // Two-phase step (round 5).  The first version above walks key tile by key tile: S / dP -> softmax -> 8 dK / dV
-    // matrix instructions whose Q^T / dO^T operands are re-read from LDS for EVERY key tile (64 transposing reads per
-    // step) right in front of their use -- with 256 registers spoken for there is nowhere to prefetch them to, and
-    // the kernel spends 54 % of its wave cycles in s_waitcnt (profiles/r04zz_pmc_attn_sq_counters.txt).  Here:
-    //   phase 1: per 16-query tile tt (A operands 16 + 8 registers instead of 32 + 16), the four key tiles are four
-    //            INDEPENDENT chains S / dP -> softmax -> packed P, dS (4 registers per chain kept: 32 in all);
-    //   phase 2: the 32 dK / dV matrix instructions of the step back to back, d-tile outermost: each Q^T / dO^T
-    //            fragment is read ONCE per step (16 transposing reads) and feeds 4 instructions.
-    // ---------------------------------------------------------------------------------------------------
-    // Keep-bit words: the 32 words (tt, kt, r) of a step sit in 64 scalar registers.  Scalar loads and LDS operations
-    // share one counter (lgkmcnt) and scalar loads return out of order, so EVERY LDS wait behind an outstanding scalar
-    // load waits for that load as well -- each word is read once, i.e. an L2 / HBM round trip.  The first version paid
-    // that four times per step.  Here the words of step k + 1 are requested after the last LDS store of step k has been
-    // waited for and right in front of the barrier that closes the step: the round trip runs while the wave sits in the
-    // barrier (the dQ wave has pulled the cache lines into L2 a step earlier with one vector load).
-    uint64_t bw[32];
-    bb_cu64p wnext = wbits;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) bw[i] = (DROP && has_keys) ? wnext[i] : 0;
-    __syncthreads();                                       // K image and tile 0 visible
-    for (int k = 0; k < nsteps; ++k) {
-      const int buf = k & 1;
-      const bf16_raw* tq = s_q + buf * (32 * LDT);
-      const bf16_raw* tdo = s_do + buf * (32 * LDT);
-      const float* st = s_stat + buf * 64;
-      bf16_raw* img = s_ds + buf * (B2_NK * B2_LDS_DS);
-      B2_STAMP(k, 0);
-      if (has_keys) {
-        uint2 dsu[4][2], pdu[4][2];
-        // phase 1 as a two-deep software pipeline over the 8 chains i = (tt, kt): the matrix instructions of chain i + 1
-        // are issued in front of the vector arithmetic of chain i; a scheduling barrier after each chain keeps the
-        // compiler from hoisting every chain's LDS reads to the top (that version needed 290 registers and spilled)
-        bf16x8 qa0, qa1, da0, da1, qb0, qb1, db0, db1;
-        float nl[4], nlb[4];
-        f32x4 ndl, ndlb;
-        auto load_rows = [&](int tt, bf16x8& q0, bf16x8& q1, bf16x8& d0, bf16x8& d1, float (&l)[4], f32x4& dl)
-                             __attribute__((always_inline)) {
-          q0 = lds_frag_rows(tq, tt, 0, lane); q1 = lds_frag_rows(tq, tt, 1, lane);
-          d0 = lds_frag_rows(tdo, tt, 0, lane); d1 = lds_frag_rows(tdo, tt, 1, lane);
-          const float4 l4 = *reinterpret_cast<const float4*>(&st[tt * 16 + g * 4]);
-          const float4 d4 = *reinterpret_cast<const float4*>(&st[32 + tt * 16 + g * 4]);
-          l[0] = -l4.x; l[1] = -l4.y; l[2] = -l4.z; l[3] = -l4.w;               // -lse (log2 domain)
-          dl = (f32x4){-d4.x, -d4.y, -d4.z, -d4.w};                             // -delta / ks
-        };
-        auto chain_mma = [&](int kt, const bf16x8& q0, const bf16x8& q1, const bf16x8& d0, const bf16x8& d1, const f32x4& dl,
-                             f32x4& sacc, f32x4& dpacc) __attribute__((always_inline)) {
-          const bf16x8 kf0 = lds_frag_rows(s_k, w * 4 + kt, 0, lane), kf1 = lds_frag_rows(s_k, w * 4 + kt, 1, lane);
-          sacc = mfma16(q0, kf0, (f32x4){0.f, 0.f, 0.f, 0.f});
-          sacc = mfma16(q1, kf1, sacc);
-          dpacc = mfma16(d0, vf[kt][0], DROP ? (f32x4){0.f, 0.f, 0.f, 0.f} : dl);
-          dpacc = mfma16(d1, vf[kt][1], dpacc);
-        };
-        load_rows(0, qa0, qa1, da0, da1, nl, ndl);
-        f32x4 sa, dpa, sb, dpb;
-        chain_mma(0, qa0, qa1, da0, da1, ndl, sa, dpa);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int tt = i >> 2, kt = i & 3;
-          if (i == 3) load_rows(1, qb0, qb1, db0, db1, nlb, ndlb);
-          // chain i + 1's matrix instructions
-          if (i < 7) {
-            const int ktn = (i + 1) & 3;
-            if (i + 1 < 4) chain_mma(ktn, qa0, qa1, da0, da1, ndl, (i & 1) ? sa : sb, (i & 1) ? dpa : dpb);
-            else chain_mma(ktn, qb0, qb1, db0, db1, ndlb, (i & 1) ? sa : sb, (i & 1) ? dpa : dpb);
-          }
-          // chain i's vector arithmetic
-          const uint64_t* bcur = bw + tt * 16 + kt * 4;
-          if (tt == 0) soft_bwd((i & 1) ? sb : sa, (i & 1) ? dpb : dpa, nl, ndl, mask2[kt], bcur, dsu[kt][tt], pdu[kt][tt]);
-          else soft_bwd((i & 1) ? sb : sa, (i & 1) ? dpb : dpa, nlb, ndlb, mask2[kt], bcur, dsu[kt][tt], pdu[kt][tt]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        B2_STAMP(k, 2);
-        // phase 2.  Program order: first d-tile's fragments, THEN the dS image (the transposing reads below may not be
-        // hoisted over LDS stores the compiler cannot prove disjoint), then read-ahead by one d-tile.
-        bf16x8 qtf = lds_frag_tr(tq, LDT, 4 * g, 16 + 4 * g, 0, lane);
-        bf16x8 dotf = lds_frag_tr(tdo, LDT, 4 * g, 16 + 4 * g, 0, lane);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
-            *reinterpret_cast<uint2*>(img + (key0 + kt * 16 + c) * B2_LDS_DS + 16 * tt + 4 * g) = dsu[kt][tt];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          bf16x8 qtn = qtf, dotn = dotf;
-          if (dt < 3) {
-            qtn = lds_frag_tr(tq, LDT, 4 * g, 16 + 4 * g, (dt + 1) * 16, lane);
-            dotn = lds_frag_tr(tdo, LDT, 4 * g, 16 + 4 * g, (dt + 1) * 16, lane);
-          }
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-            // B operands of the "contract over queries" products: k-slot (g, j) <-> query 16 (j >> 2) + 4 g + (j & 3)
-            const bf16x8 dsb = as_bf16x8(make_uint4(dsu[kt][0].x, dsu[kt][0].y, dsu[kt][1].x, dsu[kt][1].y));
-            const bf16x8 pdb = as_bf16x8(make_uint4(pdu[kt][0].x, pdu[kt][0].y, pdu[kt][1].x, pdu[kt][1].y));
-            dkacc[kt][dt] = mfma16(qtf, dsb, dkacc[kt][dt]);
-            dvacc[kt][dt] = mfma16(dotf, pdb, dvacc[kt][dt]);
-          }
-          qtf = qtn;
-          dotf = dotn;
-        }
-      }
-      // closes step k: this wave's LDS stores have landed (the address operand ties the scalar loads below to this point:
-      // loads from the constant address space would otherwise be free to move up), the next step's words are requested,
-      // then the barrier.  No fence here: an acquire fence would wait for the scalar loads in front of the barrier.
-      B2_STAMP(k, 3);
-      __builtin_amdgcn_sched_barrier(0);                   // everything of the step is issued before the scalar loads
-      if (DROP && has_keys) {
-        wnext = wbits + (size_t)(k + 1 < nsteps ? k + 1 : k) * bits_step;
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wnext) : : "memory");
-#pragma unroll
-        for (int i = 0; i < 32; ++i) bw[i] = wnext[i];
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" : : : "memory");
-      B2_STAMP(k, 4);
-    }
-  } else {
   // keep-bit words travel one key tile ahead of their use (every word is read once: each scalar load is a cache miss
   // with an L2 / HBM round trip; issued right in front of its first use that latency was fully exposed, 1 100 cycles per
   // key tile in the r03h timeline)
@@ -479,7 +299,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd2_kernel(AttnArgs a) {
         uint2 dsu[2], pdu[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-          soft_bwd(sacc[tt], dpacc[tt], nl[tt], ndl[tt], mask2[kt], bw + tt * 4, dsu[tt], pdu[tt]);
+          float dsv[4], pdv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float off = KMASK ? mask2[kt] + nl[tt][r] : nl[tt][r];
+            const float p = fast_exp2(fmaf(sacc[tt][r], sc2, off));
+            if (DROP) {
+              const float pd = keep_select(p, bw[tt * 4 + r]);
+              dsv[r] = fmaf(pd, dpacc[tt][r], p * ndl[tt][r]);            // P keep dP - P delta / ks
+              pdv[r] = pd;
+            } else {
+              dsv[r] = p * dpacc[tt][r];                                  // dP' = dP - delta came out of the matrix unit
+              pdv[r] = p;
+            }
+          }
+          dsu[tt] = make_uint2(pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3]));
+          pdu[tt] = make_uint2(pack_bf16x2(pdv[0], pdv[1]), pack_bf16x2(pdv[2], pdv[3]));
           // dS image [key][query]: this lane's 4 consecutive queries of tile tt at row key
           *reinterpret_cast<uint2*>(img + (key0 + kt * 16 + c) * B2_LDS_DS + 16 * tt + 4 * g) = dsu[tt];
         }
@@ -508,7 +343,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd2_kernel(AttnArgs a) {
     __syncthreads();                                     // closes step k
     B2_STAMP(k, 4);
   }
-  }
 
   // ---- epilogue: dK = scale * ks * dK^T, dV = ks * dV^T
 #pragma unroll
@@ -532,12 +366,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd2_kernel(AttnArgs a) {
 // =============================================================================================
 // launcher
 // =============================================================================================
-template <bool D_, bool M_, bool T_ = false, int V_ = 0>
+template <bool D_, bool M_, bool T_ = false>
 static int launch_bwd2(const AttnArgs& a, hipStream_t st) {
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd2_kernel<D_, M_, T_, V_>),
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd2_kernel<D_, M_, T_>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, B2Lds::bytes) == hipSuccess;
   BB_REQUIRE(ok, "attention bwd (7+1 waves): cannot raise the dynamic LDS limit to %d bytes", B2Lds::bytes);
-  hipLaunchKernelGGL((attn_bwd2_kernel<D_, M_, T_, V_>), dim3((unsigned)a.B * a.nh), dim3(512), B2Lds::bytes, st, a);
+  hipLaunchKernelGGL((attn_bwd2_kernel<D_, M_, T_>), dim3((unsigned)a.B * a.nh), dim3(512), B2Lds::bytes, st, a);
   BB_CHECK_LAUNCH("attn_bwd(7+1 waves)");
   return BB_OK;
 }
@@ -553,14 +387,8 @@ int attn_bwd2(const AttnArgs& a, hipStream_t st) {
                  ((uintptr_t)a.dq % 16) == 0 && ((uintptr_t)a.dk % 16) == 0 && ((uintptr_t)a.dv % 16) == 0,
              "attention bwd (MFMA path): pointers must be 16-byte aligned and strides multiples of 8 elements");
   const bool hd = a.drop_p > 0.f, km = a.key_mask != nullptr;
-  // BEVBERT_B2_VAR=0: the key-tile-by-key-tile loop of round 3 (A/B measurements, on-GPU cross-check of the two-phase loop)
-  static const int var = [] { const char* v = getenv("BEVBERT_B2_VAR"); return v ? atoi(v) : 1; }();
   static const bool trace = [] { const char* v = getenv("BEVBERT_B2_TRACE"); return v && v[0] == '1'; }();
-  if (trace && a.dbias != nullptr && hd && !km) return var == 0 ? launch_bwd2<true, false, true>(a, st) : launch_bwd2<true, false, true, 1>(a, st);
-  if (var == 0) {
-    if (hd) return km ? launch_bwd2<true, true>(a, st) : launch_bwd2<true, false>(a, st);
-    return km ? launch_bwd2<false, true>(a, st) : launch_bwd2<false, false>(a, st);
-  }
-  if (hd) return km ? launch_bwd2<true, true, false, 1>(a, st) : launch_bwd2<true, false, false, 1>(a, st);
-  return km ? launch_bwd2<false, true, false, 1>(a, st) : launch_bwd2<false, false, false, 1>(a, st);
+  if (trace && a.dbias != nullptr && hd && !km) return launch_bwd2<true, false, true>(a, st);
+  if (hd) return km ? launch_bwd2<true, true>(a, st) : launch_bwd2<true, false>(a, st);
+  return km ? launch_bwd2<false, true>(a, st) : launch_bwd2<false, false>(a, st);
 }

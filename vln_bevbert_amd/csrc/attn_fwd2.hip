@@ -250,7 +250,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd2_kernel(AttnArgs a) {
 
 // Round 5: the same kernel on a further diet (see the comments inside): fused multiply-add before the maximum, select
 // before the packed conversion, keep-bit words of a whole tile requested in front of the tile barrier.
-template <int NW, bool DROP>
+// ABL (diagnostics, BEVBERT_FWD_ABL; results WRONG): 1 = no softmax arithmetic, 2 = no P V products, 4 = no Q K^T products,
+// 8 = no K / V staging after tile 1, 16 = no running-maximum check, 64 = one key tile only
+template <int NW, bool DROP, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, 4) void attn_fwd3_kernel(AttnArgs a) {
   constexpr int QT = 2;                      // 16-query tiles per wave
   constexpr int NT = 64 * NW;
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd3_kernel(AttnArgs a) {
   for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) kw[qt][i] = DROP ? wq[qt][i] : 0;
-  for (int kv0 = 0, cur = 0; kv0 < a.Lk; kv0 += TK, cur ^= 1) {
+  const int Lk_run = (ABL & 64) ? (a.Lk < TK ? a.Lk : TK) : a.Lk;
+  for (int kv0 = 0, cur = 0; kv0 < Lk_run; kv0 += TK, cur ^= 1) {
     const bf16_raw* ck = s_k[cur];
     const bf16_raw* cv = s_v[cur];
     const float* cmask = s_mask[cur];
@@ -361,12 +364,12 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd3_kernel(AttnArgs a) {
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8 kf = f2_frag_rows(ck, t, ks, lane);
 #pragma unroll
-          for (int qt = 0; qt < QT; ++qt) sacc[qt][tt] = mfma16(kf, qf[qt][ks], sacc[qt][tt]);
+          for (int qt = 0; qt < QT; ++qt) if (!(ABL & 4)) sacc[qt][tt] = mfma16(kf, qf[qt][ks], sacc[qt][tt]);
         }
       }
       // ---- first half: stage tile j+1 into the other buffer (its last readers passed the barrier that closed
       //      iteration j-1) and start the global loads of tile j+2; both overlap the arithmetic below
-      if (hh == 0 && kv0 + TK < a.Lk) {
+      if (hh == 0 && kv0 + TK < a.Lk && !((ABL & 8) && kv0 > 0)) {
         stage_store(cur ^ 1);
         if (kv0 + 2 * TK < a.Lk) stage_load(kv0 + 2 * TK);
       }
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd3_kernel(AttnArgs a) {
         lm[qt] = max3f(max3f(s0[0], s0[1], s0[2]), max3f(s0[3], s1[0], s1[1]), fmaxf(s1[2], s1[3]));
         grow |= (lm[qt] > FWD2_THR) | ((m_run[qt] == -INFINITY) & (lm[qt] > -INFINITY));   // no maximum yet: any finite score sets it
       }
-      if (__any(grow)) {
+      if ((ABL & 16) ? (kv0 == 0 && hh == 0) : __any(grow)) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
           const float m_new = fmaxf(m_run[qt], quad_max(lm[qt]) - nm[qt]);      // lm is relative to the stale maximum
@@ -416,9 +419,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd3_kernel(AttnArgs a) {
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float p = fast_exp2(sacc[qt][tt][r]);
+            float p = (ABL & 1) ? sacc[qt][tt][r] : fast_exp2(sacc[qt][tt][r]);
             psum += p;
-            if (DROP) {
+            if (DROP && !(ABL & 1)) {
               p = drop_select(p, kw[qt][(2 * hh + tt) * 4 + r]);
               asm("" : "+v"(p));
             }
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_fwd3_kernel(AttnArgs a) {
       for (int dt = 0; dt < 4; ++dt) {
         const bf16x8 vf = f2_frag_tr(cv, 32 * hh + 4 * g, 32 * hh + 16 + 4 * g, dt * 16, lane);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = mfma16(vf, pb[qt], oacc[qt][dt]);
+        for (int qt = 0; qt < QT; ++qt) if (!(ABL & 2)) oacc[qt][dt] = mfma16(vf, pb[qt], oacc[qt][dt]);
       }
 
     }
@@ -575,6 +578,23 @@ static int launch_fwd2(const AttnArgs& a_in, hipStream_t st) {
     if (a.drop_p > 0.f) hipLaunchKernelGGL((attn_fwd2_kernel<NW, true>), grid, dim3(64 * NW), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd2_kernel<NW, false>), grid, dim3(64 * NW), 0, st, a);
   } else {
+    static const int abl = [] { const char* v = getenv("BEVBERT_FWD_ABL"); return v ? atoi(v) : 0; }();
+    if (abl && a.drop_p > 0.f && NW == 4) {
+      switch (abl) {
+        case 1: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 1>), grid, dim3(256), 0, st, a); return BB_OK;
+        case 2: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 2>), grid, dim3(256), 0, st, a); return BB_OK;
+        case 4: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 4>), grid, dim3(256), 0, st, a); return BB_OK;
+        case 6: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 6>), grid, dim3(256), 0, st, a); return BB_OK;
+        case 7: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 7>), grid, dim3(256), 0, st, a); return BB_OK;
+        case 8: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 8>), grid, dim3(256), 0, st, a); return BB_OK;
+        case 16: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 16>), grid, dim3(256), 0, st, a); return BB_OK;
+        case 17: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 17>), grid, dim3(256), 0, st, a); return BB_OK;
+        case 31: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 31>), grid, dim3(256), 0, st, a); return BB_OK;
+        case 64: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 64>), grid, dim3(256), 0, st, a); return BB_OK;
+        case 95: hipLaunchKernelGGL((attn_fwd3_kernel<4, true, 95>), grid, dim3(256), 0, st, a); return BB_OK;
+        default: break;
+      }
+    }
     if (a.drop_p > 0.f) hipLaunchKernelGGL((attn_fwd3_kernel<NW, true>), grid, dim3(64 * NW), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd3_kernel<NW, false>), grid, dim3(64 * NW), 0, st, a);
   }
@@ -596,5 +616,6 @@ int attn_fwd2(const AttnArgs& a, hipStream_t st) {
   // 4 waves x 32 queries: four workgroups share a CU (16 waves).  The 7-wave shape (two workgroups of 224 queries cover
   // the 441 BEV cells without the 14 % padding of 128-query blocks) measured slower: 97 vs 88 us (BEVBERT_FWD2_NW=7)
   if (force == 7) return launch_fwd2<7>(a, st);
+  if (force == 8) return launch_fwd2<8>(a, st);
   return launch_fwd2<4>(a, st);
 }

@@ -46,6 +46,8 @@ bool attn_fwd2_supported(const AttnArgs& a);
 int attn_drop_bits(const AttnArgs& a, uint64_t* bits_f, uint64_t* bits_b, hipStream_t st);
 int attn_bwd2(const AttnArgs& a, hipStream_t st);
 bool attn_bwd2_supported(const AttnArgs& a);
+int attn_bwd3(const AttnArgs& a, hipStream_t st);
+bool attn_bwd3_supported(const AttnArgs& a);
 int attn_small_fwd(const AttnArgs& a, hipStream_t st);
 bool attn_small_fwd_supported(const AttnArgs& a);
 int attn_small_bwd(const AttnArgs& a, hipStream_t st);
@@ -158,6 +160,10 @@ BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, co
     // query-owner / key-owner waves, attn_small.hip.  BEVBERT_ATTN_SMALL_BWD=0 keeps the single-pass kernel (A/B).
     if (!split && !gen1 && im == 2 && small_bwd2_on() && attn_small_bwd2_supported(a)) return attn_small_bwd2(a, stream);
     if (!split && !gen1 && small_kernels_on() && im == 2 && attn_small_bwd_supported(a)) return attn_small_bwd(a, stream);
+    // BEVBERT_ATTN_BWD3=0: the round-3 loop of the 7+1-wave kernel (attn_bwd2.hip) where the round-5 one (attn_bwd3.hip)
+    // would run -- A/B measurements and the on-GPU cross-check
+    static const bool gen3 = [] { const char* v = getenv("BEVBERT_ATTN_BWD3"); return !(v && v[0] == '0'); }();
+    if (!split && !gen1 && gen3 && im == 2 && attn_bwd3_supported(a)) return attn_bwd3(a, stream);
     if (!split && !gen1 && im == 2 && attn_bwd2_supported(a)) return attn_bwd2(a, stream);
     if (!split && im == 2 && attn_mfma_bwd1_supported(a)) return attn_mfma_bwd1(a, stream);
     return attn_mfma_bwd(a, stream);
