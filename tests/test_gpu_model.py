@@ -33,9 +33,22 @@ FP32_TOL = 1e-3          # north_star: "within 1e-3 fp32"
 # the tiny (ragged / fixed), object-token (REVERIE, separate obj_linear), RxR-vocabulary, CE-fork and full-R2R batches;
 # a tensor without an entry (the fine-tune API's three modes) falls back to the reference's WORST own error over all
 # recorded tensors x the same factor.
+# Round 5: the relative gates are CAPPED.  With factor 3 the loosest forward gate reached 7e-2 and the loosest
+# gradient gate 0.40 while the worst ACHIEVED values of the suite are 1.48e-2 and 0.247 (profiles/r04zz_bf16_errors.jsonl):
+# room for a dropped rounding fix or a wrong accumulation order to pass.  Ceilings: forward 3e-2, gradients 0.25; a tensor
+# whose recorded achieved value needs more is listed in BF16_GRAD_CEIL_OVERRIDE with that value + 20 %.  A tensor without
+# an entry in the golden takes the worst own error of ITS configuration (not of the whole file); comparisons outside any
+# configuration (module vectors, the fine-tune API) the file-wide worst -- under the same ceilings.
 BF16_MEAN_TOL = 1e-2
 REF_FACTOR = 3.0
 BF16_GRAD_FLOOR = 0.05
+BF16_FWD_CEIL = 3e-2
+BF16_GRAD_CEIL = 0.25
+BF16_GRAD_CEIL_OVERRIDE = {      # achieved (r04zz): 0.247 / 0.230 / 0.224 -- REVERIE objects through a separate obj_linear,
+    "tiny_objlin::og_grad::bert.embeddings.word_embeddings.weight": 0.30,      # the reference's own autocast error there: 0.10
+    "tiny_objlin::og_grad::bert.img_embeddings.img_linear.weight": 0.28,
+    "tiny_objlin::og_grad::bert.img_embeddings.nav_type_embedding.weight": 0.27,
+}
 _REF_ERR = None
 
 
@@ -48,7 +61,9 @@ def _ref_err(tag, key, kind):
         _REF_ERR = {k: float(g[k]) for k in g.files}
     v = _REF_ERR.get(f"{tag}::{key}::{kind}")
     if v is None:
-        v = max(x for k, x in _REF_ERR.items() if k.endswith("::" + kind) and "sprel_linear.bias" not in k)
+        own = [x for k, x in _REF_ERR.items() if k.startswith(f"{tag}::") and k.endswith("::" + kind)
+               and "sprel_linear.bias" not in k]
+        v = max(own) if own else max(x for k, x in _REF_ERR.items() if k.endswith("::" + kind) and "sprel_linear.bias" not in k)
     return v
 
 
@@ -74,11 +89,11 @@ def bf16_close(got, want, what, tag=None):
     scale = max(1e-6, float(np.abs(want[fin]).max()))
     err = np.abs(got[fin] - want[fin])
     ref_max = _ref_err(tag, what, "max_rel")
-    gate = max(1e-2, REF_FACTOR * ref_max)
+    gate = min(BF16_FWD_CEIL, max(1e-2, REF_FACTOR * ref_max))
     _record("fwd", f"{tag}::{what}", mean_rel=err.mean() / scale, max_rel=err.max() / scale, ref_max_rel=ref_max, gate=gate)
     assert err.mean() / scale < BF16_MEAN_TOL and err.max() / scale < gate, \
         (tag, what, f"mean {err.mean() / scale:.3e} (tol {BF16_MEAN_TOL}) max {err.max() / scale:.3e} "
-                    f"(gate {gate:.3e} = max(1e-2, {REF_FACTOR} x the reference's own {ref_max:.3e}))")
+                    f"(gate {gate:.3e} = min({BF16_FWD_CEIL}, max(1e-2, {REF_FACTOR} x the reference's own {ref_max:.3e})))")
 
 
 def bf16_grad_close(got, ref, what, tag=None):
@@ -92,10 +107,10 @@ def bf16_grad_close(got, ref, what, tag=None):
         return
     l2 = float(np.linalg.norm(got - ref) / max(1e-12, np.linalg.norm(ref)))
     ref_l2 = _ref_err(tag, what, "rel_l2")
-    gate = max(BF16_GRAD_FLOOR, REF_FACTOR * ref_l2)
+    gate = min(BF16_GRAD_CEIL_OVERRIDE.get(f"{tag}::{what}", BF16_GRAD_CEIL), max(BF16_GRAD_FLOOR, REF_FACTOR * ref_l2))
     _record("grad", f"{tag}::{what}", rel_l2=l2, ref_rel_l2=ref_l2, gate=gate)
-    assert l2 < gate, (tag, what, f"relative L2 {l2:.3e} (gate {gate:.3e} = max({BF16_GRAD_FLOOR}, {REF_FACTOR} x the "
-                                  f"reference's own {ref_l2:.3e}))")
+    assert l2 < gate, (tag, what, f"relative L2 {l2:.3e} (gate {gate:.3e} = min(ceiling, max({BF16_GRAD_FLOOR}, {REF_FACTOR} x "
+                                  f"the reference's own {ref_l2:.3e})))")
 
 
 @pytest.fixture(scope="module")

@@ -485,6 +485,7 @@ class ReduceQueue:
 
     jobs = []
     accum_jobs = []
+    table_bytes = {}     # device address of a task table -> algorithmic bytes of one launch over it (bench.py's rooflines)
     producers = {}       # raw stream handle -> torch stream on which first stages of pending records were launched
     _tables = {}
     _accum_tables = {}
@@ -543,7 +544,10 @@ class ReduceQueue:
             t["dtype"] = dt
             parts.append(t)
         table = np.concatenate(parts) if parts else np.zeros(0, dtype=cls._adtype)
-        return torch.from_numpy(table.view(np.uint8).copy()).to(device), len(table)
+        dev = torch.from_numpy(table.view(np.uint8).copy()).to(device)
+        # every partial slice read once (its own dtype), the sink read and written once (fp32)
+        cls.table_bytes[dev.data_ptr()] = int(sum(S * n * (4 if dt == lib.F32 else 2) + 8 * n for _, _, S, n, dt in jobs))
+        return dev, len(table)
 
     @classmethod
     def add(cls, partials_ptr, nblocks, nwhich, C, outs, accumulate=1):
@@ -574,6 +578,9 @@ class ReduceQueue:
                 parts.append(t)
         table = np.concatenate(parts) if parts else np.zeros(0, dtype=cls._dtype)
         dev = torch.from_numpy(table.view(np.uint8).copy()).to(device)
+        # fp32 partial sums read once, outputs written (and read when accumulating)
+        cls.table_bytes[dev.data_ptr()] = int(4 * (table["nblocks"].astype(np.int64) * table["ncols"]).sum()
+                                              + 4 * (table["ncols"] * (1 + (table["accumulate"] != 0))).sum()) if len(table) else 0
         return dev, len(table)
 
     @classmethod
