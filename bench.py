@@ -468,17 +468,6 @@ def main():
         for k, r in rows.items():
             by_entry[k.split("[")[0]] = by_entry.get(k.split("[")[0], 0.0) + r["ms"]
         dom_entry = max(by_entry, key=by_entry.get)
-        dom_key, dom = max(((k, r) for k, r in rows.items() if k.split("[")[0] == dom_entry), key=lambda kv: kv[1]["ms"])
-        traffic = traffic_source = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", name)) as f:
-                    traffic = json.load(f).get(dom_key)
-            except Exception:
-                traffic = None
-            if traffic is not None:
-                traffic_source = f"profiles/{name} (separate rocprofv3 --pmc passes over scripts/bench_attn.py, not this process)"
-                break
 
         def roof(r):
             secs = r["ms"] / 1e3
@@ -490,46 +479,66 @@ def main():
             return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4)}
 
-        # the same entry over ALL its shapes of the profiled steps (the heaviest shape is the entry's best case;
-        # its short-sequence launches run far below it): total algorithmic work / total time between the events
-        ent_rows = [r for k, r in rows.items() if k.split("[")[0] == dom_entry]
-        ent = {"ms": sum(r["ms"] for r in ent_rows), "gflop": sum(r["gflop"] for r in ent_rows),
-               "mb": sum(r["mb"] for r in ent_rows)}
-        out["roofline"] = {"kernel": dom_key, **roof(dom), "traffic": traffic, "traffic_source": traffic_source,
-                           "avg_launch_us": dom["avg_us"],
-                           "launches": dom["launches"],
-                           "entry_share_of_custom_ms": round(by_entry[dom_entry] / max(custom_ms, 1e-9), 3),
-                           "entry_frac": roof(ent)["frac"], "entry_achieved": roof(ent)["achieved"],
-                           "entry_launches": sum(r["launches"] for r in ent_rows),
-                           "entry_shapes": {k.split("[", 1)[1].rstrip("]") if "[" in k else "all":
-                                            {"launches": r["launches"], "avg_us": r["avg_us"], "frac": roof(r)["frac"]}
-                                            for k, r in rows.items() if k.split("[")[0] == dom_entry}}
-        # Cross-check of the bracketed figure for the dominant kernel: the SAME C-ABI call (same arguments; its operands
-        # were activations of the profiled step, whose memory is still mapped and no longer in use) ten times back to
-        # back between ONE pair of events.  If the per-launch brackets contained launch latency the two would differ;
-        # on the MI355X they agree within 0.1 % (239.2 vs 239.1 us), i.e. the bracket measures the kernel.
-        try:
-            name = dom_key.split("[")[0]
-            if name not in ("bevbert_attn_fwd", "bevbert_attn_bwd"):      # only entries that are pure functions of
-                raise RuntimeError(f"{name} is not replayed (it updates state)")          # their operands are repeated
-            args0 = trace[dom_key][0][2]
-            torch.cuda.synchronize()
-            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ops._raw_call(name, *args0)
-            s_ev.record()
-            for _ in range(10):
-                ops._raw_call(name, *args0)
-            e_ev.record()
-            torch.cuda.synchronize()
-            b2b_us = 100.0 * s_ev.elapsed_time(e_ev)
-            f1, b1 = algorithmic_work(dom_key, args0, esize)
-            unit_work = f1 / 1e12 if f1 > 0 else b1 / 1e9
-            peak = MFMA_BF16_PEAK_TFLOPS if f1 > 0 else HBM_PEAK_GBS
-            out["roofline"]["back_to_back_us"] = round(b2b_us, 2)
-            out["roofline"]["achieved_back_to_back"] = round(unit_work / (b2b_us * 1e-6), 2)
-            out["roofline"]["frac_back_to_back"] = round(unit_work / (b2b_us * 1e-6) / peak, 4)
-        except Exception as e:      # noqa: BLE001 -- an extra figure must not cost the bench line
-            out["roofline"]["back_to_back_error"] = repr(e)[:200]
+        def entry_block(entry):
+            """roofline of one C-ABI entry: quoted for its heaviest shape (one problem size = one row of the rocprofv3
+            per-shape summary under profiles/), plus the entry over ALL its shapes of the profiled steps (entry_frac: total
+            algorithmic work / total time; the short-sequence launches run far below the heaviest shape)"""
+            key, top = max(((k, r) for k, r in rows.items() if k.split("[")[0] == entry), key=lambda kv: kv[1]["ms"])
+            traffic = traffic_source = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
+            for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        traffic = json.load(f).get(key)
+                except Exception:
+                    traffic = None
+                if traffic is not None:
+                    traffic_source = (f"profiles/{name} (separate rocprofv3 --pmc passes over scripts/bench_attn_shape.py / "
+                                      "bench_rowops.py, not this process)")
+                    break
+            ent_rows = [r for k, r in rows.items() if k.split("[")[0] == entry]
+            ent = {"ms": sum(r["ms"] for r in ent_rows), "gflop": sum(r["gflop"] for r in ent_rows),
+                   "mb": sum(r["mb"] for r in ent_rows)}
+            blk = {"kernel": key, **roof(top), "traffic": traffic, "traffic_source": traffic_source,
+                   "avg_launch_us": top["avg_us"], "launches": top["launches"],
+                   "entry_share_of_custom_ms": round(by_entry[entry] / max(custom_ms, 1e-9), 3),
+                   "entry_frac": roof(ent)["frac"], "entry_achieved": roof(ent)["achieved"],
+                   "entry_launches": sum(r["launches"] for r in ent_rows),
+                   "entry_shapes": {k.split("[", 1)[1].rstrip("]") if "[" in k else "all":
+                                    {"launches": r["launches"], "avg_us": r["avg_us"], "frac": roof(r)["frac"]}
+                                    for k, r in rows.items() if k.split("[")[0] == entry}}
+            # Cross-check of the bracketed figure: the SAME C-ABI call (same arguments; its operands were activations of the
+            # profiled step, whose memory is still mapped and no longer in use) ten times back to back between ONE pair of
+            # events.  If the per-launch brackets contained launch latency the two would differ; on the MI355X they agree
+            # within 0.1 % (239.2 vs 239.1 us), i.e. the bracket measures the kernel.  Only entries that are pure functions
+            # of their operands are repeated (the optimiser updates state).
+            if entry in ("bevbert_attn_fwd", "bevbert_attn_bwd"):
+                try:
+                    args0 = trace[key][0][2]
+                    torch.cuda.synchronize()
+                    s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ops._raw_call(entry, *args0)
+                    s_ev.record()
+                    for _ in range(10):
+                        ops._raw_call(entry, *args0)
+                    e_ev.record()
+                    torch.cuda.synchronize()
+                    b2b_us = 100.0 * s_ev.elapsed_time(e_ev)
+                    f1, b1 = algorithmic_work(key, args0, esize)
+                    unit_work = f1 / 1e12 if f1 > 0 else b1 / 1e9
+                    peak = MFMA_BF16_PEAK_TFLOPS if f1 > 0 else HBM_PEAK_GBS
+                    blk["back_to_back_us"] = round(b2b_us, 2)
+                    blk["achieved_back_to_back"] = round(unit_work / (b2b_us * 1e-6), 2)
+                    blk["frac_back_to_back"] = round(unit_work / (b2b_us * 1e-6) / peak, 4)
+                except Exception as e:      # noqa: BLE001 -- an extra figure must not cost the bench line
+                    blk["back_to_back_error"] = repr(e)[:200]
+            return blk
+
+        out["roofline"] = entry_block(dom_entry)
+        # the hand-written MFMA kernels (rounds 1-4 quoted the 441 x 441 attention backward as the dominant kernel; since
+        # round 5 the AdamW entry takes more time per step than all attention-backward shapes together): always reported
+        for e_ in ("bevbert_attn_bwd", "bevbert_attn_fwd"):
+            if e_ in by_entry and e_ != dom_entry:
+                out["roofline_" + e_.split("_", 1)[1]] = entry_block(e_)
         # the same figure for every traced hand-written entry (heaviest first) -- context for the line above
         out["kernels"]["roofline_by_kernel"] = {
             k: {**roof(r), "avg_launch_us": r["avg_us"]} for k, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:40]
