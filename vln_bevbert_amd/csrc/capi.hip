@@ -47,6 +47,9 @@ int attn_drop_bits(const AttnArgs& a, uint64_t* bits_f, uint64_t* bits_b, hipStr
 int attn_bwd2(const AttnArgs& a, hipStream_t st);
 bool attn_bwd2_supported(const AttnArgs& a);
 int attn_bwd3(const AttnArgs& a, hipStream_t st);
+int attn_f32_fwd(const AttnArgs& a, hipStream_t st);
+int attn_f32_bwd(const AttnArgs& a, hipStream_t st);
+bool attn_f32_supported(const AttnArgs& a, int dtype, bool bwd);
 bool attn_bwd3_supported(const AttnArgs& a);
 int attn_small_fwd(const AttnArgs& a, hipStream_t st);
 bool attn_small_fwd_supported(const AttnArgs& a);
@@ -131,6 +134,9 @@ BEVBERT_API int bevbert_attn_fwd(const void* q, const void* k, const void* v, vo
     }
     return attn_mfma_fwd(a, stream);
   }
+  // exact arithmetic: fp32 tensors on the fp32 matrix instructions (attn_f32.hip); bf16 storage / BEVBERT_ATTN_F32=simple on
+  // the wave-per-row kernels
+  if (attn_f32_supported(a, dtype, false)) return attn_f32_fwd(a, stream);
   return attn_simple_fwd(a, dtype, stream);
 }
 
@@ -170,6 +176,7 @@ BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, co
   }
   rc = attn_delta(a, delta_ws, dtype, stream);
   if (rc != BB_OK) return rc;
+  if (attn_f32_supported(a, dtype, true)) return attn_f32_bwd(a, stream);
   return attn_simple_bwd(a, dtype, stream);
 }
 
