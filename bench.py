@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32: the fp32 vector rate (MI355X_MICROARCH.md)
 
 
 T_START = time.perf_counter()
@@ -469,12 +470,14 @@ def main():
             by_entry[k.split("[")[0]] = by_entry.get(k.split("[")[0], 0.0) + r["ms"]
         dom_entry = max(by_entry, key=by_entry.get)
 
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+
         def roof(r):
             secs = r["ms"] / 1e3
             if r["gflop"] > 0:
                 ach = r["gflop"] / 1e3 / secs
-                return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4)}
+                return {"bound": "mfma", "achieved": round(ach, 2), "peak": mfma_peak, "unit": "TFLOP/s",
+                        "frac": round(ach / mfma_peak, 4)}
             ach = r["mb"] / 1e3 / secs
             return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4)}
@@ -525,7 +528,7 @@ def main():
                     b2b_us = 100.0 * s_ev.elapsed_time(e_ev)
                     f1, b1 = algorithmic_work(key, args0, esize)
                     unit_work = f1 / 1e12 if f1 > 0 else b1 / 1e9
-                    peak = MFMA_BF16_PEAK_TFLOPS if f1 > 0 else HBM_PEAK_GBS
+                    peak = mfma_peak if f1 > 0 else HBM_PEAK_GBS
                     blk["back_to_back_us"] = round(b2b_us, 2)
                     blk["achieved_back_to_back"] = round(unit_work / (b2b_us * 1e-6), 2)
                     blk["frac_back_to_back"] = round(unit_work / (b2b_us * 1e-6) / peak, 4)
@@ -588,11 +591,14 @@ def side_configs(a):
     15 navigation steps: scripts/ft_r2r.bash:37 --max_action_len 15).  Side measurements, not the bench metric; skipped
     one by one once the whole run has used its time budget."""
     import subprocess
-    budget_s = float(os.environ.get("BEVBERT_BENCH_SIDE_BUDGET_S", "240"))
+    budget_s = float(os.environ.get("BEVBERT_BENCH_SIDE_BUDGET_S", "300"))
     common = ["--steps", "11", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-pass", "--no-stream", "--no-side", "--no-fwd"]
     jobs = [("rxr_b32_len160", [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "rxr", "--txt-len", "160",
                                 "--batch", "32"] + common),
             ("ce_b64", [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "ce"] + common),
+            # the reference's DEFAULT precision (configs/r2r_pretrain.json "fp16": false): fp32 tensors, fp32 library GEMMs,
+            # attention on the fp32 matrix instructions (attn_f32.hip)
+            ("r2r_b64_fp32", [sys.executable, os.path.join(ROOT, "bench.py"), "--dtype", "fp32"] + common),
             ("finetune_rollout_b32_15steps_infer", [sys.executable, os.path.join(ROOT, "scripts", "bench_nav.py"), "--batch", "32",
                                                     "--steps", "15", "--iters", "4", "--warmup", "3", "--mode", "infer"]),
             # the same rollout with the agent's action feedback: logits read back and argmaxed on the host every step
@@ -612,7 +618,7 @@ def side_configs(a):
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             line = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
             d = json.loads(line[-1])
-            keep = ("value", "unit", "ms_per_step", "step_launch", "config", "final_loss", "ms_per_nav_step", "workload",
+            keep = ("value", "unit", "ms_per_step", "dtype", "step_launch", "config", "final_loss", "ms_per_nav_step", "workload",
                     "episodes_per_s", "host_map_bookkeeping_ms_per_nav_step", "ms_per_episode_batch", "map", "action_feedback",
                     "neighbour_bound_overflow")
             res[name] = {k: d[k] for k in keep if k in d}
