@@ -81,6 +81,10 @@ def parse():
     ap.add_argument("--ragged", action="store_true",
                     help="sustained block on ragged batches (T in [1,7], text length in [L/2, L], 36..38 views): many shape "
                          "buckets, reports buckets / captures / eager steps")
+    ap.add_argument("--sustained-ragged", action="store_true",
+                    help="a SECOND sustained block ('sustained_ragged') on ragged batches, next to the fixed-shape one")
+    ap.add_argument("--txt-len-min", type=int, default=0,
+                    help="shortest instruction of the ragged sustained run (default: half of --txt-len)")
     ap.add_argument("--ship-grid", action="store_true",
                     help="sustained block ships the grid features of every batch over PCIe (462 MB fp32 at batch 64) instead "
                          "of reading rows of the device-resident feature store")
@@ -558,6 +562,21 @@ def main():
         except Exception as e:      # noqa: BLE001 -- worker processes / shared memory / a loader thread: report, do not die
             out["sustained"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             log(f"sustained block failed: {out['sustained']['error']}")
+        if a.sustained_ragged and not a.ragged:
+            # in a child process: a second loader / bucket manager in THIS process would garbage-collect the first one's
+            # captured graphs while a capture of its own is open (hipErrorStreamCaptureUnsupported, r05)
+            log("sustained throughput with a live loader, ragged batches (child process)")
+            try:
+                import subprocess
+                cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--ragged", "--steps", "22", "--warmup", "11", "--no-side",
+                       "--no-cpu-baseline", "--no-kernel-pass", "--no-fwd", "--config", a.config, "--batch", str(a.batch),
+                       "--txt-len", str(a.txt_len), "--txt-len-min", str(a.txt_len_min), "--stream-steps", str(a.stream_steps),
+                       "--dtype", a.dtype]
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                d = json.loads([ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")][-1])
+                out["sustained_ragged"] = d.get("sustained")
+            except Exception as e:      # noqa: BLE001
+                out["sustained_ragged"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline (oracle)")
         try:
@@ -685,7 +704,7 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     samples = []
     for i in range(n_pool):
         T = int(rng.integers(1, 8)) if a.ragged else 5
-        L = int(rng.integers(a.txt_len // 2, a.txt_len + 1)) if a.ragged else a.txt_len
+        L = int(rng.integers(a.txt_len_min or a.txt_len // 2, a.txt_len + 1)) if a.ragged else a.txt_len
         samples.append(synthetic.make_sample(rng, i, cfg, T, L, ragged_views=a.ragged, grid=a.ship_grid))
     t0 = time.perf_counter()
     for t in tasks:
@@ -734,7 +753,8 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     n = max(1, a.stream_steps)
     res = {"samples_per_s": round(a.stream_steps * a.batch / dt, 2), "ms_per_step": round(ms, 3),
            "vs_resident": round(resident_ms / ms, 4), "steps": a.stream_steps, "warmup_steps": n_warm,
-           "batches": "ragged (T in [1,7], text in [L/2, L], 36..38 views)" if a.ragged else "fixed shapes (T = 5, L = %d)" % a.txt_len,
+           "batches": (f"ragged (T in [1,7] panoramas, text in [{a.txt_len_min or a.txt_len // 2}, {a.txt_len}] tokens padded to the batch "
+                       "maximum rounded up to 16, 36..38 views)") if a.ragged else "fixed shapes (T = 5, L = %d)" % a.txt_len,
            "grid_features": "462 MB fp32 per batch over PCIe" if a.ship_grid else f"rows of a {store.nbytes() / 2**30:.1f} GiB device-resident store",
            "source": f"a fresh collate per step ({n_pool}-sample pool, {workers} DataLoader worker processes + its pin-memory "
                      f"thread); host-side index building and refill every step",

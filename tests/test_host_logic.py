@@ -407,7 +407,17 @@ def test_static_batch_host_side_and_in_place_refill():
     csr = sb.tensors["gmap_csr"][0]
     n = ref_csr.idx.numel()
     assert torch.equal(csr.rowptr, ref_csr.rowptr) and torch.equal(csr.idx[:n], ref_csr.idx) and csr.capacity >= n
-    assert torch.equal(csr.t_rowptr, ref_csr.t_rowptr) and torch.equal(csr.t_idx[:n], ref_csr.t_idx)
+    # round 5: the panorama axis is padded to a multiple of PANO_PAD with dummy panoramas of one zero view -- source rows
+    # behind the real ones that no segment points at (empty rows of the transposed CSR)
+    from vln_bevbert_amd.static_step import PANO_PAD
+    nr = ref_csr.t_rowptr.numel()
+    assert torch.equal(csr.t_rowptr[:nr], ref_csr.t_rowptr) and bool((csr.t_rowptr[nr:] == ref_csr.t_rowptr[-1]).all())
+    assert torch.equal(csr.t_idx[:n], ref_csr.t_idx)
+    T0 = b1["traj_view_img_fts"].shape[0]
+    Tp = sb.tensors["traj_view_img_fts"].shape[0]
+    assert Tp % PANO_PAD == 0 and T0 <= Tp < T0 + PANO_PAD and csr.n_src == Tp * 36
+    assert torch.equal(sb.tensors["traj_view_img_fts"][:T0], b1["traj_view_img_fts"]) and not sb.tensors["traj_view_img_fts"][T0:].any()
+    assert torch.equal(sb.tensors["traj_vp_view_lens"][:T0], b1["traj_vp_view_lens"]) and bool((sb.tensors["traj_vp_view_lens"][T0:] == 1).all())
     # refill in place: same buffers, the other batch's content
     ptrs = {k: v.data_ptr() for k, v in sb.tensors.items() if torch.is_tensor(v) and not k.endswith("_cpu")}
     assert StaticBatch(cfg, "sap", b2, "cpu").signature == sb.signature

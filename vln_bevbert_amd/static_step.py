@@ -32,6 +32,17 @@ MLM_ROW_PAD = 256       # masked-token rows are padded to a multiple of this (15
 SEM_ROW_PAD = 512       # supervised BEV cells (MaskSEM) likewise
 _STAGE_PINNED = __import__("os").environ.get("BEVBERT_STAGE_PINNED", "1") == "1"      # A/B knob (StaticBatch._staged)
 GMAP_PAD = 4            # global-map width G (batch max of the node counts) is rounded up to a multiple of this
+# Round 5: ragged batches.  The reference pads every batch to ITS OWN maxima (pretrain_src/data/tasks.py:116-163), so the
+# flat panorama count (sum of the path lengths, 64 draws of 1..7), the text width and the view count change from step to
+# step -- one shape bucket (= one captured graph) per batch, i.e. no replays at all (r05 measurement: 64 buckets, 27 of
+# them created inside a 33-step window, every step eager, 0.66 x the resident rate).  Each varying axis is rounded up:
+# text to TXT_PAD tokens (beyond txt_lens: masked like the reference's own padding), panoramas to PANO_PAD dummy
+# panoramas of ONE zero view (no segment of the global-map aggregation refers to them and their outputs feed nothing, so
+# they contribute exact zeros to every gradient; one valid view keeps their softmax finite), views to VIEW_PAD.
+_env_int = lambda k, d: int(__import__("os").environ.get(k, d))
+TXT_PAD = _env_int("BEVBERT_TXT_PAD", 16)
+PANO_PAD = _env_int("BEVBERT_PANO_PAD", 32)
+VIEW_PAD = _env_int("BEVBERT_VIEW_PAD", 4)
 
 
 def _round_up(n, m):
@@ -98,20 +109,44 @@ class StaticBatch:
             full[:, :pd.shape[1], :pd.shape[2]] = pd
             pd = full
         padded["gmap_pair_dists"] = pd
-        lens = batch["traj_vp_view_lens"]
+        has_obj = batch.get("traj_obj_img_fts") is not None
+        # ---- text width
+        L = batch["txt_ids"].shape[1]
+        Lp = _round_up(L, TXT_PAD)
+        if Lp > L:
+            for k, fill in (("txt_ids", 0), ("txt_labels", -1)):
+                if batch.get(k) is not None:
+                    padded[k] = torch.cat([batch[k], batch[k].new_full((B, Lp - L), fill)], 1)
+        txt_shape = (B, Lp)
+        # ---- panorama count and view count (object-token batches run eagerly anyway: left as they are)
+        view_lens = batch["traj_vp_view_lens"]
+        T0, V0 = batch["traj_view_img_fts"].shape[:2]
+        Tp, Vp = (T0, V0) if has_obj else (_round_up(T0, PANO_PAD), _round_up(V0, VIEW_PAD))
+        if (Tp, Vp) != (T0, V0):
+            for k in ("traj_view_img_fts", "traj_loc_fts", "traj_nav_types", "traj_view_dep_fts"):
+                v = batch.get(k)
+                if v is None:
+                    continue
+                full = v.new_zeros((Tp, Vp) + tuple(v.shape[2:]))
+                full[:T0, :V0] = v
+                padded[k] = full
+            view_lens = torch.cat([view_lens, view_lens.new_ones(Tp - T0)])
+            padded["traj_vp_view_lens"] = view_lens
+        lens = view_lens
         if batch.get("traj_vp_obj_lens") is not None:
             lens = lens + batch["traj_vp_obj_lens"]
-        n_views = batch["traj_loc_fts"].shape[1]
+        n_views = Vp
         rowptr, idx, w, n_src, G = gmap_csr_arrays(list(batch["traj_step_lens"]), lens.tolist(), batch["traj_vpids"],
                                                   batch["traj_cand_vpids"], batch["gmap_vpids"], n_views, G)
+        n_src = Tp * n_views                       # the dummy panoramas are source rows no segment points at
         static = {}
-        sig = [task, B, tuple(batch["txt_ids"].shape), tuple(batch["traj_view_img_fts"].shape), G]
+        sig = [task, B, txt_shape, (Tp, Vp) + tuple(batch["traj_view_img_fts"].shape[2:]), G]
         if batch.get("traj_obj_img_fts") is not None:      # buffers of a bucket must agree on the object-token layout too
             # (incl. the width of the joint [views | objects] token axis: the maximum of views + objects over the panoramas)
             sig.append(("obj", tuple(batch["traj_obj_img_fts"].shape), tuple(int(x) for x in batch["traj_step_lens"]),
                         int(n_views)))
         if task.startswith("mlm"):
-            labels = batch["txt_labels"].reshape(-1)
+            labels = padded.get("txt_labels", batch["txt_labels"]).reshape(-1)
             pos = torch.nonzero(labels != -1).squeeze(1)
             n = int(pos.numel())
             npad = _round_up(max(n, 1), MLM_ROW_PAD)
