@@ -135,7 +135,7 @@ class StaticBatch:
         lens = view_lens
         if batch.get("traj_vp_obj_lens") is not None:
             lens = lens + batch["traj_vp_obj_lens"]
-        n_views = Vp
+        n_views = batch["traj_loc_fts"].shape[1] if has_obj else Vp        # objects: the joint [views | objects] token axis
         rowptr, idx, w, n_src, G = gmap_csr_arrays(list(batch["traj_step_lens"]), lens.tolist(), batch["traj_vpids"],
                                                   batch["traj_cand_vpids"], batch["gmap_vpids"], n_views, G)
         n_src = Tp * n_views                       # the dummy panoramas are source rows no segment points at
