@@ -50,7 +50,15 @@ def _worker(rank, world, port, q):
         if leaf[n].grad is not None:
             p.main_grad.copy_(leaf[n].grad)
     local = arena.grads.clone()
-    reducer.phase_a()                       # map encoders + heads first (overlaps with the text encoder's backward)
+    # round 5: regions that follow backward through the map encoders go out FIRST (the heads, then an x-layer's run), in
+    # any order; phase A then reduces only what they left of [split, end) -- every element exactly once
+    n_all = arena.numel
+    heads_lo = min(o for n, (o, k) in arena.slices.items() if not n.startswith("bert."))
+    reducer.launch_region(heads_lo, n_all)
+    mid_lo, mid_hi = split + (heads_lo - split) // 3, split + (heads_lo - split) // 2
+    reducer.launch_region(mid_lo, mid_hi)
+    reducer.phase_a()                       # the rest of map encoders + heads (overlaps with the text encoder's backward)
+    assert reducer._remaining() == [(0, split)] and sorted(reducer._done) == [(split, mid_lo), (mid_lo, mid_hi), (mid_hi, heads_lo), (heads_lo, n_all)]
     reducer.launch_region(split // 3, split // 2)       # an out-of-order middle region (opt-in per-layer text phases)
     assert reducer._remaining() == [(0, split // 3), (split // 2, split)]
     reducer.finish()                        # ... and whatever is left, exactly once

@@ -258,6 +258,65 @@ def test_text_layer_regions_are_final_when_their_hooks_fire(env, dtype):
             h.remove()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_map_layer_regions_are_final_when_their_hooks_fire(env, dtype):
+    """Round 5: the gradient exchange follows backward THROUGH the map encoders -- the heads' region and the region of every
+    x-layer k >= 1 of the local / global encoder go out when d loss / d (streaming input of layer k) is complete
+    (train.PretrainTrainer.map_layer_regions / install_map_layer_hooks).  Same check as for the other phases: snapshot each
+    region when the trainer's hook would launch it (after the flush GradReducer._launch does) and compare with the region
+    after the whole backward, bit for bit, for every task -- including that the hoisted K | V projections, whose gradient
+    is final only at the end of an encoder, are outside every layer region."""
+    from vln_bevbert_amd import ops
+    from vln_bevbert_amd.train import PretrainTrainer
+    cfg = BevBertConfig.tiny(num_l_layers=2, num_x_layers=3, vocab_size=400)
+    model, arena = _fresh(cfg, dtype)
+    tr = PretrainTrainer(model, arena, overlap=False)
+    tr.install_map_layer_hooks()
+    regions = tr._map_regions
+    assert set(regions) == {"heads", ("local", 1), ("local", 2), ("global", 1), ("global", 2)}
+    for enc in ("local", "global"):
+        kv = {n for grp in getattr(model.bert, f"{enc}_encoder").encoder.arena_groups(f"bert.{enc}_encoder.encoder.") for n in grp}
+        for n in kv:
+            o, _ = arena.slices[n]
+            assert not any(lo <= o < hi for key, (lo, hi) in regions.items() if key != "heads"), n
+    snap = {}
+
+    class Spy:                                       # stands in for the reducer: records instead of reducing
+        active = True
+
+        def launch_region(self, lo, hi):
+            ops.WgradStream.flush_all()
+            torch.cuda.synchronize()
+            snap[(lo, hi)] = arena.grads[lo:hi].clone()
+
+    real, tr.reducer = tr.reducer, Spy()
+    try:
+        for step, task in enumerate(("sap", "mlm", "masksem")):
+            snap.clear()
+            tr._reset_map_hooks()
+            ops.RT.new_step(900 + step)
+            arena.zero_grad()
+            b = synthetic.batch_to(synthetic.make_batch(cfg, task, 3, seed=60 + step, ragged=True), DEV)
+            model(b, task).mean().backward()
+            arena.sync()
+            torch.cuda.synchronize()
+            want = {"heads", ("local", 1), ("local", 2)} | ({("global", 1), ("global", 2)} if task != "masksem" else set())
+            assert {k for k, r in regions.items() if r in snap} >= want, (task, sorted(map(str, snap)))
+            for (lo, hi), got in snap.items():
+                final = arena.grads[lo:hi]
+                late = (got != final).nonzero()
+                if late.numel():
+                    off = int(late[0]) + lo
+                    name = [n for n, (o, kk) in arena.slices.items() if o <= off < o + kk]
+                    raise AssertionError(f"{task}: {late.shape[0]} gradient elements of region [{lo}, {hi}) changed after "
+                                         f"its hook, first in {name}")
+                assert float(final.abs().sum()) > 0 or task == "masksem"
+    finally:
+        tr.reducer = real
+        for enc in ("local", "global"):
+            getattr(model.bert, f"{enc}_encoder").encoder.region_hook = None
+
+
 # ----------------------------------------------------------------------------- static batches and captured steps
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_static_batch_step_equals_the_reference_api_step(env, dtype):

@@ -160,11 +160,19 @@ class GradReducer:
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def launch_uncovered(self, lo, hi):
+        """Reduce what has not been issued yet of [lo, hi) (regions inside it may have gone out from earlier hooks)."""
+        for a, b in self._remaining():
+            a, b = max(a, int(lo)), min(b, int(hi))
+            if b > a:
+                self.launch_region(a, b)
+
     def phase_a(self, *_):
-        """Call when every gradient in [split, end) has been enqueued (tensor hook on the text embeddings)."""
+        """Call when every gradient in [split, end) has been enqueued (tensor hook on the text embeddings): reduces what
+        the per-layer hooks of the map encoders have not sent already."""
         if self.active and not self._phase_a_done:
             self._phase_a_done = True
-            self.launch_region(self.split, self.flat.numel())
+            self.launch_uncovered(self.split, self.flat.numel())
 
     def finish(self):
         """Call after backward: reduces what phase A did not cover and joins the side stream."""
@@ -231,6 +239,7 @@ class PretrainTrainer:
         if self.early_flush and not self.overlap:
             model.bert.lang_encoder.register_forward_hook(self._hook_flush)
         if self.overlap:
+            self.install_map_layer_hooks()
             model.bert.lang_encoder.register_forward_hook(self._hook_text)
             # finer pipeline for phase B (embeddings + text + panorama encoders, 43 % of the gradient bytes): when the
             # gradient w.r.t. the INPUT of text layer k is complete, every kernel of the text layers >= k has been
@@ -240,6 +249,58 @@ class PretrainTrainer:
             # finality of every region is tested on the GPU (test_text_layer_regions_are_final_when_their_hooks_fire).
             for k, lo, hi in self.text_layer_regions(model, arena):
                 model.bert.lang_encoder.layer[k].register_forward_pre_hook(self._make_layer_hook(lo, hi))
+
+    @staticmethod
+    def map_layer_regions(model, arena):
+        """Arena regions that follow backward THROUGH the map encoders (round 5; before, the first collective -- 57 % of the
+        bytes -- waited for both encoders, ~70 % of a SAP step's backward): {"heads": (lo, hi), ("local" | "global", k): (lo, hi)
+        for the x-layers k >= 1}.  Layer k's region is the contiguous run of its own parameters WITHOUT the K | V
+        projections of its cross-attention: those are packed with every layer's into one operand (ops.hoisted_kv, laid out
+        inside layer 0's run) whose gradient is final only when the whole encoder is done.  Layer 0, the packed K | V, the
+        encoder's input embeddings and what follows the layers (sprel_linear) stay with the catch-all of phase A."""
+        out = {}
+        heads = [(o, o + k) for n, (o, k) in arena.slices.items() if not n.startswith("bert.")]
+        if heads:
+            out["heads"] = (min(lo for lo, _ in heads), max(hi for _, hi in heads))
+        for enc in ("local", "global"):
+            mod = getattr(model.bert, f"{enc}_encoder").encoder
+            kv = {n for group in mod.arena_groups(f"bert.{enc}_encoder.encoder.") for n in group}
+            for k in range(1, len(mod.x_layers)):
+                pre = f"bert.{enc}_encoder.encoder.x_layers.{k}."
+                own = sorted((o, o + c) for n, (o, c) in arena.slices.items() if n.startswith(pre) and n not in kv)
+                if not own:
+                    continue
+                lo, hi = own[0][0], own[-1][1]
+                # nothing foreign inside the run (tensors start on 1024-element boundaries: gaps are padding)
+                inside = [n for n, (o, c) in arena.slices.items() if lo <= o < hi and not (n.startswith(pre) and n not in kv)]
+                if not inside:
+                    out[(enc, k)] = (lo, hi)
+        return out
+
+    def install_map_layer_hooks(self):
+        regions = self.map_layer_regions(self.model, self.arena)
+        self._map_regions = regions
+        self._map_uses, self._map_fired, self._heads_sent = {}, {}, False
+
+        def make(enc):
+            def hook(k, fired):
+                key = (enc, k)
+                if not fired:                                      # forward: one more use of layer k
+                    self._map_uses[key] = self._map_uses.get(key, 0) + 1
+                    return
+                self._map_fired[key] = self._map_fired.get(key, 0) + 1
+                if not self._heads_sent and "heads" in regions:     # every head's backward precedes any x-layer's
+                    self._heads_sent = True
+                    self.reducer.launch_region(*regions["heads"])
+                if key in regions and self._map_fired[key] == self._map_uses.get(key, 0):
+                    self.reducer.launch_region(*regions[key])
+            return hook
+        for enc in ("local", "global"):
+            getattr(self.model.bert, f"{enc}_encoder").encoder.region_hook = make(enc)
+
+    def _reset_map_hooks(self):
+        if getattr(self, "_map_regions", None) is not None:
+            self._map_uses, self._map_fired, self._heads_sent = {}, {}, False
 
     @staticmethod
     def text_layer_regions(model, arena, spec=None):
@@ -312,6 +373,7 @@ class PretrainTrainer:
         return (task, batch.signature) if isinstance(batch, StaticBatch) else None
 
     def _forward_backward(self, task, batch):
+        self._reset_map_hooks()
         self.arena.zero_grad()
         if isinstance(batch, StaticBatch):
             loss = self.model.loss_mean(batch.tensors, task)

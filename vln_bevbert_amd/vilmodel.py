@@ -367,12 +367,24 @@ class CrossmodalEncoder(_Finalizable):
         w = packed.shape[-1] // self.num_x_layers
         return [packed[..., i * w:(i + 1) * w] for i in range(self.num_x_layers)]
 
+    # Gradient exchange (train.PretrainTrainer, round 5): ``region_hook(k)`` is called when d loss / d (the streaming input
+    # of x-layer k) is complete, i.e. when every backward kernel of the layers >= k of this encoder has been issued -- except
+    # the hoisted K|V projection (one op for all layers: its backward runs after layer 0's) and the input embeddings.
+    region_hook = None
+
+    def _watch(self, k, x):
+        if self.region_hook is not None and torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled():
+            hook = self.region_hook
+            hook(k, False)                                         # one more use of layer k in this forward
+            x.register_hook(lambda g, k=k: (hook(k, True), g)[1])
+        return x
+
     def forward(self, txt_embeds, txt_masks, img_embeds, img_masks, graph_sprels=None, kvs=None):
         tm, im = neg_key_mask(txt_masks), neg_key_mask(img_masks)
         if kvs is None:
             kvs = self.hoist_kv(txt_embeds)
-        for layer, kv in zip(self.x_layers, kvs):
-            img_embeds = layer(txt_embeds, tm, img_embeds, im, graph_sprels=graph_sprels, ctx_kv=kv)
+        for k, (layer, kv) in enumerate(zip(self.x_layers, kvs)):
+            img_embeds = layer(txt_embeds, tm, self._watch(k, img_embeds), im, graph_sprels=graph_sprels, ctx_kv=kv)
         return img_embeds
 
     def forward_lang2visn(self, txt_embeds, txt_key_mask, visn_feats, visn_key_mask, kvs=None):
@@ -380,8 +392,8 @@ class CrossmodalEncoder(_Finalizable):
         hoisted K|V projections of ``visn_feats`` if the caller computed them ahead (they do not depend on the text)."""
         if kvs is None:
             kvs = self.hoist_kv(visn_feats)
-        for layer, kv in zip(self.x_layers, kvs):
-            txt_embeds = layer.forward_lang2visn(txt_embeds, txt_key_mask, visn_feats, visn_key_mask, ctx_kv=kv)
+        for k, (layer, kv) in enumerate(zip(self.x_layers, kvs)):
+            txt_embeds = layer.forward_lang2visn(self._watch(k, txt_embeds), txt_key_mask, visn_feats, visn_key_mask, ctx_kv=kv)
         return txt_embeds
 
 
@@ -886,8 +898,8 @@ class GlocalTextPathCMT(nn.Module):
         elif sem_pred_token == "sattn":
             bev_embeds = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
             km = neg_key_mask(bm)
-            for layer in self.local_encoder.encoder.x_layers:
-                bev_embeds = layer.forward_visn2visn(bev_embeds, km)
+            for k, layer in enumerate(self.local_encoder.encoder.x_layers):
+                bev_embeds = layer.forward_visn2visn(self.local_encoder.encoder._watch(k, bev_embeds), km)
         elif sem_pred_token == "embed":
             bev_embeds = self.local_encoder.bev_input_embedding(bev_fts, bev_pos_fts, bev_nav_masks)
         else:
