@@ -801,3 +801,18 @@ def test_scratch_ring_continues_in_further_buffers_while_reductions_are_queued(m
     ring.reset()
     b = [ring.alloc(1000, dev) for _ in range(14)]
     assert b[:12] == a[:10] + b[10:12] and b[12:] == a[:2] and len(ring._chunks) == 3
+
+
+def test_grad_reducer_skips_gaps_that_hold_no_tensor():
+    """Round 5: regions issued from tensor borders leave the arena's alignment padding between them; a gap no tensor
+    lives in is not a collective of its own, a gap with even a one-element tensor is."""
+    from vln_bevbert_amd.train import GradReducer
+    flat = torch.zeros(8192)
+    red = GradReducer(flat, 4096)
+    red.set_occupied([(0, 1000), (1024, 1), (2048, 2048), (4096, 3000), (7168, 1024)])
+    red._done = [(0, 1000), (2048, 4096), (4096, 7096)]
+    assert red._remaining() == [(1000, 2048), (7096, 8192)]          # [1000, 2048) holds the one-element tensor at 1024
+    red._done += [(1024, 1025), (7168, 8192)]
+    assert red._remaining() == []                                    # what is left is padding only
+    red.occupied = None
+    assert red._remaining() == [(1000, 1024), (1025, 2048), (7096, 7168)]

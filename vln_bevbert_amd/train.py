@@ -92,6 +92,7 @@ class GradReducer:
         self._works = []
         self._phase_a_done = False
         self._done = []          # [lo, hi) regions already issued in this step
+        self.occupied = None     # sorted (start, end) of the tensors in the buffer (set_occupied): padding gaps are skipped
         self.timeline = None     # set to [] to collect (lo, hi, start event, end event) per region (bench.py's rccl block)
 
     def drop_pending(self):
@@ -114,7 +115,24 @@ class GradReducer:
             at = max(at, hi)
         if at < self.flat.numel():
             gaps.append((at, self.flat.numel()))
+        if self.occupied is not None:
+            # tensors start on 1024-element boundaries: between two regions that end / start on tensor borders lies padding
+            # that no kernel writes -- not worth a collective of its own (r05: eight zero-size launches per step)
+            import bisect
+            starts = self._occ_starts
+            keep = []
+            for lo, hi in gaps:
+                i = bisect.bisect_right(starts, lo) - 1
+                hit = (i >= 0 and self.occupied[i][1] > lo) or (i + 1 < len(starts) and starts[i + 1] < hi)
+                if hit:
+                    keep.append((lo, hi))
+            gaps = keep
         return gaps
+
+    def set_occupied(self, slices):
+        """slices: iterable of (offset, numel) of the tensors living in the flat buffer (ParamArena.slices.values())."""
+        self.occupied = sorted((int(o), int(o) + int(k)) for o, k in slices)
+        self._occ_starts = [o for o, _ in self.occupied]
 
     def _exchange_bf16(self, view):
         """SUM over ranks of ``view`` (fp32, in place) with bf16 on the wire (see __init__ for the two variants)."""
@@ -221,6 +239,7 @@ class PretrainTrainer:
                         or not n.startswith("bert."))
         # the arena keeps registration order: embeddings, lang_encoder, img_embeddings come before the map encoders
         self.reducer = GradReducer(arena.grads, first_map, force=force_collectives)
+        self.reducer.set_occupied(arena.slices.values())
         self.overlap = overlap and self.reducer.active
         # RCCL 2.26's all-to-all under stream capture takes the process down (segmentation fault on the MI355X box,
         # one-rank group, gpurun_out r03w) while all-reduce, reduce-scatter and all-gather capture fine: only steps with
