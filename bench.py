@@ -67,6 +67,9 @@ def parse():
                     help="r2r = BASELINE.json configs[1] (the bench line); rxr (xlm-roberta vocabulary, use --txt-len 160) "
                          "and ce (continuous-environment fork) are side measurements")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--residual", default="", choices=["", "fp32"],
+                    help="bf16 run with an fp32 residual stream (torch.autocast's arithmetic: LayerNorm outputs and residual "
+                         "sums of the post-norm blocks stay fp32; side measurement, the bench line is plain bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-pass", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -213,7 +216,7 @@ def main():
     cfg = {"r2r": BevBertConfig, "rxr": BevBertConfig.rxr, "ce": BevBertConfig.ce}[a.config]()   # configs/*_model.json
     torch.manual_seed(0)                                    # identical initial weights on every rank
     model = GlocalTextPathCMTPreTraining(cfg)
-    arena = model.finalize(dev, cdt)
+    arena = model.finalize(dev, cdt, torch.float32 if (a.residual == "fp32" and a.dtype == "bf16") else None)
     model.train()
     model.set_dropout(0.1)                                  # train_r2r.py:157
     trainer = PretrainTrainer(model, arena, rank=rank, world_size=world, force_collectives=force)
@@ -316,7 +319,7 @@ def main():
     out = {
         "metric": "pretrain_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype + ("+fp32-residual" if a.residual == "fp32" and a.dtype == "bf16" else ""), "data": "synthetic",
         "config": {"workload": f"{a.config.upper()} pre-train step (lift+splat, fwd, bwd, all-reduce, clip, AdamW), "
                                "scripts/pt_r2r.bash shapes: 36 views x 512, 5-step paths, 2352 grid points x 768 -> "
                                f"{cfg.bev_dim}x{cfg.bev_dim} BEV, {a.txt_len}-token text, task cycle "
@@ -618,6 +621,8 @@ def side_configs(a):
             # the reference's DEFAULT precision (configs/r2r_pretrain.json "fp16": false): fp32 tensors, fp32 library GEMMs,
             # attention on the fp32 matrix instructions (attn_f32.hip)
             ("r2r_b64_fp32", [sys.executable, os.path.join(ROOT, "bench.py"), "--dtype", "fp32"] + common),
+            # bf16 GEMM / attention operands around an fp32 residual stream: what torch.autocast computes (train_r2r.py:256-258)
+            ("r2r_b64_bf16_fp32_residual", [sys.executable, os.path.join(ROOT, "bench.py"), "--residual", "fp32"] + common),
             ("finetune_rollout_b32_15steps_infer", [sys.executable, os.path.join(ROOT, "scripts", "bench_nav.py"), "--batch", "32",
                                                     "--steps", "15", "--iters", "4", "--warmup", "3", "--mode", "infer"]),
             # the same rollout with the agent's action feedback: logits read back and argmaxed on the host every step

@@ -134,6 +134,21 @@ int bevbert_layernorm_bwd_add(const void* dy, const void* z, const float* mean, 
                               void* dz, void* dx, const void* dz_add, float* dgamma, float* dbeta, float* dbias,
                               float* workspace, int rows, int H, int dtype, float drop_p, uint64_t seed, uint64_t offset,
                               int accumulate, hipStream_t stream);
+/* The LayerNorm pair with an fp32 RESIDUAL STREAM around bf16 matrix operands -- what torch.autocast does to these modules
+ * (pretrain_src/train_r2r.py:256-258: LayerNorm outputs and residual sums stay fp32, only GEMM operands are rounded).
+ * fwd: x bf16 (dense output), residual fp32 or bf16 (residual_dtype: 0 / 1) or NULL; y16 = bf16(y) for the next GEMMs,
+ * y32 = y (fp32) for the next residual add, z32 = the pre-norm sum in fp32 (y32 / z32 / mean / rstd may be NULL).
+ * bwd: the output gradient is dy16 (bf16, from the GEMMs that read y16) + dy32 (fp32, from the residual add that read
+ * y32), either may be NULL; dz32 (fp32) = gradient w.r.t. the residual, dx16 (bf16) = gradient w.r.t. the dense output
+ * (dz through the dropout mask); parameter gradients and workspace as in bevbert_layernorm_bwd. */
+int bevbert_layernorm_res32_fwd(const void* x, const float* bias, const void* residual, int residual_dtype,
+                                const float* gamma, const float* beta, void* y16, float* y32, float* z32, float* mean,
+                                float* rstd, int rows, int H, float eps, float drop_p, uint64_t seed, uint64_t offset,
+                                hipStream_t stream);
+int bevbert_layernorm_res32_bwd(const void* dy16, const float* dy32, const float* z32, const float* mean,
+                                const float* rstd, const float* gamma, float* dz32, void* dx16, float* dgamma,
+                                float* dbeta, float* dbias, float* workspace, int rows, int H, float drop_p, uint64_t seed,
+                                uint64_t offset, int accumulate, hipStream_t stream);
 int64_t bevbert_colsum_workspace_floats(int total_cols);
 /* Split form of the parameter-gradient reductions: bevbert_layernorm_bwd / bevbert_bias_gelu_bwd called with NULL
  * dgamma/dbeta/dbias leave per-block partial sums [bevbert_colsum_partial_rows(rows)][nwhich][C] (nwhich = 3 for

@@ -196,6 +196,167 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
+// =============================================================================================
+// The same pair with an fp32 RESIDUAL STREAM around bf16 matrix operands (round 5; torch.autocast keeps LayerNorm outputs
+// and residual sums in fp32 and only rounds what enters a GEMM: pretrain_src/train_r2r.py:256-258).
+//   forward:  z = dropout(x + bias) + residual, x bf16 (a GEMM output), residual fp32 (the previous LayerNorm's fp32 output)
+//             or bf16 (a stream that starts here); writes y16 = bf16(y) for the next GEMMs, y32 = y for the next residual
+//             add, z in fp32 for the backward
+//   backward: dy = dy16 (bf16: from the GEMMs that read y16) + dy32 (fp32: from the residual add that read y32), either
+//             may be null; dz32 (fp32) continues the residual stream's gradient, dx16 = bf16(dz through the dropout mask)
+//             feeds the dense layer's backward GEMMs; column partials as in ln_bwd_kernel
+// =============================================================================================
+template <typename TR, int NV>
+__global__ __launch_bounds__(256) void ln_res32_fwd_kernel(const bf16_raw* __restrict__ x, const float* __restrict__ bias,
+                                                           const TR* __restrict__ residual, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, bf16_raw* __restrict__ y16,
+                                                           float* __restrict__ y32, float* __restrict__ z_out,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           int rows, float eps, float drop_p, uint32_t drop_thr,
+                                                           uint32_t drop_key, const uint32_t* __restrict__ salt) {
+  constexpr int H = NV * 256;
+  if (drop_p > 0.f) drop_key = bb_salted(drop_key, salt);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float4 v[NV];
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    float4 a = ld4<bf16_raw>(x + (size_t)row * H + col);
+    if (bias != nullptr) {
+      const float4 bb = *reinterpret_cast<const float4*>(bias + col);
+      a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
+    }
+    if (drop_p > 0.f) {
+      const uint32_t pr = ((uint32_t)row * H + col) >> 1;
+      const uint32_t b0 = bb_pair_bits(drop_key, pr), b1 = bb_pair_bits(drop_key, pr + 1);
+      a.x = bb_keep_lo(b0, drop_thr) ? a.x * keep_scale : 0.f;
+      a.y = bb_keep_hi(b0, drop_thr) ? a.y * keep_scale : 0.f;
+      a.z = bb_keep_lo(b1, drop_thr) ? a.z * keep_scale : 0.f;
+      a.w = bb_keep_hi(b1, drop_thr) ? a.w * keep_scale : 0.f;
+    }
+    if (residual != nullptr) {
+      const float4 r = ld4<TR>(residual + (size_t)row * H + col);
+      a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    }
+    v[i] = a;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    if (z_out != nullptr) st4<float>(z_out + (size_t)row * H + col, v[i]);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + col);
+    const float4 b = *reinterpret_cast<const float4*>(beta + col);
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * g.x + b.x;
+    o.y = (v[i].y - mean) * rstd * g.y + b.y;
+    o.z = (v[i].z - mean) * rstd * g.z + b.z;
+    o.w = (v[i].w - mean) * rstd * g.w + b.w;
+    st4<bf16_raw>(y16 + (size_t)row * H + col, o);
+    if (y32 != nullptr) st4<float>(y32 + (size_t)row * H + col, o);
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_res32_bwd_kernel(const bf16_raw* __restrict__ dy16, const float* __restrict__ dy32,
+                                                           const float* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           float* __restrict__ dz_out, bf16_raw* __restrict__ dx_out,
+                                                           float* __restrict__ partials, int rows, float drop_p,
+                                                           uint32_t drop_thr, uint32_t drop_key,
+                                                           const uint32_t* __restrict__ salt) {
+  constexpr int H = NV * 256;
+  if (drop_p > 0.f) drop_key = bb_salted(drop_key, salt);
+  __shared__ float4 s_red[3][4][NV * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  float4 ag[NV], ab[NV], ax[NV];
+  float4 g[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    ag[i] = ab[i] = ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    g[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 d[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int col = (i * 64 + lane) * 4;
+      d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dy16 != nullptr) d[i] = ld4<bf16_raw>(dy16 + (size_t)row * H + col);
+      if (dy32 != nullptr) {
+        const float4 e = ld4<float>(dy32 + (size_t)row * H + col);
+        d[i].x += e.x; d[i].y += e.y; d[i].z += e.z; d[i].w += e.w;
+      }
+      const float4 zz = ld4<float>(z + (size_t)row * H + col);
+      xh[i] = make_float4((zz.x - mu) * rs, (zz.y - mu) * rs, (zz.z - mu) * rs, (zz.w - mu) * rs);
+      ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+      ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+      d[i].x *= g[i].x; d[i].y *= g[i].y; d[i].z *= g[i].z; d[i].w *= g[i].w;
+      s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+      s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+    }
+    s1 = wave_sum(s1) * (1.0f / H);
+    s2 = wave_sum(s2) * (1.0f / H);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int col = (i * 64 + lane) * 4;
+      float4 o;
+      o.x = rs * (d[i].x - s1 - xh[i].x * s2);
+      o.y = rs * (d[i].y - s1 - xh[i].y * s2);
+      o.z = rs * (d[i].z - s1 - xh[i].z * s2);
+      o.w = rs * (d[i].w - s1 - xh[i].w * s2);
+      if (dz_out != nullptr) st4<float>(dz_out + (size_t)row * H + col, o);
+      if (drop_p > 0.f) {
+        const uint32_t pr = ((uint32_t)row * H + col) >> 1;
+        const uint32_t b0 = bb_pair_bits(drop_key, pr), b1 = bb_pair_bits(drop_key, pr + 1);
+        o.x = bb_keep_lo(b0, drop_thr) ? o.x * keep_scale : 0.f;
+        o.y = bb_keep_hi(b0, drop_thr) ? o.y * keep_scale : 0.f;
+        o.z = bb_keep_lo(b1, drop_thr) ? o.z * keep_scale : 0.f;
+        o.w = bb_keep_hi(b1, drop_thr) ? o.w * keep_scale : 0.f;
+      }
+      if (dx_out != nullptr) st4<bf16_raw>(dx_out + (size_t)row * H + col, o);
+      ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    s_red[0][wave][i * 64 + lane] = ag[i];
+    s_red[1][wave][i * 64 + lane] = ab[i];
+    s_red[2][wave][i * 64 + lane] = ax[i];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 3 * NV * 64; k += 256) {
+    const int which = k / (NV * 64), j = k % (NV * 64);
+    float4 a = s_red[which][0][j];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 t = s_red[which][w][j];
+      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    *reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * 3 + which) * H + j * 4) = a;
+  }
+}
+
 // out_w[c] (+)= sum_b partials[b][w][c] for every w with a non-null output.  Block = 64 columns x 16 partial groups:
 // coalesced 256-B reads, 16 independent running sums per column, fixed combination order => deterministic.
 struct FinalizeOut { float* out[3]; };
@@ -829,6 +990,61 @@ static int layernorm_bwd_impl(const void* dy, const void* z, const float* mean, 
   BB_CHECK_LAUNCH("layernorm_bwd");
   if (dgamma || dbeta || dbias) launch_finalize(workspace, nb, 3, H, dgamma, dbeta, dbias, accumulate, stream);
   BB_CHECK_LAUNCH("layernorm_bwd finalize");
+  return BB_OK;
+}
+
+// bf16 activations around an fp32 residual stream (see ln_res32_*_kernel): residual_dtype BB_F32 / BB_BF16 (ignored when
+// residual is NULL); y32 / z32 may be NULL (inference: no backward, or a consumer that only wants the bf16 copy)
+BEVBERT_API int bevbert_layernorm_res32_fwd(const void* x, const float* bias, const void* residual, int residual_dtype,
+                                            const float* gamma, const float* beta, void* y16, float* y32, float* z32,
+                                            float* mean, float* rstd, int rows, int H, float eps, float drop_p,
+                                            uint64_t seed, uint64_t offset, hipStream_t stream) {
+  BB_REQUIRE(rows >= 0 && H % 256 == 0 && H / 256 <= 4, "layernorm_res32_fwd: H=%d must be 256, 512, 768 or 1024", H);
+  BB_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_res32_fwd: dropout p=%f", drop_p);
+  BB_REQUIRE(residual == nullptr || residual_dtype == BB_F32 || residual_dtype == BB_BF16, "layernorm_res32_fwd: residual dtype %d", residual_dtype);
+  if (rows == 0) return BB_OK;
+  const dim3 grid((rows + 3) / 4);
+  const uint32_t thr = bb_drop_threshold(drop_p);
+#define GO(TR, N)                                                                                                       \
+  hipLaunchKernelGGL((ln_res32_fwd_kernel<TR, N>), grid, dim3(256), 0, stream, (const bf16_raw*)x, bias, (const TR*)residual, \
+                     gamma, beta, (bf16_raw*)y16, y32, z32, mean, rstd, rows, eps, drop_p, thr, bb_site_key(seed, offset),   \
+                     bb_step_salt())
+#define SW(TR)                \
+  switch (H / 256) {          \
+    case 1: GO(TR, 1); break; \
+    case 2: GO(TR, 2); break; \
+    case 3: GO(TR, 3); break; \
+    default: GO(TR, 4); break; \
+  }
+  if (residual != nullptr && residual_dtype == BB_BF16) { SW(bf16_raw) } else { SW(float) }
+#undef SW
+#undef GO
+  BB_CHECK_LAUNCH("layernorm_res32_fwd");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_layernorm_res32_bwd(const void* dy16, const float* dy32, const float* z32, const float* mean,
+                                            const float* rstd, const float* gamma, float* dz32, void* dx16, float* dgamma,
+                                            float* dbeta, float* dbias, float* workspace, int rows, int H, float drop_p,
+                                            uint64_t seed, uint64_t offset, int accumulate, hipStream_t stream) {
+  BB_REQUIRE(H % 256 == 0 && H / 256 <= 4, "layernorm_res32_bwd: H=%d must be 256, 512, 768 or 1024", H);
+  BB_REQUIRE(dy16 != nullptr || dy32 != nullptr, "layernorm_res32_bwd: no output gradient");
+  if (rows <= 0) return BB_OK;
+  const int nb = partial_blocks(rows, 16);
+  const uint32_t thr = bb_drop_threshold(drop_p);
+#define GO(N)                                                                                                          \
+  hipLaunchKernelGGL((ln_res32_bwd_kernel<N>), dim3(nb), dim3(256), 0, stream, (const bf16_raw*)dy16, dy32, z32, mean, rstd, \
+                     gamma, dz32, (bf16_raw*)dx16, workspace, rows, drop_p, thr, bb_site_key(seed, offset), bb_step_salt())
+  switch (H / 256) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    default: GO(4); break;
+  }
+#undef GO
+  BB_CHECK_LAUNCH("layernorm_res32_bwd");
+  if (dgamma || dbeta || dbias) launch_finalize(workspace, nb, 3, H, dgamma, dbeta, dbias, accumulate, stream);
+  BB_CHECK_LAUNCH("layernorm_res32_bwd finalize");
   return BB_OK;
 }
 

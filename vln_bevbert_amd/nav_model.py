@@ -55,8 +55,8 @@ class GlocalTextPathNavCMT(nn.Module):
         """The call map_nav_src/models/vlnbert_init.py:78-81 makes; see vilmodel.from_pretrained."""
         return from_pretrained(cls, pretrained_model_name_or_path, config, state_dict)
 
-    def finalize(self, device, compute_dtype=torch.float32):
-        return finalize(self, device, compute_dtype)
+    def finalize(self, device, compute_dtype=torch.float32, residual=None):
+        return finalize(self, device, compute_dtype, residual)
 
     def forward_text(self, txt_ids, txt_masks):
         return self.lang_encoder(self.embeddings(txt_ids), txt_masks)

@@ -53,6 +53,9 @@ class _Runtime:
         self.seed = self.SEED
         self.offset = 0
         self.attn_impl = 0      # 0 auto, 1 exact kernels, 2 MFMA kernels
+        # bf16 mode with an fp32 RESIDUAL STREAM (finalize(..., residual=torch.float32)): the post-norm blocks keep their
+        # LayerNorm outputs and residual sums in fp32 next to the bf16 copy the GEMMs read -- torch.autocast's arithmetic
+        self.res32 = False
         self._ws = {}
         self._ws_ptr = {}
         self._salt = None
@@ -1087,10 +1090,84 @@ class _BiasDropResLN(torch.autograd.Function):
                 g1, g2, None)
 
 
+class _BiasDropResLN32(torch.autograd.Function):
+    """LayerNorm(dropout(x + bias) + residual) with the fp32 residual stream of ``RT.res32``: x bf16 (a GEMM output),
+    residual fp32 (the previous block's ``y32``) or bf16 (where a stream starts); returns (y16, y32).  The backward sums the
+    two output gradients in the kernel (bf16 from the GEMMs that read y16, fp32 from the residual add that read y32) and
+    returns dz in fp32 to an fp32 residual."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, gamma, beta, eps, drop_p):
+        assert x.is_contiguous() and x.dtype == torch.bfloat16 and x.dim() >= 2
+        H = x.shape[-1]
+        rows = x.numel() // H
+        need_grad = any(ctx.needs_input_grad)
+        y16 = torch.empty_like(x)
+        y32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        z32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_grad else None
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need_grad else None
+        off = RT.next_offset(x.numel()) if drop_p > 0 else 0
+        assert residual.is_contiguous() and residual.shape == x.shape and residual.dtype in (torch.float32, torch.bfloat16)
+        call("bevbert_layernorm_res32_fwd", ptr(x), ptr(_f32(bias)) if bias is not None else None, ptr(residual),
+             dtype_code(residual), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(y16), ptr(y32), ptr(z32), ptr(mean), ptr(rstd),
+             rows, H, float(eps), float(drop_p), RT.seed, off, stream())
+        ctx.save_for_backward(z32, mean, rstd)
+        ctx.params = (bias, gamma, beta)
+        ctx.cfg = (rows, H, float(drop_p), RT.seed, off, residual.dtype)
+        return y16, y32
+
+    @staticmethod
+    def backward(ctx, dy16, dy32):
+        z32, mean, rstd = ctx.saved_tensors
+        bias, gamma, beta = ctx.params
+        rows, H, drop_p, seed, off, res_dtype = ctx.cfg
+        dev = z32.device
+        if dy16 is None and dy32 is None:
+            dy32 = torch.zeros_like(z32)
+        dy16 = dy16.contiguous() if dy16 is not None else None
+        dy32 = dy32.contiguous() if dy32 is not None else None
+        dz32 = torch.empty_like(z32)
+        dx16 = torch.empty(z32.shape, dtype=torch.bfloat16, device=dev)
+        outs = []
+        for p in (gamma, beta, bias):
+            if p is None:
+                outs.append((None, None, 0))
+            elif p is bias and not getattr(p, "requires_grad", True):
+                outs.append((None, None, None))
+            elif _sink(p) is not None:
+                outs.append((_sink(p), None, 1))
+                _mark_touched(p)
+            else:
+                t = torch.empty(H, dtype=torch.float32, device=dev)
+                outs.append((t, t, 0))
+        (dg, rg, ag), (db, rb, ab), (dbi, rbi, abi) = outs
+        assert ag == ab and (bias is None or abi is None or abi == ag), "mixed arena / plain parameters in one LayerNorm"
+        if ag == 1 and WgradStream.DEFER_FINALIZE and dev.type == "cuda":
+            nb = _partial_rows(rows)
+            part = SCRATCH.alloc(nb * 3 * H * 4, dev)
+            call("bevbert_layernorm_res32_bwd", ptr(dy16), ptr(dy32), ptr(z32), ptr(mean), ptr(rstd), ptr(_f32(gamma)),
+                 ptr(dz32), ptr(dx16), None, None, None, part, rows, H, drop_p, seed, off, 1, stream())
+            ReduceQueue.add(part, nb, 3, H, (ptr(dg), ptr(db), ptr(dbi)))
+        else:
+            ws = RT.workspace(dev, lib.load().bevbert_colsum_workspace_floats(3 * H))
+            call("bevbert_layernorm_res32_bwd", ptr(dy16), ptr(dy32), ptr(z32), ptr(mean), ptr(rstd), ptr(_f32(gamma)),
+                 ptr(dz32), ptr(dx16), ptr(dg), ptr(db), ptr(dbi), ptr(ws), rows, H, drop_p, seed, off, ag, stream())
+        cast = lambda r, p: None if r is None else r.to(p.dtype)
+        gres = dz32 if res_dtype == torch.float32 else dz32.to(torch.bfloat16)      # (a bf16 residual: where a stream starts)
+        return dx16, cast(rbi, bias) if bias is not None else None, gres, cast(rg, gamma), cast(rb, beta), None, None
+
+
 def bias_dropout_residual_layernorm(x, bias, residual, gamma, beta, eps, drop_p=0.0, training=False,
                                     inplace_z=True):
     """LayerNorm(dropout(x + bias) + residual)  -- vilmodel.py:150-154,189-193."""
     p = float(drop_p) if training else 0.0
+    if RT.res32 and residual is not None and x.dtype == torch.bfloat16 and x.is_cuda:
+        # fp32 residual stream: the previous block left its fp32 output on the bf16 tensor the model passes around
+        r32 = getattr(residual, "_res32", None)
+        y16, y32 = _BiasDropResLN32.apply(x, bias, r32 if r32 is not None else residual, gamma, beta, eps, p)
+        y16._res32 = y32
+        return y16
     return _BiasDropResLN.apply(x, bias, residual, gamma, beta, eps, p, inplace_z, None, None)
 
 
@@ -1351,7 +1428,8 @@ def linear(x, weight, bias=None, w_c=None, b_c=None):
 def linear_res(x, weight, bias=None):
     """(linear(x), x) for an input that also feeds a residual connection: use the SECOND output as the residual and
     the gradient of the residual branch is folded into this layer's input-gradient GEMM (see _Linear.forward)."""
-    if not (x.requires_grad and torch.is_grad_enabled()):
+    if not (x.requires_grad and torch.is_grad_enabled()) or getattr(x, "_res32", None) is not None:
+        # (fp32 residual stream: the residual is x's fp32 twin, its gradient joins x's inside the LayerNorm backward kernel)
         return linear(x, weight, bias), x
     return _Linear.apply(x, weight, bias, _compute(weight), None if bias is None else _compute(bias), True)
 
@@ -1479,7 +1557,7 @@ def hoisted_kv(context, pw, pb, n_layers):
 
 def linear_packed_res(x, pw, pb):
     """(packed projection of x, x as residual tap) -- see linear_res."""
-    if not (x.requires_grad and torch.is_grad_enabled()):
+    if not (x.requires_grad and torch.is_grad_enabled()) or getattr(x, "_res32", None) is not None:
         return _LinearPacked.apply(x, pw, pb), x
     return _LinearPacked.apply(x, pw, pb, True)
 

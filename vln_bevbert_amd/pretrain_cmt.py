@@ -154,9 +154,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         """The call train_r2r.py:153-155 makes; see vilmodel.from_pretrained."""
         return from_pretrained(cls, pretrained_model_name_or_path, config, state_dict)
 
-    def finalize(self, device, compute_dtype=torch.float32):
+    def finalize(self, device, compute_dtype=torch.float32, residual=None):
         """Place parameters in the flat arena on ``device`` (fp32 masters + optional bf16 compute copy)."""
-        return finalize(self, device, compute_dtype)
+        return finalize(self, device, compute_dtype, residual)
 
     feat_dropout = property(lambda self: self.drop_env.p, lambda self, v: setattr(self.drop_env, "p", v))
 

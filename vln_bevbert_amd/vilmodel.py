@@ -994,10 +994,16 @@ def ensure_arena(module):
     return arena
 
 
-def finalize(module, device, compute_dtype=torch.float32):
-    """Move a freshly built / loaded model into a ParamArena on ``device`` and cache the packed views."""
+def finalize(module, device, compute_dtype=torch.float32, residual=None):
+    """Move a freshly built / loaded model into a ParamArena on ``device`` and cache the packed views.
+    ``residual=torch.float32`` with bf16 compute: the post-norm blocks keep LayerNorm outputs and residual sums in fp32
+    (torch.autocast's arithmetic, pretrain_src/train_r2r.py:256-258) -- a process-wide switch of the kernel library's
+    Python layer (ops.RT.res32), like the attention implementation."""
     if compute_dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("compute dtype must be float32 or bfloat16")
+    if residual not in (None, torch.float32, torch.bfloat16) or (residual == torch.bfloat16 and compute_dtype != torch.bfloat16):
+        raise ValueError("residual stream dtype must be None (= compute dtype), float32, or bfloat16 with bf16 compute")
+    ops.RT.res32 = compute_dtype == torch.bfloat16 and residual == torch.float32
     for b in module.buffers():
         b.data = b.data.to(device)
     arena = ParamArena(module, device, compute_dtype, groups=arena_groups(module))
