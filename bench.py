@@ -84,8 +84,9 @@ def parse():
     ap.add_argument("--ragged", action="store_true",
                     help="sustained block on ragged batches (T in [1,7], text length in [L/2, L], 36..38 views): many shape "
                          "buckets, reports buckets / captures / eager steps")
-    ap.add_argument("--sustained-ragged", action="store_true",
-                    help="a SECOND sustained block ('sustained_ragged') on ragged batches, next to the fixed-shape one")
+    ap.add_argument("--sustained-ragged", action=argparse.BooleanOptionalAction, default=True,
+                    help="a SECOND sustained block ('sustained_ragged') on ragged batches, next to the fixed-shape one "
+                         "(one GPU, in a child process; --no-sustained-ragged skips it)")
     ap.add_argument("--txt-len-min", type=int, default=0,
                     help="shortest instruction of the ragged sustained run (default: half of --txt-len)")
     ap.add_argument("--ship-grid", action="store_true",

@@ -18,7 +18,7 @@ ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 
 MARK = os.environ.get("ROWOPS_MARK") == "1"      # PMC passes: a marker launch (bevbert_cast_f32 over 65 536 (idx + 1) elements)
 _mark_idx = [0]                                   # in front of every record, so that the counter rows between two markers
-_mark_src = None                                  # can be attributed to one record (scripts/gpu_r5_pmc.sh)
+_mark_src = None                                  # can be attributed to one record (scripts/gpu_pmc_all.sh)
 
 
 def _marker():

@@ -1,11 +1,11 @@
 #!/bin/bash
-# round 5: the fp32 MFMA attention (attn_f32.hip): parity tests of the attention entry, then timings against the
-# wave-per-row kernels (BEVBERT_ATTN_F32=simple) at the step's shapes.  usage: gpu_r5_f32.sh <tag>
+# the fp32 MFMA attention (attn_f32.hip): parity tests of the attention entry, then timings against the
+# wave-per-row kernels (BEVBERT_ATTN_F32=simple) at the step's shapes.  usage: gpu_attn_f32.sh <tag>
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"; mkdir -p gpurun_out
 T=${1:-a}
-O=gpurun_out/r05${T}
+O=gpurun_out/${T}
 timeout 900 python -m pytest tests/test_gpu_kernels.py -q -x -k "attention" 2>&1 | tail -5 > ${O}_f32_attn_tests.log; tail -3 ${O}_f32_attn_tests.log
 python - > ${O}_f32_attention_timings.jsonl <<'PY'
 import json, math, os, subprocess, sys

@@ -1,11 +1,11 @@
 #!/bin/bash
-# round 5: quick check of an attention kernel edit -- parity tests of the attention entry, then timings of the big shape
-# usage: gpu_r5_quick.sh <tag> ["env assignments" ...]   each extra argument is one A/B arm, e.g. "BEVBERT_B2_VAR=0"
+# quick check of an attention kernel edit -- parity tests of the attention entry, then timings of the big shape
+# usage: gpu_attn_quick.sh <tag> ["env assignments" ...]   each extra argument is one A/B arm, e.g. "BEVBERT_ATTN_BWD3=0"
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"; mkdir -p gpurun_out
 T=${1:-q}; shift || true
-O=gpurun_out/r05${T}
+O=gpurun_out/${T}
 timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "attention" 2>&1 | tail -4 > ${O}_attn_tests.log; tail -2 ${O}_attn_tests.log
 : > ${O}_attn.jsonl
 for ARM in "" "$@"; do

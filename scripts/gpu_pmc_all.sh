@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, SEPARATE passes, kernel trace only) of
+# HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, SEPARATE passes, kernel trace only) of
 #   (a) the attention kernels at the BEV self-attention shape (scripts/bench_attn_shape.py 64 441 441 0.1), and
 #   (b) every HBM-bound hand-written kernel at its step size (scripts/bench_rowops.py with marker launches between records),
 # joined with the algorithmic bytes of each record -> gpurun_out/r05<tag>_pmc_traffic.json (ratio traffic / algorithmic).
@@ -7,7 +7,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 T=${1:-a}
-OUT=$ROOT/gpurun_out/pmc_r05$T
+OUT=$ROOT/gpurun_out/pmc_$T
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -20,10 +20,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   find "$OUT/row_$C" -name '*counter_collection*' -exec cp {} "$OUT/row_${C}.csv" \;
   rm -rf "$OUT/row_$C"
 done
-python3 - "$OUT" "$ROOT/gpurun_out/r05${T}_pmc_traffic.json" <<'PY'
+python3 - "$OUT" "$ROOT/gpurun_out/${T}_pmc_traffic.json" <<'PY'
 import csv, sys, os, collections, json
 d, dst = sys.argv[1], sys.argv[2]
-out = {"_source": "scripts/gpu_r5_pmc.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes); bytes per launch = "
+out = {"_source": "scripts/gpu_pmc_all.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes); bytes per launch = "
                   "(2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950 wide-read correction); algorithmic = the record's byte count"}
 # (a) attention: per kernel symbol
 att = collections.defaultdict(dict)
