@@ -494,7 +494,10 @@ def main():
             """roofline of one C-ABI entry: quoted for its heaviest shape (one problem size = one row of the rocprofv3
             per-shape summary under profiles/), plus the entry over ALL its shapes of the profiled steps (entry_frac: total
             algorithmic work / total time; the short-sequence launches run far below the heaviest shape)"""
-            key, top = max(((k, r) for k, r in rows.items() if k.split("[")[0] == entry), key=lambda kv: kv[1]["ms"])
+            cand = [(k, r) for k, r in rows.items() if k.split("[")[0] == entry]
+            # heaviest shape = most algorithmic work per launch (the 441 x 441 problem of the attention entries; by total
+            # time the many short text launches of the forward would win)
+            key, top = max(cand, key=lambda kv: (max(kv[1]["gflop"], kv[1]["mb"] * 1e-3) / max(kv[1]["launches"], 1), kv[1]["ms"]))
             traffic = traffic_source = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
             for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:

@@ -24,7 +24,7 @@ except Exception as e:
     print("no bench line in", sys.argv[1], e); sys.exit(0)
 r = d.get("roofline", {})
 print({k: d.get(k) for k in ("value", "ms_per_step", "dtype")}, r.get("kernel"), r.get("frac"),
-      "bwd", (d.get("roofline_bwd") or {}).get("frac"), "fwd", (d.get("roofline_fwd") or {}).get("frac"),
+      "bwd", (d.get("roofline_attn_bwd") or {}).get("frac"), "fwd", (d.get("roofline_attn_fwd") or {}).get("frac"),
       "sustained", (d.get("sustained") or {}).get("vs_resident"), "ragged", (d.get("sustained_ragged") or {}).get("vs_resident"),
       "cpu", (d.get("cpu_baseline") or {}).get("value"))
 for k, v in (d.get("side_configs") or {}).items():
@@ -36,7 +36,7 @@ for P in $PARTS; do
   case $P in
     tests)
       rm -f gpurun_out/bf16_errors.jsonl
-      timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -25 > ${O}_gputests.log; tail -3 ${O}_gputests.log
+      timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -25 > ${O}_gputests.log; tail -3 ${O}_gputests.log
       cp gpurun_out/bf16_errors.jsonl ${O}_bf16_errors.jsonl 2>/dev/null ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 > ${O}_smoke.log; tail -1 ${O}_smoke.log ;;

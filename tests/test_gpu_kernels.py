@@ -629,7 +629,7 @@ def test_attention_keep_bit_workspace_holds_the_exported_mask_in_both_layouts(op
     keep = ops.dropout_keep_mask(B * nh * Lq * Lk2, p, ops.RT.seed, 5, DEV).view(B * nh, Lq, Lk2).cpu().numpy()
     nq16, nk64 = (Lq + 127) // 128 * 8, (Lk + 63) // 64
     half = B * nh * nq16 * nk64 * 16
-    assert bits.shape[0] == 2 * half
+    assert bits.shape[0] == 3 * half
     lanes = np.arange(64)
     f = bits[:half].reshape(B * nh, nq16, nk64, 4, 4)
     q = np.arange(nq16)[:, None, None, None, None] * 16 + (lanes & 15)
@@ -642,7 +642,7 @@ def test_attention_keep_bit_workspace_holds_the_exported_mask_in_both_layouts(op
     assert np.array_equal(got[:, ok], want[:, ok]), "forward layout"
     if not 256 < Lk <= 448:          # the backward layout is only produced for the shapes the 7+1-wave backward takes
         return
-    bw = bits[half:].reshape(B * nh, nq16 // 2, nk64, 2, 4, 4)                           # (bh, q32, k64, tt, t, r)
+    bw = bits[half:2 * half].reshape(B * nh, nq16 // 2, nk64, 2, 4, 4)                   # (bh, q32, k64, tt, t, r)
     q = (np.arange(nq16 // 2)[:, None, None, None, None, None] * 32 + np.arange(2)[None, None, :, None, None, None] * 16
          + (lanes >> 4) * 4 + np.arange(4)[None, None, None, None, :, None])
     k = (np.arange(nk64)[None, :, None, None, None, None] * 64 + np.arange(4)[None, None, None, :, None, None] * 16
@@ -652,6 +652,19 @@ def test_attention_keep_bit_workspace_holds_the_exported_mask_in_both_layouts(op
     qq, kk = np.broadcast_arrays(np.minimum(q, Lq - 1), np.minimum(k, Lk - 1))
     want = keep[:, qq, kk]
     assert np.array_equal(got[:, ok], want[:, ok]), "backward layout"
+    # per-lane layout of the one-workgroup-per-head forward: 32-bit word (bh, q64, k64, half, lane), element e = 8 qt + 4 tt + r
+    # = keep(q = 64 q64 + 16 qt + (lane & 15), key = 64 k64 + 32 half + 16 tt + 4 (lane >> 4) + r) at bit (e >> 1) + 16 (e & 1)
+    lw = bits[2 * half:].view(np.uint32).reshape(B * nh, nq16 // 4, nk64, 2, 64)
+    e = np.arange(32)
+    got = ((lw[..., None] >> ((e >> 1) + 16 * (e & 1)).astype(np.uint32)) & np.uint32(1)).astype(bool)   # (bh, q64, k64, half, lane, e)
+    qt, tt, r = e >> 3, (e >> 2) & 1, e & 3
+    q = np.arange(nq16 // 4)[:, None, None, None, None] * 64 + qt * 16 + (lanes & 15)[:, None]
+    k = (np.arange(nk64)[None, :, None, None, None] * 64 + np.arange(2)[None, None, :, None, None] * 32 + tt * 16
+         + (lanes >> 4)[:, None] * 4 + r)
+    q, k = np.broadcast_arrays(q, k)
+    ok = (q < Lq) & (k < Lk)
+    want = keep[:, np.minimum(q, Lq - 1), np.minimum(k, Lk - 1)]
+    assert np.array_equal(got[:, ok], want[:, ok]), "per-lane layout"
 
 
 def test_attention_packed_layouts(ops):

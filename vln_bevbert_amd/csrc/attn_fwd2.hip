@@ -500,14 +500,20 @@ template <int LANE0> __device__ __forceinline__ void put_words4(uint32_t& lo, ui
 }
 
 template <bool WITH_B>
-__global__ __launch_bounds__(256) void attn_drop_bits_kernel(AttnArgs a, uint64_t* bits_f, uint64_t* bits_b) {
+__global__ __launch_bounds__(256) void attn_drop_bits_kernel(AttnArgs a, uint64_t* bits_f, uint64_t* bits_b, uint32_t* bits_l) {
+  constexpr int NQT = WITH_B ? 4 : 1;            // 16-query tiles per task: the L words span the 64 queries of a fwd4 wave
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const uint32_t key = bb_salted(a.drop_key, a.salt);
   const uint32_t thr_hi = a.drop_thr << 16;      // (bits >> 16) >= thr  <=>  bits >= thr << 16;  low field: shift it up first
-  const int per_bh = a.nq16 * a.nk64, total = a.B * a.nh * per_bh;
-  for (int task = wave; task < total; task += nwaves) {
-    const int bh = task / per_bh, rem = task - bh * per_bh, q16 = rem / a.nk64, k64 = rem - q16 * a.nk64;
+  const int nqg = a.nq16 / NQT, per_bh = nqg * a.nk64, total = a.B * a.nh * per_bh;
+  for (int gtask = wave; gtask < total; gtask += nwaves) {
+    const int bh = gtask / per_bh, rem = gtask - bh * per_bh, qg = rem / a.nk64, k64 = rem - qg * a.nk64;
+    uint32_t wl0 = 0, wl1 = 0;                   // L layout: this lane's elements of the two 32-key halves
+#pragma unroll 1
+   for (int qt = 0; qt < NQT; ++qt) {
+    const int q16 = qg * NQT + qt;
+    const int task = (bh * a.nq16 + q16) * a.nk64 + k64;
     const int q = q16 * 16 + c;
     const uint32_t rbase = (uint32_t)(((uint32_t)bh * a.Lq + (q < a.Lq ? q : a.Lq - 1)) * (uint32_t)a.Lk2);
     uint32_t mine = 0;                   // bit (4 t + r) = keep of (q, key 64 k64 + 16 t + 4 g + r)       (WITH_B only)
@@ -548,18 +554,35 @@ __global__ __launch_bounds__(256) void attn_drop_bits_kernel(AttnArgs a, uint64_
         const size_t wi = ((((size_t)bh * (a.nq16 >> 1) + (q16 >> 1)) * a.nk64 + k64) * 2 + (q16 & 1)) * 16 + t * 4 + rp;
         bits_b[wi] = ((uint64_t)bhi << 32) | blo;
       }
+      // even / odd elements of the 16 (t, r) bits compressed to 8 bits each: bits 0..3 = pairs of the first 32-key half, 4..7 = second
+      uint32_t ev = mine & 0x5555u, od = (mine >> 1) & 0x5555u;
+      ev = (ev | (ev >> 1)) & 0x3333u; od = (od | (od >> 1)) & 0x3333u;
+      ev = (ev | (ev >> 2)) & 0x0f0fu; od = (od | (od >> 2)) & 0x0f0fu;
+      ev = (ev | (ev >> 4)) & 0x00ffu; od = (od | (od >> 4)) & 0x00ffu;
+      wl0 |= ((ev & 15u) | ((od & 15u) << 16)) << (4 * qt);
+      wl1 |= ((ev >> 4) | ((od >> 4) << 16)) << (4 * qt);
+    }
+   }
+    // L layout (attn_fwd4.hip): word (bh, q64, k64, half, lane); element e = 8 qt + 4 tt + r, i.e. keep(q = 64 q64 + 16 qt +
+    // (lane & 15), key = 64 k64 + 32 half + 16 tt + 4 (lane >> 4) + r), at bit (e >> 1) + 16 (e & 1): the reader turns the
+    // two halves into the AND mask of a packed bf16 pair with two packed 16-bit shifts
+    if (WITH_B) {
+      uint32_t* dst = bits_l + (((size_t)bh * nqg + qg) * a.nk64 + k64) * 128 + lane;
+      dst[0] = wl0;
+      dst[64] = wl1;
     }
   }
 }
 
-int attn_drop_bits(const AttnArgs& a, uint64_t* bits_f, uint64_t* bits_b, hipStream_t st) {
-  const int total = a.B * a.nh * a.nq16 * a.nk64;
+int attn_drop_bits(const AttnArgs& a, uint64_t* bits_f, uint64_t* bits_b, uint32_t* bits_l, hipStream_t st) {
+  // the backward layout is only read by the 7+1-wave backward (attn_bwd3.hip: 256 < Lk <= 448, no bias), the per-lane
+  // layout by the one-workgroup-per-head forward (attn_fwd4.hip, same key range): both are written for that key range
+  const bool with_b = bits_b != nullptr && bits_l != nullptr && a.bias == nullptr && a.Lk > 256 && a.Lk <= 448;
+  const int total = a.B * a.nh * (with_b ? a.nq16 / 4 : a.nq16) * a.nk64;
   int nb = (total + 3) / 4;
   if (nb > 8192) nb = 8192;
-  // the backward layout is only read by the 7+1-wave backward (attn_bwd2.hip: 256 < Lk <= 448, no bias)
-  const bool with_b = bits_b != nullptr && a.bias == nullptr && a.Lk > 256 && a.Lk <= 448;
-  if (with_b) hipLaunchKernelGGL(attn_drop_bits_kernel<true>, dim3(nb), dim3(256), 0, st, a, bits_f, bits_b);
-  else hipLaunchKernelGGL(attn_drop_bits_kernel<false>, dim3(nb), dim3(256), 0, st, a, bits_f, bits_b);
+  if (with_b) hipLaunchKernelGGL(attn_drop_bits_kernel<true>, dim3(nb), dim3(256), 0, st, a, bits_f, bits_b, bits_l);
+  else hipLaunchKernelGGL(attn_drop_bits_kernel<false>, dim3(nb), dim3(256), 0, st, a, bits_f, bits_b, bits_l);
   BB_CHECK_LAUNCH("attn_drop_bits");
   return BB_OK;
 }

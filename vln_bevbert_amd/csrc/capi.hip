@@ -43,7 +43,9 @@ int attn_mfma_bwd1(const AttnArgs& a, hipStream_t st);
 bool attn_mfma_bwd1_supported(const AttnArgs& a);
 int attn_fwd2(const AttnArgs& a, hipStream_t st);
 bool attn_fwd2_supported(const AttnArgs& a);
-int attn_drop_bits(const AttnArgs& a, uint64_t* bits_f, uint64_t* bits_b, hipStream_t st);
+int attn_drop_bits(const AttnArgs& a, uint64_t* bits_f, uint64_t* bits_b, uint32_t* bits_l, hipStream_t st);
+int attn_fwd4(const AttnArgs& a, const uint32_t* bits_l, hipStream_t st);
+bool attn_fwd4_supported(const AttnArgs& a, const uint32_t* bits_l);
 int attn_bwd2(const AttnArgs& a, hipStream_t st);
 bool attn_bwd2_supported(const AttnArgs& a);
 int attn_bwd3(const AttnArgs& a, hipStream_t st);
@@ -58,7 +60,8 @@ bool attn_small_bwd_supported(const AttnArgs& a);
 int attn_small_bwd2(const AttnArgs& a, hipStream_t st);
 bool attn_small_bwd2_supported(const AttnArgs& a);
 
-// The keep-bit workspace of a call holds the matrix twice: [forward layout | backward layout], see attn_fwd2.hip
+// The keep-bit workspace of a call holds the matrix three times: [forward layout | backward layout | per-lane layout of
+// attn_fwd4.hip], see attn_fwd2.hip
 static int64_t bits_words_one(int B, int nh, int Lq, int Lk) {
   return (int64_t)B * nh * ((Lq + 127) / 128 * 8) * ((Lk + 63) / 64) * 16;
 }
@@ -126,10 +129,12 @@ BEVBERT_API int bevbert_attn_fwd(const void* q, const void* k, const void* v, vo
     const bool small = drop_p > 0.f && (int64_t)Lq * Lk < 32768 && Lk <= 256 && !bits_ready;   // (Lk > 256: the 7+1-wave
     // backward wants the backward-layout bits, which only bevbert_attn_drop_bits writes)
     if (!gen1 && !small && attn_fwd2_supported(a)) {
+      uint32_t* bits_l = drop_bits ? reinterpret_cast<uint32_t*>(drop_bits + 2 * bits_words_one(B, nh, Lq, Lk)) : nullptr;
       if (drop_p > 0.f && !bits_ready) {
-        rc = attn_drop_bits(a, a.drop_bits, a.drop_bits_b, stream);
+        rc = attn_drop_bits(a, a.drop_bits, a.drop_bits_b, bits_l, stream);
         if (rc != BB_OK) return rc;
       }
+      if (attn_fwd4_supported(a, bits_l)) return attn_fwd4(a, bits_l, stream);
       return attn_fwd2(a, stream);
     }
     return attn_mfma_fwd(a, stream);
@@ -188,7 +193,7 @@ __global__ void keep_mask_kernel(uint8_t* out, size_t n, uint32_t key, uint32_t 
 }
 // Size of the keep-bit matrix of an attention call (64-bit words), see attn_common.h.
 BEVBERT_API int64_t bevbert_attn_drop_bits_words(int B, int nh, int Lq, int Lk) {
-  return 2 * bits_words_one(B, nh, Lq, Lk);
+  return 3 * bits_words_one(B, nh, Lq, Lk);
 }
 
 // Fill the keep-bit workspace of one attention call ahead of its forward (any stream: the mask is a pure function of
@@ -200,7 +205,8 @@ BEVBERT_API int bevbert_attn_drop_bits(uint64_t* drop_bits, int B, int nh, int L
   const int64_t st[8] = {64, 64, 64, 64, 64, 64, 64, 64};
   int rc = fill_common(a, nullptr, nullptr, nullptr, nullptr, nullptr, st, B, nh, Lq, Lk, ATTN_D, 1.f, drop_p, seed, offset);
   if (rc != BB_OK) return rc;
-  return attn_drop_bits(a, drop_bits, drop_bits + bits_words_one(B, nh, Lq, Lk), stream);
+  const int64_t one = bits_words_one(B, nh, Lq, Lk);
+  return attn_drop_bits(a, drop_bits, drop_bits + one, reinterpret_cast<uint32_t*>(drop_bits + 2 * one), stream);
 }
 
 BEVBERT_API int bevbert_dropout_keep_mask(uint8_t* out, int64_t n, float drop_p, uint64_t seed, uint64_t offset,

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbevbert_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_f32.hip", "attn_mfma.hip", "attn_bwd1.hip", "attn_fwd2.hip", "attn_bwd2.hip", "attn_bwd3.hip", "attn_small.hip", "sap_loss.hip", "graph_nav.hip", "gemm.hip", "capi.hip"]
+SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_f32.hip", "attn_mfma.hip", "attn_bwd1.hip", "attn_fwd2.hip", "attn_fwd4.hip", "attn_bwd2.hip", "attn_bwd3.hip", "attn_small.hip", "sap_loss.hip", "graph_nav.hip", "gemm.hip", "capi.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bevbert_hip.h")
 
 F32, BF16, F16 = 0, 1, 2
