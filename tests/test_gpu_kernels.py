@@ -571,6 +571,42 @@ def test_attention_short_key_kernels_with_dropout(ops, Lq, Lk, mk, small_fwd, mo
         assert rel_err(a, b_) < 3e-2, (name, rel_err(a, b_))
 
 
+@pytest.mark.parametrize("B,Lq,Lk,mk,p,wgs", [(2, 441, 441, None, 0.1, "5"), (2, 441, 441, "neg", 0.0, "24"), (1, 300, 290, "inf", 0.1, "3"),
+                                             (3, 500, 448, "neg", 0.1, "7"), (2, 257, 385, None, 0.1, "1")])
+def test_attention_persistent_forward_of_the_long_shapes(ops, B, Lq, Lk, mk, p, wgs, monkeypatch):
+    """attn_fwd4.hip (no bias, 256 < Lk <= 448, Lq > 256): one workgroup per CU walking (batch, head, 448-query block) items,
+    a producer wave streaming the K / V tiles across item boundaries, keep bits in the per-lane layout.  Forced on for small
+    batches (the launcher takes it only when the items fill at least two rounds of CUs) with a grid of `wgs` workgroups, so
+    that a workgroup walks several items (uneven counts included) and more than one query block per head (Lq = 500);
+    against the fp32 reference under the exported mask AND against the 4-wave kernel on the same inputs."""
+    dtype = torch.bfloat16
+    q, k, v, km, _, nh = _make_attn_inputs(B, Lq, Lk, mk, False, dtype, seed=Lq + Lk)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BEVBERT_ATTN_FWD4", mode)
+        monkeypatch.setenv("BEVBERT_FWD4_WGS", wgs)
+        ops.RT.new_step(4321 + Lk)
+        qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
+        o = ops._Attention.apply("sep", qi, ki, vi, km, None, nh, p, 2)
+        do = torch.randn(o.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).to(dtype)
+        o.backward(do)
+        outs[mode] = (o.detach().float(), qi.grad.float(), ki.grad.float(), vi.grad.float())
+    Lk2 = (Lk + 1) // 2 * 2
+    keep = None
+    if p > 0:
+        keep = ops.dropout_keep_mask(B * nh * Lq * Lk2, p, ops.RT.seed, 0, DEV).view(B, nh, Lq, Lk2)[..., :Lk]
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    orf = _attn_ref(qr, kr, vr, km, None, nh, keep, p)
+    scale = max(1.0, float(orf.abs().max()))
+    assert bool(torch.isfinite(outs["1"][0]).all())
+    assert float((outs["1"][0] - orf).abs().max()) < 1.5e-2 * scale
+    # same products in the same order as the 4-wave kernel; only the row sums are accumulated in a different order
+    assert float((outs["1"][0] - outs["0"][0]).abs().max()) < 2 ** -7 * scale
+    orf.backward(do.float())
+    for name, a, b_ in zip(("dq", "dk", "dv"), outs["1"][1:], (qr.grad, kr.grad, vr.grad)):
+        assert rel_err(a, b_) < 3e-2, (name, rel_err(a, b_))       # the backward reads the log-sum-exp this forward wrote
+
+
 @pytest.mark.parametrize("Lk", [140, 441, 36])
 @pytest.mark.parametrize("impl,dtype", [(1, torch.float32), (2, torch.bfloat16), (3, torch.bfloat16)])
 def test_attention_dropout_matches_exported_mask(ops, impl, dtype, Lk):

@@ -358,20 +358,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd4_kernel(AttnArgs a, const uin
 // =============================================================================================
 // launcher
 // =============================================================================================
+static int f4_workgroups() {
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const char* v = getenv("BEVBERT_FWD4_WGS");        // read per call: tests walk several items per workgroup on small batches
+  return (v && atoi(v) > 0) ? atoi(v) : ncu;
+}
+
 template <bool D_, int A_ = 0>
 static int launch_fwd4(const AttnArgs& a_in, const uint32_t* bits_l, hipStream_t st) {
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd4_kernel<D_, A_>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, F4Lds::bytes) == hipSuccess;
   BB_REQUIRE(ok, "attention fwd (gen 4): cannot raise the dynamic LDS limit to %d bytes", F4Lds::bytes);
   // one workgroup per CU (its LDS fills the CU), each walking items blockIdx.x, blockIdx.x + gridDim.x, ...
-  static const int ncu = [] {
-    int dev = 0, n = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    const char* v = getenv("BEVBERT_FWD4_WGS");      // A/B measurements
-    if (v && atoi(v) > 0) n = atoi(v);
-    return n > 0 ? n : 256;
-  }();
+  const int ncu = f4_workgroups();
   AttnArgs a = a_in;
   a.nblk = (a.Lq + F4_NQ - 1) / F4_NQ;
   const int nitems = a.nblk * a.nh * a.B;
@@ -401,9 +405,19 @@ static int launch_fwd4(const AttnArgs& a_in, const uint32_t* bits_l, hipStream_t
 }
 
 // BEVBERT_ATTN_FWD4=0: these shapes go to the 4-wave kernels of attn_fwd2.hip (A/B measurements, on-GPU cross-check)
+// An item fills a CU, so the kernel pays for whole rounds of items: it takes the call when the rounds are at least 85 % full
+// and there are at least two of them (B = 64 x 12 heads = 768 items = 3.0 rounds of 256 CUs: 78.7 against 89.1 us; B = 32:
+// 1.5 rounds, 51.4 against 47.8 us for the 4-wave kernel with its four workgroups per CU; B = 16: 28.6 against 28.0 us).
+// BEVBERT_ATTN_FWD4=1 forces it for every supported shape (tests), =0 switches it off.
 bool attn_fwd4_supported(const AttnArgs& a, const uint32_t* bits_l) {
-  static const bool on = [] { const char* v = getenv("BEVBERT_ATTN_FWD4"); return !(v && v[0] == '0'); }();
-  return on && a.bias == nullptr && a.Lk > 256 && a.Lk <= F4_NK && a.Lq > 256 && (a.drop_p <= 0.f || bits_l != nullptr);
+  const char* env = getenv("BEVBERT_ATTN_FWD4");      // read per call
+  const int mode = env ? atoi(env) : -1;
+  if (mode == 0) return false;
+  if (!(a.bias == nullptr && a.Lk > 256 && a.Lk <= F4_NK && a.Lq > 256 && (a.drop_p <= 0.f || bits_l != nullptr))) return false;
+  if (mode == 1) return true;
+  const int nitems = (a.Lq + F4_NQ - 1) / F4_NQ * a.nh * a.B, ncu = f4_workgroups();
+  const int rounds = (nitems + ncu - 1) / ncu;
+  return rounds >= 2 && nitems * 100 >= rounds * ncu * 85;
 }
 
 int attn_fwd4(const AttnArgs& a, const uint32_t* bits_l, hipStream_t st) {
