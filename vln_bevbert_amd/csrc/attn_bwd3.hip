@@ -1,6 +1,6 @@
 // K2 backward in one pass, third generation (bf16 in / fp32 accumulate): the 7 + 1-wave workgroup of attn_bwd2.hip
 // (7 key waves own 64 keys each, dK^T / dV^T in registers; wave 7 stages the 32-query tiles and contracts dQ^T = K^T dS^T
-// one step behind from the dS image) with its step re-cut after the measurements of round 5 (profiles/r05_attention_*):
+// one step behind from the dS image) with its step re-cut after the measurements of round 5 (profiles/r05_attention_ablations_and_arms.txt, r05a_bwd2_phase_timeline_round3_kernel.txt):
 //
 //   * the round-3 loop spent 54 % of its wave cycles in s_waitcnt: per key tile it re-read the Q^T / dO^T fragments of the
 //     dK / dV products from LDS (64 transposing reads per step) right in front of their use.  Here a step has two
@@ -16,7 +16,7 @@
 //     32-byte pieces per store instruction; with one workgroup per CU nothing overlaps that tail);
 //   * dQ wave: delta = rowsum(dO o O) on v_dot2c_f32_bf16, zero fill only on the partial tile.
 //
-// What was measured and NOT kept (same file history, profiles/r05_attention_bwd_ablations.txt): running phase 2 of waves
+// What was measured and NOT kept (same file history, profiles/r05_attention_ablations_and_arms.txt): running phase 2 of waves
 // 4 .. 6 one step late under their SIMD partner's phase 1 (+3 % time: matrix and vector instructions of the two waves of
 // a SIMD do not overlap on this chip -- every ablation removes its part's issue time, the parts add up); staging the
 // query tiles from waves 0 .. 3 with wave 7 touching the lines into L2 (the 13 extra live registers made the compiler
