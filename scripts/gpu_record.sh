@@ -7,7 +7,8 @@
 #     profile  rocprofv3 --kernel-trace --stats of the bench command, per-step / per-shape tables (summarize_trace.py)
 #     sq       SQ counters of the attention kernels at the BEV self-attention shape (separate --pmc passes)
 #     traffic  FETCH_SIZE / WRITE_SIZE per launch of every hand-written HBM-bound kernel against its algorithmic bytes
-#     modes    the fp32 mode, the fp32-residual bf16 mode, the forced one-rank collectives (bench.py lines)
+#     modes    the RCCL exchange forced on a one-rank group (bench.py line with the per-region timeline); the fp32 mode and the
+#              fp32-residual bf16 mode are side configurations of the default bench line
 #     nav      fine-tune rollouts (bench_nav.py): device / host map, with / without action feedback, training mode
 #   everything lands in gpurun_out/<tag>_*; copy what is to be kept into profiles/.
 set -u
@@ -52,8 +53,6 @@ for P in $PARTS; do
     traffic)
       bash scripts/gpu_pmc_all.sh ${T} 2>&1 | tail -40 ;;
     modes)
-      timeout 600 python bench.py --dtype fp32 --no-sustained-ragged --no-side --no-cpu-baseline --no-stream > ${O}_bench_fp32.json 2> ${O}_bench_fp32.err; line ${O}_bench_fp32.json
-      timeout 600 python bench.py --residual fp32 --no-sustained-ragged --no-side --no-cpu-baseline --no-stream > ${O}_bench_bf16_fp32_residual.json 2> ${O}_bench_res32.err; line ${O}_bench_bf16_fp32_residual.json
       BEVBERT_FORCE_COLLECTIVES=1 timeout 600 python bench.py --no-side --no-cpu-baseline --no-stream > ${O}_bench_forced_collectives.json 2> ${O}_bench_forced.err; line ${O}_bench_forced_collectives.json ;;
     nav)
       rm -f ${O}_nav.jsonl
