@@ -435,7 +435,7 @@ def main():
         # Every rank runs the three steps (they contain the gradient all-reduce); only rank 0 records.
         log("kernel timing pass")
         if rank == 0:
-            ops.TRACE = {}
+            ops.RT.trace = {}
         prof_start = torch.cuda.Event(enable_timing=True)
         prof_end = torch.cuda.Event(enable_timing=True)
         prof_start.record()
@@ -444,7 +444,7 @@ def main():
         prof_end.record()
         torch.cuda.synchronize()
     if rank == 0 and not a.no_kernel_pass:
-        trace, ops.TRACE = ops.TRACE, None
+        trace, ops.RT.trace = ops.RT.trace, None
         total_ms = prof_start.elapsed_time(prof_end)
         rows = {}
         for key, evs in trace.items():

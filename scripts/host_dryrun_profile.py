@@ -34,17 +34,30 @@ def _noop_call(name, *args):
     N_CALLS[name] = N_CALLS.get(name, 0) + 1
 
 
+# ops.py re-exports the modules below: a stub has to be installed where the CALLERS look the name up
+from vln_bevbert_amd import ops_attention, ops_core, ops_gemm, ops_reduce, ops_rowops  # noqa: E402
+_MODS = (ops, ops_core, ops_reduce, ops_gemm, ops_rowops, ops_attention)
+
+
+def _stub(name, value):
+    for m in _MODS:
+        if hasattr(m, name):
+            setattr(m, name, value)
+
+
 lib.call = _noop_call
-ops._raw_call = _noop_call
-lib.ptr = ops.ptr = lambda t: None if t is None else t.data_ptr()
-lib.stream = ops.stream = lambda: 0
-ops._linear_fwd = lambda x, w, b: torch.empty(x.shape[:-1] + (w.shape[0],), dtype=x.dtype)
-ops._linear_dgrad = lambda dy2, w, add=None: torch.empty(dy2.shape[0], w.shape[1], dtype=dy2.dtype)
-ops._linear_wgrad = lambda dy2, x2, S=1, scratch=False: torch.empty(
-    (S, dy2.shape[1], x2.shape[1]) if S > 1 else (dy2.shape[1], x2.shape[1]), dtype=dy2.dtype)
-ops.SCRATCH.alloc = lambda nbytes, device: 0            # scratch-ring addresses are only ever passed to the (stubbed) C ABI
+_stub("_raw_call", _noop_call)
+lib.ptr = lambda t: None if t is None else t.data_ptr()
+lib.stream = lambda: 0
+_stub("ptr", lib.ptr)
+_stub("stream", lib.stream)
+_stub("_linear_fwd", lambda x, w, b: torch.empty(x.shape[:-1] + (w.shape[0],), dtype=x.dtype))
+_stub("_linear_dgrad", lambda dy2, w, add=None: torch.empty(dy2.shape[0], w.shape[1], dtype=dy2.dtype))
+_stub("_linear_wgrad", lambda dy2, x2, S=1, scratch=False: torch.empty(
+    (S, dy2.shape[1], x2.shape[1]) if S > 1 else (dy2.shape[1], x2.shape[1]), dtype=dy2.dtype))
+ops.RT.scratch.alloc = lambda nbytes, device: 0         # scratch-ring addresses are only ever passed to the (stubbed) C ABI
 ops.ReduceQueue.flush = classmethod(lambda cls, device: (cls.jobs.clear(), cls.accum_jobs.clear()))
-ops._partial_rows = lambda rows: min(512, (rows + 15) // 16)
+_stub("_partial_rows", lambda rows: min(512, (rows + 15) // 16))
 ops.WgradStream.active = classmethod(lambda cls, device: False)      # closures run inline (their cost is still counted)
 
 from vln_bevbert_amd.pretrain_cmt import GlocalTextPathCMTPreTraining  # noqa: E402

@@ -537,7 +537,7 @@ def test_backward_through_many_forwards_spills_into_further_scratch_buffers(env,
     assert need > 0 and ops.SCRATCH.ci == 0
     small = ops.ScratchRing(max(max(sizes), need // 5 // 256 * 256), max_total=4 * need + (1 << 20))
     monkeypatch.setattr(ops.ScratchRing, "INITIAL", 1 << 14)
-    monkeypatch.setattr(ops, "SCRATCH", small)
+    monkeypatch.setattr(ops.RT, "scratch", small)
     ops.ReduceQueue._tables.clear(); ops.ReduceQueue._accum_tables.clear()
     l1, g1 = long_backward()                           # the first buffer grows during this pass (warm-up)
     assert l1 == l0 and torch.equal(g1, g0)

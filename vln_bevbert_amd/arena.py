@@ -171,7 +171,7 @@ class ParamArena:
         # been issued and the current stream waits for the side streams, so the scratch ring may start over
         if self.device.type == "cuda":
             from . import ops
-            ops.SCRATCH.reset()
+            ops.RT.scratch.reset()
         fresh = self._fresh
         if self.allreduce_group is not None and not self.defer_allreduce:
             import torch.distributed as dist
@@ -245,7 +245,7 @@ class ParamArena:
         self.sync()
         if self.device.type == "cuda":
             from . import ops
-            ops.SCRATCH.reset()        # partial-sum addresses repeat from step to step (ops.ReduceQueue caches on them)
+            ops.RT.scratch.reset()        # partial-sum addresses repeat from step to step (ops.ReduceQueue caches on them)
         self.grads.zero_()
 
     def load_state_dict_into(self, module, sd, strict=True):

@@ -416,7 +416,7 @@ class PretrainTrainer:
         A ``static_step.StaticBatch`` runs eagerly ``GRAPH_WARMUP`` times, is then captured into a hipGraph (forward,
         backward with the weight-gradient stream, clip, AdamW -- and, on several GPUs, the in-place all-reduce on its
         side stream) and replayed from then on: one launch per step instead of ~1 000."""
-        if isinstance(batch, StaticBatch) and self.use_graphs and self.capture_ok and batch.capturable and ops.TRACE is None:
+        if isinstance(batch, StaticBatch) and self.use_graphs and self.capture_ok and batch.capturable and ops.RT.trace is None:
             return self._static_step(task, batch)
         loss = self.forward_backward(task, batch)
         self.optimizer_step()
