@@ -148,10 +148,10 @@ def algorithmic_work(key, args, esize):
     if key in ("bevbert_multi_accum", "bevbert_multi_finalize"):      # device task tables: bytes recorded when built
         from vln_bevbert_amd import ops as _ops
         return 0.0, float(_ops.ReduceQueue.table_bytes.get(args[0], 0))
-    if key == "bevbert_attn_drop_bits":             # the keep-bit matrix (forward layout; + backward layout for 256 < Lk <= 448)
-        B, nh, Lq, Lk = args[1], args[2], args[3], args[4]
+    if key == "bevbert_attn_drop_bits":             # the keep-bit matrix (forward layout; + the key-major and the per-lane
+        B, nh, Lq, Lk = args[1], args[2], args[3], args[4]   # layouts for 256 < Lk <= 448: attn_bwd3 / attn_fwd4)
         words = B * nh * ((Lq + 127) // 128 * 8) * ((Lk + 63) // 64) * 16
-        return 0.0, 8.0 * words * (2 if 256 < Lk <= 448 else 1)
+        return 0.0, 8.0 * words * (3 if 256 < Lk <= 448 else 1)
     if key == "bevbert_colsum_partials":
         return 0.0, args[2] * args[3] * size_of[args[4]]
     if key in ("bevbert_embedding_grad", "bevbert_embedding_grad_sliced"):

@@ -41,7 +41,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k in tot: att[k][c + "_KiB"] = tot[k] / cnt[k]
 B, nh, L, es = 64, 12, 441, 2
 alg = {"attn_fwd": (2 * L + 2 * L) * nh * 64 * B * es, "attn_bwd": (4 * L + 4 * L) * nh * 64 * B * es,
-       "attn_drop_bits": 2 * 8 * B * nh * 32 * 7 * 16}
+       "attn_drop_bits": 3 * 8 * B * nh * 32 * 7 * 16}
 for k, v in att.items():
     t = (2 * v.get("FETCH_SIZE_KiB", 0.0) + v.get("WRITE_SIZE_KiB", 0.0)) * 1024
     a = next((x for n, x in alg.items() if n in k), None)
