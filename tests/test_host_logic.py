@@ -649,6 +649,26 @@ def test_bucket_manager_never_refills_a_buffer_set_the_consumer_still_holds():
         mgr2.acquire("mlm", batches[2])
 
 
+def test_streaming_loader_close_wakes_a_producer_that_waits_for_an_unreleased_set():
+    """a consumer that stops early WITHOUT releasing what it holds (it raised, or broke out of its loop) leaves
+    the producer waiting for that buffer set; close() must end that wait at once (not after the two-minute timeout of the
+    wait), release what is still queued and leave no error behind."""
+    import time
+    from vln_bevbert_amd.loader import BucketManager, StreamingLoader
+    cfg = BevBertConfig.tiny(num_l_layers=1, num_x_layers=1, vocab_size=400)
+    base = synthetic.make_batch(cfg, "mlm", 2, seed=7, sems_as="ids")
+    mgr = BucketManager(cfg, "cpu", depth=2, max_buckets=4)
+    loader = StreamingLoader((("mlm", dict(base)) for _ in range(8)), mgr, prefetch=1)
+    it = iter(loader)
+    held = [next(it), next(it)]                       # both buffer sets of the bucket, never released
+    time.sleep(0.3)                                   # the producer now waits for a set to come free
+    t0 = time.perf_counter()
+    loader.close()
+    assert time.perf_counter() - t0 < 5.0
+    assert not loader.thread.is_alive() and loader.error is None
+    assert all(sb.in_use for _, sb in held)           # what the consumer holds is still the consumer's
+
+
 def test_host_feed_cpu_fallback_and_bucket_padding():
     """graph_map.HostFeed on a CPU device packs like on the GPU (without pinning): typed views of one buffer, addresses for
     kernel arguments without a view; nav_static pads the node / candidate axes to multiples of the bucket step."""

@@ -36,6 +36,8 @@ struct Plan {
   int id = -1;
   int choice = -1, ncand = 0;   // tuning-table row: index of the chosen candidate in the heuristic's list of `ncand`,
                                 // or (ncand == -1) the library-wide solution index of an exhaustive search
+  std::vector<hipblasLtMatmulHeuristicResult_t> heur;   // the heuristic's list behind an imported exhaustive-search row: what a
+                                // failed verification of that row falls back to
   int sel = -1;                 // position of the chosen algorithm in `cand` while candidates are kept
   hipblasOperation_t ta = HIPBLAS_OP_N, tb = HIPBLAS_OP_N;
   hipDataType tin = HIP_R_16BF, tout = HIP_R_16BF;
@@ -139,6 +141,7 @@ int make_plan(const Problem& q, int64_t workspace_bytes, int autotune) {
             HIPBLAS_STATUS_SUCCESS && (int64_t)ws <= workspace_bytes) {
       one[0].workspaceSize = ws;
       one[0].state = HIPBLAS_STATUS_SUCCESS;
+      p.heur = p.cand;
       p.cand = one;
       p.choice = imported->second.first;
       p.ncand = -1;
@@ -334,7 +337,13 @@ void tune_plan(Plan& p, const void* A, const void* B, void* C, void* workspace, 
       p.verified = true;
       p.cand.clear();
       p.cand.shrink_to_fit();
+      p.heur.clear();
       return;
+    }
+    if (p.ncand == -1 && !p.heur.empty()) {      // the imported exhaustive-search pick does not repeat / launch here: time
+      p.cand.swap(p.heur);                       // the heuristic's candidates instead of giving the problem up
+      p.heur.clear();
+      p.ncand = (int)p.cand.size();
     }
     tune_plan(p, A, B, C_real, workspace, workspace_bytes, stream, -1);
     return;

@@ -181,7 +181,9 @@ class DeviceGraphMap:
         same launch when asked, agent.py:471-474 (``step_id`` = t + 1 for the samples not in ``step_ended``) and the
         bookkeeping of GraphMap.update_node_pc (``store_rows``: feature-store row of each sample's viewpoint)."""
         B = self.B
-        self._dig = self._last = None        # a new step: the per-step caches are keyed by the identity of ``obs`` only
+        # a new step: every per-step cache goes (they are keyed by the identity of ``obs`` only, and a caller may refresh the
+        # same list object in place; _last_up is rewritten below)
+        self._dig = self._last = self._nav_up = self._last_up = None
         cur, cand, ncand = self._resolve(obs, True, ended)
         if int(self.n.max()) > self.N:
             self._alloc(max(2 * self.N, int(self.n.max())))
@@ -413,7 +415,13 @@ class DeviceGraphMap:
         position features of the start viewpoint come out of that launch too)."""
         B, V = self.B, self.V
         cur, _, _ = self._resolve(obs, False)
-        R = min(64, self._neighbour_bound(cur, pc_order))
+        R = self._neighbour_bound(cur, pc_order)
+        if R > 64:
+            # the reference's gather_node_pc is unbounded; the kernel keeps its choice in a 64-entry LDS list.  The bound is
+            # exact for pc_order <= 1 and an episode of max_action_len 15 visits at most 16 nodes, so this is a configuration
+            # this build does not serve -- say so on the host instead of truncating on the device
+            raise lib.BevBertHipError(f"bev_inputs: up to {R} visited nodes within {pc_order} hops of a viewpoint; "
+                                      "bevbert_gm_bev_select takes at most 64")
         args = self._bev_args = (bev_dim, bev_res)
         nu = self._nav_up
         if nu is None or nu[0] is not obs:

@@ -50,6 +50,7 @@ class BucketManager:
         self.copy_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.stats = collections.Counter()
         self._cv = threading.Condition()
+        self.stopped = False            # set by stop(): a producer waiting for a buffer set gives up promptly
 
     def _on_copy_stream(self):
         return torch.cuda.stream(self.copy_stream) if self.copy_stream is not None else _NullCtx()
@@ -59,6 +60,8 @@ class BucketManager:
         t0 = time.perf_counter()
         with self._cv:
             while getattr(sb, "in_use", False):
+                if self.stopped:
+                    raise LoaderStopped("BucketManager.stop(): the consumer is gone")
                 if not self._cv.wait(timeout=1.0) and time.perf_counter() - t0 > self.WAIT_TIMEOUT_S:
                     raise RuntimeError("BucketManager: a buffer set was never released (call release(sb) after the step "
                                        "on it has been enqueued); depth must be >= 2 for the producer to run ahead")
@@ -117,6 +120,12 @@ class BucketManager:
         ev.record(self.copy_stream)
         return ev
 
+    def stop(self):
+        """The consumer is done (StreamingLoader.close): wake a producer that waits for a buffer set."""
+        with self._cv:
+            self.stopped = True
+            self._cv.notify_all()
+
     def release(self, sb):
         """Call right after the step on ``sb`` has been enqueued: its buffers may be refilled once that step is done."""
         if self.device.type == "cuda":
@@ -129,6 +138,10 @@ class BucketManager:
 
     def captured_graphs(self):
         return sum(sb.graph is not None for b in self.buckets.values() for sb in b["sets"])
+
+
+class LoaderStopped(RuntimeError):
+    """Raised inside the producer thread when BucketManager.stop() ends a wait for a buffer set."""
 
 
 class _NullCtx:
@@ -168,6 +181,8 @@ class StreamingLoader:
                 t0 = time.perf_counter()
                 self.q.put((task, sb))
                 st["queue_s"] += time.perf_counter() - t0           # waiting for the consumer to take the previous batch
+        except LoaderStopped:
+            pass                        # close() while this thread waited for a buffer set: not an error
         except Exception as e:          # noqa: BLE001 -- surfaced in the consumer thread
             self.error = e
         self.q.put(None)
@@ -189,9 +204,15 @@ class StreamingLoader:
         self.manager.release(sb)
 
     def close(self):
+        """Stop the producer.  Items still queued are released (nobody will run a step on them), and a producer that is
+        waiting for a buffer set the consumer never released -- it stopped early, or raised before release(sb) -- is woken
+        up instead of sitting out the two-minute timeout of that wait."""
         self._stop = True
+        self.manager.stop()
         while self.thread.is_alive():
             try:
-                self.q.get(timeout=0.1)
+                item = self.q.get(timeout=0.1)
             except queue.Empty:
-                pass
+                continue
+            if isinstance(item, tuple) and len(item) == 2 and hasattr(item[1], "in_use"):
+                self.manager.release(item[1])
