@@ -336,19 +336,35 @@ __global__ __launch_bounds__(512, 2) void attn_fwd4_kernel(AttnArgs a, const uin
     issue_PV(oacc[3], pbq[1]);
     stamp(60);
 
-    // ---- epilogue: normalise (dropout scaling folded in), store O[q][h*64 + dt*16 + g*4 .. +3] and the log-sum-exp
+    // ---- epilogue: normalise (dropout scaling folded in) and store O as whole 128-byte rows, 16 bytes per lane, through an
+    //      LDS region nobody reads any more (the accumulator layout would give sixteen 32-byte pieces per store instruction).
+    //      Free regions: this wave has passed the barrier of the last tile, so every wave is done with tiles 0 .. ntiles - 2;
+    //      region 0 is the producer's (next item's tile 0, stored right after that barrier), regions >= ntiles are never
+    //      written; the producer touches region t >= 1 only after the barrier of tile t - 1 of the NEXT item, i.e. after
+    //      every wave has left this epilogue.  Five such K regions (waves 0 .. 4) and two V regions (waves 5, 6).
     const float ks = DROP ? a.keep_scale : 1.0f;
+    const int ri = w < 5 ? w : w - 5;
+    const int region = ri + 1 < ntiles - 1 ? ri + 1 : ri + 2;
+    bf16_raw* stg = (w < 5 ? s_k : s_v) + region * 64 * F4_LD;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       const float l = quad_sum(l_run[qt][0] + l_run[qt][1]);
       const float inv = ks / l;
-      if (orow[qt] < a.Lq) {
-        bf16_raw* op = (bf16_raw*)a.o + (size_t)b * a.bso + (size_t)orow[qt] * a.ldo + h * ATTN_D;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          st4<bf16_raw>(op + dt * 16 + g * 4, make_float4(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv,
-                                                           oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv));
-        if (a.lse && g == 0) a.lse[((size_t)b * a.nh + h) * a.Lq + orow[qt]] = (log2f(l) - nm[qt]) * LN2;
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(stg + (16 * qt + c) * F4_LD + 16 * dt + 4 * g) =
+            make_uint2(pack_bf16x2(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv),
+                       pack_bf16x2(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv));
+      if (orow[qt] < a.Lq && a.lse && g == 0) a.lse[((size_t)b * a.nh + h) * a.Lq + orow[qt]] = (log2f(l) - nm[qt]) * LN2;
+    }
+    {
+      const int q0 = orow[0] - c;                      // first query of this wave
+      bf16_raw* op = (bf16_raw*)a.o + (size_t)b * a.bso + h * ATTN_D;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = (lane >> 3) + 8 * i, ch = lane & 7;
+        const uint4 val = *reinterpret_cast<const uint4*>(stg + row * F4_LD + ch * 8);
+        if (q0 + row < a.Lq) *reinterpret_cast<uint4*>(op + (size_t)(q0 + row) * a.ldo + ch * 8) = val;
       }
     }
     stamp(62);
