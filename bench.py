@@ -407,6 +407,13 @@ def main():
             regions[t] = {"forward_backward_ms": round(s_ev.elapsed_time(b_ev), 3),
                           "regions": [{"MB": round((hi - lo) * 4 / 1e6, 1), "start_ms": round(s_ev.elapsed_time(e0), 3),
                                        "end_ms": round(s_ev.elapsed_time(e1), 3)} for lo, hi, e0, e1 in trainer.reducer.timeline]}
+            bs = getattr(trainer, "backward_start", None)
+            if bs is not None and regions[t]["regions"]:
+                # where in the backward pass the first collective is enqueued (before 30 % of it)
+                b0, fb = s_ev.elapsed_time(bs), regions[t]["forward_backward_ms"]
+                regions[t]["backward_start_ms"] = round(b0, 3)
+                regions[t]["first_collective_at_fraction_of_backward"] = round(
+                    (regions[t]["regions"][0]["start_ms"] - b0) / max(fb - b0, 1e-6), 3)
             trainer.reducer.timeline = None
         trainer.use_graphs = was_graphs
         digest = []

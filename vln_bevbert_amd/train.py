@@ -398,6 +398,9 @@ class PretrainTrainer:
             loss = self.model.loss_mean(batch.tensors, task)
         else:
             loss = self.model(batch, task, compute_loss=True).mean()                 # train_r2r.py:263
+        if self.reducer is not None and self.reducer.timeline is not None:           # bench.py's region timeline
+            self.backward_start = torch.cuda.Event(enable_timing=True)
+            self.backward_start.record()
         loss.backward()
         self.arena.sync()                      # side-stream work has written its gradients
         self.reducer.finish()
