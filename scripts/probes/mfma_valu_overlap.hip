@@ -1,156 +1,120 @@
-// Do matrix (v_mfma_f32_16x16x32_bf16) and vector instructions overlap on a gfx950 SIMD?  One workgroup per CU, cycles from
-// s_memtime around a loop of ITER rounds; per round a wave issues NM independent matrix instructions and / or NV vector
-// instructions (8 independent dependency chains each, so neither side stalls on its own latency).
-//   mode 0: matrix only            mode 1: vector only (v_fma_f32)      mode 2: both, interleaved in ONE wave
-//   mode 3: two waves per SIMD, waves 0-3 matrix only, waves 4-7 vector only
-//   mode 4: two waves per SIMD, both interleaved (half the rounds each)
-//   mode 5: vector only, v_exp_f32 instead of v_fma_f32 (cost of the transcendental)
-//   mode 6: vector only, v_pk_fma_f32           mode 7: matrix + v_exp_f32 interleaved, one wave
-//   mode 8 / 9: as 0 / 2 with v_mfma_f32_32x32x16_bf16 (4 per round = the same flops)
-//   mode 10: two waves per SIMD, waves 4-7 (the YOUNGER ones) matrix only, waves 0-3 vector only
-//   mode 11 / 12 / 13: as 0 / 2 / 3 with the accumulators in the AGPR file (inline asm, "a" constraint)
+// Do matrix (v_mfma_f32_16x16x32_bf16) and vector instructions overlap on a gfx950 SIMD, and what does a vector instruction
+// cost?  Every measured instruction is an `asm volatile` statement (the first version of this probe let the compiler see the
+// vector chains: it packed pairs of v_fma_f32 into v_pk_fma_f32 and moved accumulators between the register files, and the
+// numbers described its output, not the instructions named).  One workgroup per CU; cycles from s_memtime around ROUNDS rounds;
+// a round = NM matrix instructions (8 independent AGPR accumulators) and / or NV vector instructions (8 independent chains).
+//   A. one wave per SIMD: matrix only; each vector kind only; matrix + vector kind interleaved (1 matrix : 5 vector)
+//   B. two waves per SIMD: waves 0-3 matrix only for the whole run, waves 4-7 one vector kind for a QUARTER of the rounds (so the
+//      vector waves live entirely inside the matrix waves' run): their time per round against the same waves running alone
+//   C. two waves per SIMD, both running the interleaved stream of A, half the rounds each: SIMD time per round
 // Build: hipcc --offload-arch=gfx950 -O2 mfma_valu_overlap.hip -o mfma_valu_overlap
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define ITER 2000
+#define ROUNDS 2000
 #define NM 8
 #define NV 40
 
-template <bool DO_M, int VKIND>   // VKIND: 0 none, 1 fma, 2 exp, 3 pk_fma
+enum { V_NONE, V_FMA, V_PK_FMA, V_EXP, V_ADD, V_MAX3, V_CVT_PK, V_AND, V_PK_SHL16, V_ADD_CO, V_CNDMASK_S, NKIND };
+static const char* kind_name[] = {"-", "v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_add_f32", "v_max3_f32", "v_cvt_pk_bf16_f32",
+                                  "v_and_b32", "v_pk_lshlrev_b16", "v_add_co_u32 (vcc)", "v_cndmask_b32 (sgpr pair mask)"};
+
+template <int K>
+__device__ __forceinline__ void vinst(uint32_t (&v)[16], int i, uint32_t k, unsigned long long mask) {
+  uint32_t& x = v[i & 7];
+  unsigned long long& x2 = *reinterpret_cast<unsigned long long*>(&v[(2 * i) & 14]);
+  if (K == V_FMA) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(k));
+  if (K == V_PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(x2) : "v"((unsigned long long)k << 32 | k));
+  if (K == V_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
+  if (K == V_ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(k));
+  if (K == V_MAX3) asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(x) : "v"(k));
+  if (K == V_CVT_PK) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x) : "v"(k));
+  if (K == V_AND) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(k));
+  if (K == V_PK_SHL16) asm volatile("v_pk_lshlrev_b16 %0, 1, %0" : "+v"(x));
+  if (K == V_ADD_CO) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(x) : "v"(k) : "vcc");
+  if (K == V_CNDMASK_S) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(x) : "v"(k), "s"(mask));
+}
+
+template <bool DO_M, int K>
 __device__ __forceinline__ void body(float* out, int rounds) {
   f32x4 acc[NM];
   for (int i = 0; i < NM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   bf16x8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.001f + i); b[i] = (__bf16)(i * 0.5f); }
-  float v[8];
-  f32x2 v2[8];
-  for (int i = 0; i < 8; ++i) { v[i] = threadIdx.x * 1e-3f + i; v2[i] = (f32x2){v[i], v[i] + 1.f}; }
-  const float k0 = 0.999f, k1 = 1e-3f;
-  for (int it = 0; it < rounds; ++it) {
-#pragma unroll
-    for (int j = 0; j < NM; ++j) {
-      if (DO_M) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NV / NM; ++i) {
-        const int c = (j * (NV / NM) + i) & 7;
-        if (VKIND == 1) v[c] = __builtin_fmaf(v[c], k0, k1);
-        if (VKIND == 2) v[c] = __builtin_amdgcn_exp2f(v[c]);
-        if (VKIND == 3) v2[c] = __builtin_elementwise_fma(v2[c], (f32x2){k0, k0}, (f32x2){k1, k1});
-      }
-    }
-  }
-  float s = 0.f;
-  for (int i = 0; i < NM; ++i) s += acc[i][0] + acc[i][3];
-  for (int i = 0; i < 8; ++i) s += v[i] + v2[i][0] + v2[i][1];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-template <bool DO_M, bool DO_V>
-__device__ __forceinline__ void body_agpr(float* out, int rounds) {
-  f32x4 acc[NM];
-  for (int i = 0; i < NM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 a, b;
-  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.001f + i); b[i] = (__bf16)(i * 0.5f); }
-  float v[8];
-  for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 1e-3f + i;
-  const float k0 = 0.999f, k1 = 1e-3f;
+  uint32_t v[16];
+  for (int i = 0; i < 16; ++i) v[i] = 0x3f800000u + threadIdx.x * 64u + i;     // floats a little above 1
+  const uint32_t k = 0x3f7fff00u;                                                // a float a little below 1
+  const unsigned long long mask = 0x5555555555555555ull;
   for (int it = 0; it < rounds; ++it) {
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
       if (DO_M) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a), "v"(b));
 #pragma unroll
-      for (int i = 0; i < NV / NM; ++i) {
-        const int c = (j * (NV / NM) + i) & 7;
-        if (DO_V) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(k0), "v"(k1));
-      }
+      for (int i = 0; i < NV / NM; ++i) vinst<K>(v, j * (NV / NM) + i, k, mask);
     }
   }
   float s = 0.f;
   for (int i = 0; i < NM; ++i) s += acc[i][0] + acc[i][3];
-  for (int i = 0; i < 8; ++i) s += v[i];
+  for (int i = 0; i < 16; ++i) s += __builtin_bit_cast(float, v[i]);
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <bool DO_V>
-__device__ __forceinline__ void body32(float* out, int rounds) {
-  f32x16 acc[4];
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-  bf16x8 a, b;
-  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.001f + i); b[i] = (__bf16)(i * 0.5f); }
-  float v[8];
-  for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 1e-3f + i;
-  const float k0 = 0.999f, k1 = 1e-3f;
-  for (int it = 0; it < rounds; ++it) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NV / 4; ++i) {
-        const int c = (j * (NV / 4) + i) & 7;
-        if (DO_V) v[c] = __builtin_fmaf(v[c], k0, k1);
-      }
-    }
-  }
-  float s = 0.f;
-  for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
-  for (int i = 0; i < 8; ++i) s += v[i];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
+template <int K>
 __global__ __launch_bounds__(512) void probe(int mode, float* out, unsigned long long* cyc) {
   const int w = threadIdx.x >> 6;
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  switch (mode) {
-    case 0: body<true, 0>(out, ITER); break;
-    case 1: body<false, 1>(out, ITER); break;
-    case 2: body<true, 1>(out, ITER); break;
-    case 3: if (w < 4) body<true, 0>(out, ITER); else body<false, 1>(out, ITER); break;
-    case 4: body<true, 1>(out, ITER / 2); break;
-    case 5: body<false, 2>(out, ITER); break;
-    case 6: body<false, 3>(out, ITER); break;
-    case 7: body<true, 2>(out, ITER); break;
-    case 8: body32<false>(out, ITER); break;
-    case 9: body32<true>(out, ITER); break;
-    case 10: if (w >= 4) body<true, 0>(out, ITER); else body<false, 1>(out, ITER); break;
-    case 11: body_agpr<true, false>(out, ITER); break;
-    case 12: body_agpr<true, true>(out, ITER); break;
-    case 13: if (w < 4) body_agpr<true, false>(out, ITER); else body_agpr<false, true>(out, ITER); break;
-  }
+  if (mode == 0) body<true, V_NONE>(out, ROUNDS);                // matrix only
+  if (mode == 1) body<false, K>(out, ROUNDS);                    // vector kind only
+  if (mode == 2) body<true, K>(out, ROUNDS);                     // interleaved in one wave
+  if (mode == 3) { if (w < 4) body<true, V_NONE>(out, ROUNDS); else body<false, K>(out, ROUNDS / 4); }
+  if (mode == 4) body<true, K>(out, ROUNDS / 2);                 // two waves per SIMD, BOTH interleaved, half the rounds each
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) cyc[w] = t1 - t0;
 }
 
-int main() {
-  float* out; unsigned long long* cyc; unsigned long long h[8];
-  hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 64);
-  const char* names[] = {"matrix only, 1 wave/SIMD", "v_fma only, 1 wave/SIMD", "matrix + v_fma interleaved, 1 wave/SIMD",
-                         "2 waves/SIMD: one matrix-only, one v_fma-only", "2 waves/SIMD, both interleaved, half the rounds each",
-                         "v_exp_f32 only, 1 wave/SIMD", "v_pk_fma_f32 only, 1 wave/SIMD", "matrix + v_exp interleaved, 1 wave/SIMD",
-                         "32x32x16 matrix only (4 per round), 1 wave/SIMD", "32x32x16 matrix + v_fma interleaved, 1 wave/SIMD",
-                         "2 waves/SIMD: the older v_fma-only, the younger matrix-only",
-                         "matrix only, accumulators in AGPRs, 1 wave/SIMD", "matrix (AGPR accumulators) + v_fma interleaved, 1 wave/SIMD",
-                         "2 waves/SIMD: one matrix-only (AGPR accumulators), one v_fma-only"};
-  for (int mode = 0; mode < 14; ++mode) {
-    const int threads = (mode == 3 || mode == 4 || mode == 10 || mode == 13) ? 512 : 256;
+template <int K>
+static void run(float* out, unsigned long long* cyc, double mfma_alone) {
+  unsigned long long h[8];
+  double t[5] = {0, 0, 0, 0, 0};
+  for (int mode = (K == V_NONE ? 0 : 1); mode < (K == V_NONE ? 1 : 5); ++mode) {
+    const int threads = mode >= 3 ? 512 : 256;
     for (int rep = 0; rep < 2; ++rep) {
-      hipMemset(cyc, 0, 64);
-      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-      hipEventRecord(e0);
-      hipLaunchKernelGGL(probe, dim3(256), dim3(threads), 0, 0, mode, out, cyc);
-      hipEventRecord(e1); hipEventSynchronize(e1);
-      float ms; hipEventElapsedTime(&ms, e0, e1);
-      hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
-      if (rep == 1)
-        printf("mode %d (%s): %d rounds x (%d matrix + %d vector): wave 0 %.1f ticks/round, wave %d %.1f ticks/round; kernel %.1f us -> %.1f ns/round\n",
-               mode, names[mode], ITER, NM, NV, (double)h[0] / ITER, threads / 64 - 1, (double)h[threads / 64 - 1] / ITER, ms * 1e3,
-               ms * 1e6 / ITER);
+      (void)hipMemset(cyc, 0, 64);
+      hipLaunchKernelGGL(probe<K>, dim3(256), dim3(threads), 0, 0, mode, out, cyc);
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
     }
+    t[mode] = mode == 3 ? (double)h[7] / (ROUNDS / 4) : (double)h[0] / ROUNDS;
+    if (mode == 3) t[0] = (double)h[0] / ROUNDS;      // the matrix wave of the same SIMD, per round
+    if (mode == 4) t[4] = (double)(h[0] > h[4] ? h[0] : h[4]) / ROUNDS;   // SIMD time per round of (matrix + vector) work, two waves sharing it
   }
+  if (K == V_NONE) {
+    printf("matrix only: %.1f cycles per round of %d v_mfma_f32_16x16x32_bf16 = %.2f each\n", t[0], NM, t[0] / NM);
+    return;
+  }
+  printf("%-32s alone %6.1f cycles / %d = %5.2f each | interleaved with %d matrix instructions in one wave: %6.1f (sum of the two alone: %6.1f)"
+         " | beside a matrix-only wave on the same SIMD: %6.1f per round = %.2f x alone (the matrix wave: %.1f per round)"
+         " | the interleaved rounds split over TWO waves of the SIMD: %6.1f per round\n",
+         kind_name[K], t[1], NV, t[1] / NV, NM, t[2], t[1] + mfma_alone, t[3], t[3] / t[1], t[0], t[4]);
+}
+
+int main() {
+  float* out; unsigned long long* cyc;
+  (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&cyc, 64);
+  // matrix only first: its time per round is the reference of the "sum" column
+  unsigned long long h[8];
+  for (int rep = 0; rep < 2; ++rep) {
+    (void)hipMemset(cyc, 0, 64);
+    hipLaunchKernelGGL(probe<V_NONE>, dim3(256), dim3(256), 0, 0, 0, out, cyc);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
+  }
+  const double m = (double)h[0] / ROUNDS;
+  run<V_NONE>(out, cyc, m);
+  run<V_FMA>(out, cyc, m); run<V_PK_FMA>(out, cyc, m); run<V_EXP>(out, cyc, m); run<V_ADD>(out, cyc, m); run<V_MAX3>(out, cyc, m);
+  run<V_CVT_PK>(out, cyc, m); run<V_AND>(out, cyc, m); run<V_PK_SHL16>(out, cyc, m); run<V_ADD_CO>(out, cyc, m); run<V_CNDMASK_S>(out, cyc, m);
   return 0;
 }

@@ -17,8 +17,10 @@
 //   * dQ wave: delta = rowsum(dO o O) on v_dot2c_f32_bf16, zero fill only on the partial tile.
 //
 // What was measured and NOT kept (same file history, profiles/r05_attention_ablations_and_arms.txt): running phase 2 of waves
-// 4 .. 6 one step late under their SIMD partner's phase 1 (+3 % time: matrix and vector instructions of the two waves of
-// a SIMD do not overlap on this chip -- every ablation removes its part's issue time, the parts add up); staging the
+// 4 .. 6 one step late under their SIMD partner's phase 1 (+3 % time; every ablation of this kernel removes about its part's
+// own issue time -- the parts add up -- although the chip can hide matrix instructions behind the other wave's plain vector
+// instructions: scripts/probes/mfma_valu_overlap.hip.  Its packed fp32 lines (soft_bwd) are one suspect: packed fp32 does not
+// overlap with v_mfma; the scalar form of those lines spilled 20 - 60 registers at the 256-register limit); staging the
 // query tiles from waves 0 .. 3 with wave 7 touching the lines into L2 (the 13 extra live registers made the compiler
 // spill the V fragments and the staged chunks: 2 x slower).
 //

@@ -3,11 +3,14 @@
 // (transposed formulation S^T = K Q^T, O^T = V^T P^T, lazy running maximum, mask as the C operand), different shape.
 //
 // What the shape answers (measured on the MI355X, this round):
-//   * scripts/probes/mfma_valu_overlap.hip (profiles/r05_mfma_valu_overlap_probe.txt): on a gfx950 SIMD matrix and vector
-//     instructions do NOT overlap -- neither inside one wave nor between two waves of a SIMD, with 16x16x32 or 32x32x16 tiles,
-//     accumulators in VGPRs or AGPRs: the time of a SIMD is (matrix instructions x 16 cycles) + (vector instructions x 2.2,
-//     packed fp32 4.4, v_exp_f32 8.4 cycles).  More waves per SIMD hide latencies, they do not create overlap; so this kernel
-//     runs two waves per SIMD with a large tile each and spends its effort on what is NOT arithmetic;
+//   * scripts/probes/mfma_valu_overlap.hip (profiles/r05_mfma_valu_overlap_probe.txt): two waves of a gfx950 SIMD that both
+//     interleave matrix and PLAIN vector instructions hide the matrix instructions almost completely (8 v_mfma + 40 vector
+//     instructions: 234 - 247 cycles against 205 - 225 for the vector instructions alone), while packed fp32 instructions
+//     (v_pk_fma_f32 ...) do not mix with v_mfma at all (worse than one after the other).  The ceiling of this kernel is its vector
+//     work, ~280 cycles per (16 queries x 32 keys); its loop runs at ~380 (the dependent chains inside a unit, the LDS reads), and
+//     what a kernel can win beyond that is everything that is NOT arithmetic.  This file is compiled without the SLP vectoriser
+//     and keeps its row sums in scalar chains so that no packed fp32 instruction sits in the loop (measured: no difference,
+//     77.6 against 77.7 us -- they were not what keeps the loop from the probe's overlap);
 //   * the s_memtime timeline of one workgroup of the non-persistent version (BEVBERT_FWD4_ABL=32): 22 % of a workgroup's life
 //     was its prologue -- 256 workgroups start a round together and ask for their first 110 KB at once, 28 MB at HBM speed --
 //     and the units in which a wave fetched fragments from LDS took twice the time of the others.
@@ -290,15 +293,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd4_kernel(AttnArgs a, const uin
         // P = exp2(t); row sums before dropout (packed adds); dropout on the packed bf16 pairs: pair j of the iteration
         // (elements 2 j, 2 j + 1 in (qt, tt, r) order) has its keep bits at bit j of the two halves of the word, so
         // mask = each half shifted left by 15 - j, then arithmetically right by 15: two packed 16-bit shifts + one AND per pair
-        f32x2 ps = (f32x2){0.f, 0.f};
+        float ps0 = 0.f, ps1 = 0.f;     // two scalar chains: packed fp32 adds would not overlap with the other wave's matrix work
         uint32_t pk[4];
         auto soft_pair = [&](int i) {
           const int tt = i >> 1, r0 = 2 * (i & 1);
-          f32x2 p;
-          p[0] = (ABL & 1) ? sa[qt][tt][r0] : fast_exp2(sa[qt][tt][r0]);
-          p[1] = (ABL & 1) ? sa[qt][tt][r0 + 1] : fast_exp2(sa[qt][tt][r0 + 1]);
-          ps += p;
-          pk[i] = pack_bf16x2(p[0], p[1]);
+          const float p0 = (ABL & 1) ? sa[qt][tt][r0] : fast_exp2(sa[qt][tt][r0]);
+          const float p1 = (ABL & 1) ? sa[qt][tt][r0 + 1] : fast_exp2(sa[qt][tt][r0 + 1]);
+          ps0 += p0;
+          ps1 += p1;
+          pk[i] = pack_bf16x2(p0, p1);
           if (DROP && !(ABL & 1)) {
             typedef short s16x2 __attribute__((ext_vector_type(2)));
             const s16x2 wv = __builtin_bit_cast(s16x2, wd0);
@@ -325,7 +328,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd4_kernel(AttnArgs a, const uin
             wd2 = wl[64];
           }
         }
-        l_run[qt] += ps;
+        l_run[qt][0] += ps0;
+        l_run[qt][1] += ps1;
         pbq[P] = as_bf16x8(make_uint4(pk[0], pk[1], pk[2], pk[3]));
       }
       wd0 = wd1;

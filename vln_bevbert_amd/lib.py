@@ -14,6 +14,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbevbert_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
+# Per-file compiler flags.  The persistent attention forward is compiled without the SLP vectoriser: it packs pairs of
+# fp32 operations into v_pk_*_f32 instructions, and on gfx950 packed fp32 instructions do not overlap with the matrix
+# instructions of the SIMD's other wave while plain ones do (scripts/probes/mfma_valu_overlap.hip,
+# profiles/r05_mfma_valu_overlap_probe.txt).  Measured on that kernel: no difference either way.
+EXTRA_FLAGS = {"attn_fwd4.hip": ["-fno-slp-vectorize"]}
 SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_f32.hip", "attn_mfma.hip", "attn_bwd1.hip", "attn_fwd2.hip", "attn_fwd4.hip", "attn_bwd2.hip", "attn_bwd3.hip", "attn_small.hip", "sap_loss.hip", "graph_nav.hip", "gemm.hip", "capi.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bevbert_hip.h")
 
@@ -47,7 +52,7 @@ def build(force=False, verbose=False):
         src, obj = os.path.join(CSRC, name), os.path.join(objdir, name[:-4] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
-            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + flags + EXTRA_FLAGS.get(name, []) + ["-c", src, "-o", obj])
     if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH
 
