@@ -836,3 +836,32 @@ def test_grad_reducer_skips_gaps_that_hold_no_tensor():
     assert red._remaining() == []                                    # what is left is padding only
     red.occupied = None
     assert red._remaining() == [(1000, 1024), (1025, 2048), (7096, 7168)]
+
+
+def test_summarize_trace_splits_a_kernel_symbol_by_problem_size(tmp_path):
+    """scripts/summarize_trace.py (the per-step / per-shape view of a rocprofv3 kernel trace behind profiles/*_last_steps_*):
+    keeps the last K steps (delimited by adamw_kernel), classes kernels, and splits ONE symbol launched on ONE grid into its
+    duration clusters -- the 441 x 441 and 80 x 441 problems of an attention kernel share symbol and grid."""
+    import subprocess
+    import sys
+    rows = ["Kind,Agent_Id,Queue_Id,Kernel_Name,Start_Timestamp,End_Timestamp,Workgroup_Size_X,Grid_Size_X"]
+    t = 0
+    for step in range(4):
+        for dur, name, grid in ((160_000, "void attn_bwd3_kernel<true, false, 0>(AttnArgs)", 768 * 512),
+                                (75_000, "void attn_bwd3_kernel<true, false, 0>(AttnArgs)", 768 * 512),
+                                (90_000, "Cijk_Ailk_Bljk_BBS_BH_Bias_HA_S_SAV_UserArgs_MT128x128x128", 240 * 256),
+                                (12_000, "void at::native::vectorized_elementwise_kernel<4>()", 1024 * 256),
+                                (1_100_000, "adamw_kernel(float*, float const*)", 4096 * 256)):
+            rows.append(f"KERNEL_DISPATCH,1,{1 + (name[0] == 'C')},\"{name}\",{t},{t + dur},{512 if 'attn' in name else 256},{grid}")
+            t += dur + 5_000
+    d = tmp_path / "trace"
+    d.mkdir()
+    (d / "x_kernel_trace.csv").write_text("\n".join(rows) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "summarize_trace.py"), str(d), "2"],
+                         capture_output=True, text=True, check=True).stdout
+    assert "last 2 steps" in out and "5 launches/step" in out
+    assert "custom" in out and "gemm" in out and "torch" in out
+    shape_lines = [ln for ln in out.splitlines() if "attn_bwd3_kernel" in ln and "calls/step" in ln]
+    assert len(shape_lines) == 2, out                       # two problem sizes of one symbol on one grid
+    assert "160.00 us avg" in shape_lines[0] and "75.00 us avg" in shape_lines[1]
