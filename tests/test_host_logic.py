@@ -865,3 +865,16 @@ def test_summarize_trace_splits_a_kernel_symbol_by_problem_size(tmp_path):
     shape_lines = [ln for ln in out.splitlines() if "attn_bwd3_kernel" in ln and "calls/step" in ln]
     assert len(shape_lines) == 2, out                       # two problem sizes of one symbol on one grid
     assert "160.00 us avg" in shape_lines[0] and "75.00 us avg" in shape_lines[1]
+
+
+def test_gpu_scripts_parse():
+    """The gpurun scripts under scripts/ are only ever run on the GPU box: at least their shell syntax is checked here."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(glob.glob(os.path.join(root, "scripts", "*.sh")))
+    assert scripts
+    for sh in scripts:
+        r = subprocess.run(["bash", "-n", sh], capture_output=True, text=True)
+        assert r.returncode == 0, (sh, r.stderr)
+    for py in sorted(glob.glob(os.path.join(root, "scripts", "*.py"))) + [os.path.join(root, "bench.py")]:
+        compile(open(py).read(), py, "exec")
