@@ -95,6 +95,12 @@ def parse():
     ap.add_argument("--stream-steps", type=int, default=33)
     ap.add_argument("--loader-workers", type=int, default=4,
                     help="DataLoader worker processes that collate the sustained run's batches (0: in the producer thread)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="only exercise the rank launch: every rank prints its RANK / WORLD_SIZE / LOCAL_RANK as one JSON line and "
+                         "exits (no GPU needed; tests/test_host_logic.py)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (per-kernel tables, every CPU cell, full side configs); the stdout line is "
+                         "the compact contract line")
     ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
                     help="how the step is issued: eager (~700 launches from Python), graph (hipGraph replay), or auto = time "
                          "both in the untimed preparation and keep the faster one (BEVBERT_GRAPHS=0/1 in the environment "
@@ -173,17 +179,115 @@ def algorithmic_work(key, args, esize):
     return 0.0, 0.0
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N ranks of this script on this
+    node (the reference starts its ranks the same way, scripts/pt_r2r.bash:8-10 `python -m torch.distributed.launch
+    --nproc_per_node`).  The ranks inherit stdout / stderr; rank 0 prints the line."""
+    import socket
+    if not a.dry_launch and torch.cuda.device_count() < a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus}, but {torch.cuda.device_count()} GPUs are visible")
+    with socket.socket() as sk:             # a free port for the rendezvous (two benches on one node must not collide)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // a.gpus)))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's only working transport on these hosts
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"starting {a.gpus} ranks: {' '.join(cmd[1:9])} bench.py ...")
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+LINE_LIMIT = 6144          # bytes: the driver parses the LAST stdout line; round 5's 24 KB line was not parsed
+
+
+def _short_roofline(blk):
+    if not isinstance(blk, dict):
+        return blk
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches", "entry_frac",
+            "frac_back_to_back")
+    return {k: blk[k] for k in keep if k in blk}
+
+
+def compact_line(out, detail_path=None):
+    """The contract line: what the driver parses (contract fields, config, roofline, cpu_baseline) plus one short figure
+    per optional block.  Everything else -- per-kernel tables, per-shape rooflines, all CPU cells, the full side configs,
+    the RCCL digest -- lives in the detail record (``--detail``, default bench_detail.json next to this file)."""
+    first = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "step_launch", "launch_calibration", "graph_error", "final_loss",
+             "host_enqueue_ms_per_step", "whole_cycles", "fwd_ms_per_batch")
+    line = {k: out[k] for k in first if k in out}
+    for k in ("roofline", "roofline_attn_bwd", "roofline_attn_fwd", "roofline_attn_short"):
+        if k in out:
+            line[k] = _short_roofline(out[k])
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "error") if k in cb}
+        fw = cb.get("forward") or {}
+        if fw:
+            c["host_cpu"] = fw.get("host_cpu")
+            # BASELINE.json configs[0]: the batch-2 forward on all usable cores, SAP and MLM
+            c["forward_b2_all_cores"] = {x["task"]: {"median_s": x["median_s"], "samples_per_s": x["samples_per_s"]}
+                                         for x in fw.get("cells", []) if x["batch"] == 2 and x["threads"] == fw.get("usable_cores")}
+        line["cpu_baseline"] = c
+    for k in ("sustained", "sustained_ragged"):
+        v = out.get(k)
+        if isinstance(v, dict):
+            line[k] = {x: v[x] for x in ("samples_per_s", "ms_per_step", "vs_resident", "steps_eager", "buckets", "error") if x in v}
+    if isinstance(out.get("kernels"), dict):
+        kn = out["kernels"]
+        line["kernels"] = {x: kn[x] for x in ("profiled_steps", "wall_ms", "custom_kernel_ms", "library_gemm_ms",
+                                              "library_gemm_tflops", "other_ms", "custom_ms_share_with_roofline") if x in kn}
+    sc = out.get("side_configs")
+    if isinstance(sc, dict):
+        line["side_configs"] = {}
+        for name, d in sc.items():
+            if not isinstance(d, dict):
+                continue
+            short = {x: d[x] for x in ("value", "ms_per_step", "ms_per_nav_step", "episodes_per_s") if x in d}
+            if "error" in d or "skipped" in d:
+                short["note"] = str(d.get("error") or d.get("skipped"))[:80]
+            line["side_configs"][name] = short
+    rc = out.get("rccl")
+    if isinstance(rc, dict):
+        line["rccl"] = {x: rc[x] for x in ("ranks", "backend", "exchange", "allreduce_bytes_per_step", "allreduce_alone_ms",
+                                          "allreduce_alone_GBps", "eager_ms_per_step_by_exchange", "first_collective_at_fraction_of_backward",
+                                          "error") if x in rc}
+    if detail_path:
+        line["detail"] = os.path.basename(detail_path)
+    # the limit is a hard property of the line: shed optional blocks (least important first) rather than exceed it
+    for drop in ("side_configs", "kernels", "sustained_ragged", "sustained", "fwd_ms_per_batch", "rccl", "roofline_attn_short",
+                 "launch_calibration", "whole_cycles"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    return line
+
+
 def main():
     a = parse()
     # watchdog: a stalled run (a collective that never completes, a wedged queue) dumps every thread's Python stack to
     # stderr and exits instead of sitting on the GPU until somebody kills it; a normal run takes 1-3 minutes
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("BEVBERT_BENCH_WATCHDOG_S", "1500")), exit=True)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)                      # does not return: this process becomes the launcher of --gpus ranks
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU is visible"
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: pass the launcher's --nproc-per-node as --gpus "
+                 "(or run plain `python bench.py --gpus N`, which starts its own ranks)")
+    if a.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "world_size": world, "local_rank": local_rank,
+                          "master": f"{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '')}"}), flush=True)
+        return
+    if not torch.cuda.is_available():
+        sys.exit("bench.py measures the MI355X path; no GPU is visible")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} wants GPU {local_rank}, but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # BEVBERT_FORCE_COLLECTIVES=1: run the RCCL exchange (side stream, backward hook, in-place all-reduce) on a one-rank
@@ -316,6 +420,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     value = a.steps * a.batch * world / dt
+    whole = None
+    if a.steps % len(cycle):
+        # K is not a whole number of 11-step task cycles (the driver's --steps 20): the K steps above are the contract's
+        # timed region; a second region of ceil(K / 11) whole cycles, continuing the same walk from a cycle boundary, gives
+        # the figure for the exact 5:5:1 task mix next to it
+        run((-counter[0]) % len(cycle))
+        n_whole = -(-a.steps // len(cycle)) * len(cycle)
+        barrier()
+        t0 = time.perf_counter()
+        run(n_whole)
+        barrier()
+        dtw = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dtw], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtw = float(tt.item())
+        whole = {"steps": n_whole, "ms_per_step": round(1000.0 * dtw / n_whole, 3),
+                 "value": round(n_whole * a.batch * world / dtw, 2)}
+        log(f"whole task cycles: {n_whole} steps at {whole['ms_per_step']:.2f} ms/step")
 
     out = {
         "metric": "pretrain_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
@@ -337,6 +460,8 @@ def main():
         "gemm_plans": ops.gemm_plan_count(), "gemm_candidates_rejected_as_not_reproducible": lib.load().bevbert_gemm_rejected_count(),
         "final_loss": round(float(losses[-1].item()), 4),
     }
+    if whole is not None:
+        out["whole_cycles"] = whole
 
     # ---- forward ms/batch (the second half of BASELINE.json's metric; reference: train_r2r.py:256-260): the training
     # forward (dropout on, tape recorded) issued eagerly, and the same batch's inference forward replayed from a graph
@@ -415,7 +540,28 @@ def main():
                 regions[t]["first_collective_at_fraction_of_backward"] = round(
                     (regions[t]["regions"][0]["start_ms"] - b0) / max(fb - b0, 1e-6), 3)
             trainer.reducer.timeline = None
+        # the same eager step with each wire format of the exchange (BEVBERT_GRAD_EXCHANGE): fp32 in-place all-reduce (the
+        # reference's DDP semantics, the bench line) against bf16 reduce-scatter + all-gather (half the bytes per xGMI link);
+        # one task cycle each, issued eagerly in both cases so that the two figures differ by the exchange only
+        by_exchange = {}
+        ex0 = trainer.reducer.exchange
+        for ex in ("fp32", "bf16"):
+            try:
+                trainer.reducer.exchange = ex
+                run(2)
+                barrier()
+                t0 = time.perf_counter()
+                run(len(cycle))
+                barrier()
+                tt = torch.tensor([1000.0 * (time.perf_counter() - t0) / len(cycle)], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                by_exchange[ex] = round(float(tt.item()), 3)
+            except Exception as e:      # noqa: BLE001
+                by_exchange[ex] = f"{type(e).__name__}: {e}"[:160]
+                break
+        trainer.reducer.exchange = ex0
         trainer.use_graphs = was_graphs
+        fracs = [r.get("first_collective_at_fraction_of_backward") for r in regions.values()]
         digest = []
         try:
             import glob
@@ -433,6 +579,8 @@ def main():
                        "phase_a_bytes": int(arena.numel - trainer.reducer.split) * 4,
                        "allreduce_alone_ms": round(ar_ms, 3),
                        "allreduce_alone_GBps": round(arena.numel * 4 / ar_ms / 1e6, 1),
+                       "eager_ms_per_step_by_exchange": by_exchange,
+                       "first_collective_at_fraction_of_backward": [f for f in fracs if f is not None],
                        "overlap": "phase A from the text-embedding gradient hook, phase B after backward; both on a "
                                   "side stream" + (", captured inside the step graph" if n_graphs else "")}
         arena.grads.zero_()
@@ -614,7 +762,16 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:       # noqa: BLE001
             pass
-        print(json.dumps(out), flush=True)
+        detail_path = None
+        try:
+            with open(a.detail, "w") as f:
+                json.dump(out, f, indent=1)
+            detail_path = a.detail
+        except OSError as e:
+            log(f"detail record not written ({e!r})")
+        sys.stderr.write("[bench detail] " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+        print(json.dumps(compact_line(out, detail_path)), flush=True)
 
 
 def side_configs(a):

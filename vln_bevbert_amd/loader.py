@@ -55,13 +55,15 @@ class BucketManager:
     def _on_copy_stream(self):
         return torch.cuda.stream(self.copy_stream) if self.copy_stream is not None else _NullCtx()
 
-    def _wait_free(self, sb):
-        """Block until the consumer has released ``sb``; then order the copy stream behind the step that read it."""
+    def _wait_free(self, sb, stop=None):
+        """Block until the consumer has released ``sb``; then order the copy stream behind the step that read it.
+        ``stop``: the calling loader's own stop token (a threading.Event)."""
         t0 = time.perf_counter()
         with self._cv:
             while getattr(sb, "in_use", False):
-                if self.stopped:
-                    raise LoaderStopped("BucketManager.stop(): the consumer is gone")
+                if self.stopped or (stop is not None and stop.is_set()):
+                    raise LoaderStopped("the consumer of this loader is gone" if not self.stopped else
+                                        "BucketManager.stop(): the manager was shut down")
                 if not self._cv.wait(timeout=1.0) and time.perf_counter() - t0 > self.WAIT_TIMEOUT_S:
                     raise RuntimeError("BucketManager: a buffer set was never released (call release(sb) after the step "
                                        "on it has been enqueued); depth must be >= 2 for the producer to run ahead")
@@ -72,9 +74,10 @@ class BucketManager:
             done.synchronize()                          # host order: the host-side fields are rewritten below too
         self.stats["wait_s"] += time.perf_counter() - t0      # time spent waiting (consumer + GPU), not loader work
 
-    def acquire(self, task, batch, grid_keys=None):
+    def acquire(self, task, batch, grid_keys=None, stop=None):
         """Device-resident StaticBatch holding ``batch`` (host tensors, collate schema).  Blocks while the buffer set it
-        is about to overwrite is still held by the consumer or read by an earlier step."""
+        is about to overwrite is still held by the consumer or read by an earlier step; ``stop`` (a threading.Event owned
+        by the calling loader) ends such a wait with LoaderStopped."""
         t0 = time.perf_counter()
         host = StaticBatch.plan(self.cfg, task, batch)
         sig = host["signature"]
@@ -87,7 +90,7 @@ class BucketManager:
                 old_sig = next(iter(self.buckets))
                 old = self.buckets[old_sig]
                 for sb in old["sets"]:
-                    self._wait_free(sb)
+                    self._wait_free(sb, stop)
                 del self.buckets[old_sig]
                 self.stats["buckets_evicted"] += 1
         self.buckets.move_to_end(sig)
@@ -101,7 +104,7 @@ class BucketManager:
         else:
             sb = b["sets"][b["next"] % self.depth]
             b["next"] += 1
-            self._wait_free(sb)
+            self._wait_free(sb, stop)
             with self._on_copy_stream():
                 sb.load(batch, grid_keys=grid_keys, host=host)
                 sb.ready = self._record()
@@ -121,9 +124,17 @@ class BucketManager:
         return ev
 
     def stop(self):
-        """The consumer is done (StreamingLoader.close): wake a producer that waits for a buffer set."""
+        """Shut the MANAGER down for good: every producer waiting for a buffer set gives up.  A loader that ends does not
+        call this (the flag used to be set by StreamingLoader.close and never cleared, so the second loader on
+        the same manager -- the next epoch, same buckets, same captured graphs -- lost batches silently at its first
+        back-pressure wait); it sets its own token and calls wake()."""
         with self._cv:
             self.stopped = True
+            self._cv.notify_all()
+
+    def wake(self):
+        """Make waiting producers re-check their stop tokens."""
+        with self._cv:
             self._cv.notify_all()
 
     def release(self, sb):
@@ -159,6 +170,7 @@ class StreamingLoader:
         self.source, self.manager = source, manager
         self.q = queue.Queue(maxsize=max(1, prefetch))
         self._stop = False
+        self._stop_token = threading.Event()        # this loader's own: the manager outlives it (next epoch, same buckets)
         self.error = None
         self.thread = threading.Thread(target=self._produce, daemon=True)
 
@@ -177,12 +189,14 @@ class StreamingLoader:
                 st["source_s"] += time.perf_counter() - t0          # waiting for the collate workers / the dataset
                 task, batch = item[0], item[1]
                 keys = item[2] if len(item) > 2 else None
-                sb = self.manager.acquire(task, batch, grid_keys=keys)
+                sb = self.manager.acquire(task, batch, grid_keys=keys, stop=self._stop_token)
                 t0 = time.perf_counter()
                 self.q.put((task, sb))
                 st["queue_s"] += time.perf_counter() - t0           # waiting for the consumer to take the previous batch
-        except LoaderStopped:
-            pass                        # close() while this thread waited for a buffer set: not an error
+        except LoaderStopped as e:
+            if not self._stop:          # nobody closed THIS loader: the stream must not end as if the source were exhausted
+                self.error = e
+            # else: close() while this thread waited for a buffer set -- not an error
         except Exception as e:          # noqa: BLE001 -- surfaced in the consumer thread
             self.error = e
         self.q.put(None)
@@ -208,7 +222,8 @@ class StreamingLoader:
         waiting for a buffer set the consumer never released -- it stopped early, or raised before release(sb) -- is woken
         up instead of sitting out the two-minute timeout of that wait."""
         self._stop = True
-        self.manager.stop()
+        self._stop_token.set()
+        self.manager.wake()
         while self.thread.is_alive():
             try:
                 item = self.q.get(timeout=0.1)

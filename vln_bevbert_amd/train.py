@@ -93,7 +93,8 @@ class GradReducer:
         self._phase_a_done = False
         self._done = []          # [lo, hi) regions already issued in this step
         self.occupied = None     # sorted (start, end) of the tensors in the buffer (set_occupied): padding gaps are skipped
-        self.timeline = None     # set to [] to collect (lo, hi, start event, end event) per region (bench.py's rccl block)
+        self.timeline = None     # set to [] to collect (lo, hi, start event, end event) per region (bench.py's rccl block);
+                                 # both events sit on the reducer's stream, the end one right behind its own collective
 
     def drop_pending(self):
         """Forget the collectives of an aborted step (failed graph capture): the step is issued again eagerly."""
@@ -118,16 +119,15 @@ class GradReducer:
         if self.occupied is not None:
             # tensors start on 1024-element boundaries: between two regions that end / start on tensor borders lies padding
             # that no kernel writes -- not worth a collective of its own (r05: eight zero-size launches per step)
-            import bisect
-            starts = self._occ_starts
-            keep = []
-            for lo, hi in gaps:
-                i = bisect.bisect_right(starts, lo) - 1
-                hit = (i >= 0 and self.occupied[i][1] > lo) or (i + 1 < len(starts) and starts[i + 1] < hi)
-                if hit:
-                    keep.append((lo, hi))
-            gaps = keep
+            gaps = [(lo, hi) for lo, hi in gaps if self._holds_a_tensor(lo, hi)]
         return gaps
+
+    def _holds_a_tensor(self, lo, hi):
+        if self.occupied is None:
+            return True
+        import bisect
+        i = bisect.bisect_right(self._occ_starts, lo) - 1
+        return (i >= 0 and self.occupied[i][1] > lo) or (i + 1 < len(self._occ_starts) and self._occ_starts[i + 1] < hi)
 
     def set_occupied(self, slices):
         """slices: iterable of (offset, numel) of the tensors living in the flat buffer (ParamArena.slices.values())."""
@@ -173,6 +173,13 @@ class GradReducer:
                     self._exchange_bf16(view)                  # stream-ordered on the reducer's stream
                 else:
                     self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.timeline is not None:
+                    # the collective runs on the process group's own stream: join it into the reducer's stream now (a
+                    # device-side wait, the host goes on) so that the END event is this region's completion and not, as
+                    # until round 5, "after every collective of the step had been issued"
+                    if self._works and self.exchange == "fp32":
+                        self._works[-1].wait()
+                    e1.record(self.stream)
         elif self.exchange != "fp32":
             self._exchange_bf16(view)
         else:
@@ -182,7 +189,7 @@ class GradReducer:
         """Reduce what has not been issued yet of [lo, hi) (regions inside it may have gone out from earlier hooks)."""
         for a, b in self._remaining():
             a, b = max(a, int(lo)), min(b, int(hi))
-            if b > a:
+            if b > a and self._holds_a_tensor(a, b):      # the clipped piece of a kept gap may be padding only
                 self.launch_region(a, b)
 
     def phase_a(self, *_):
@@ -200,14 +207,6 @@ class GradReducer:
             for w in self._works:
                 w.wait()
             if self.stream is not None:
-                if self.timeline:
-                    # every region's end event goes out after ALL collectives were issued (they run in order on the
-                    # stream): the events then read "region k finished no later than"; good enough to see the overlap
-                    with torch.cuda.stream(self.stream):
-                        for _, _, _, e1 in self.timeline:
-                            if not getattr(e1, "_rec", False):
-                                e1.record(self.stream)
-                                e1._rec = True
                 torch.cuda.current_stream().wait_stream(self.stream)
         self._works = []
         self._phase_a_done = False
@@ -280,7 +279,12 @@ class PretrainTrainer:
         out = {}
         heads = [(o, o + k) for n, (o, k) in arena.slices.items() if not n.startswith("bert.")]
         if heads:
-            out["heads"] = (min(lo for lo, _ in heads), max(hi for _, hi in heads))
+            lo, hi = min(lo for lo, _ in heads), max(hi for _, hi in heads)
+            # same rule as for the x-layer runs below: the span goes out from the FIRST x-layer hook, so an
+            # encoder tensor registered between two heads would be reduced before its gradient is final -- then the heads
+            # stay with the catch-all of phase A instead
+            if not any(n.startswith("bert.") and lo <= o < hi for n, (o, c) in arena.slices.items()):
+                out["heads"] = (lo, hi)
         for enc in ("local", "global"):
             mod = getattr(model.bert, f"{enc}_encoder").encoder
             kv = {n for group in mod.arena_groups(f"bert.{enc}_encoder.encoder.") for n in group}

@@ -991,14 +991,18 @@ def ensure_arena(module):
     elif arena.publish_grads:
         arena.maybe_lazy_zero()
         arena.maybe_refresh_shadow()
+    # the residual-stream mode belongs to the model (finalize() of a second model in the process used to flip it
+    # under every model finalized earlier): each forward entry installs its own arena's mode in the kernel library's
+    # Python layer; the backward of that forward reads what its autograd nodes saved, not the switch
+    ops.RT.res32 = bool(getattr(arena, "res32", False))
     return arena
 
 
 def finalize(module, device, compute_dtype=torch.float32, residual=None):
     """Move a freshly built / loaded model into a ParamArena on ``device`` and cache the packed views.
     ``residual=torch.float32`` with bf16 compute: the post-norm blocks keep LayerNorm outputs and residual sums in fp32
-    (torch.autocast's arithmetic, pretrain_src/train_r2r.py:256-258) -- a process-wide switch of the kernel library's
-    Python layer (ops.RT.res32), like the attention implementation."""
+    (torch.autocast's arithmetic, pretrain_src/train_r2r.py:256-258).  The mode is stored on the arena (``arena.res32``) and
+    installed in the kernel library's Python layer (ops.RT.res32) at every forward entry (``ensure_arena``)."""
     if compute_dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("compute dtype must be float32 or bfloat16")
     if residual not in (None, torch.float32, torch.bfloat16) or (residual == torch.bfloat16 and compute_dtype != torch.bfloat16):
@@ -1007,6 +1011,7 @@ def finalize(module, device, compute_dtype=torch.float32, residual=None):
     for b in module.buffers():
         b.data = b.data.to(device)
     arena = ParamArena(module, device, compute_dtype, groups=arena_groups(module))
+    arena.res32 = ops.RT.res32
     for name, m in module.named_modules():
         if isinstance(m, _Finalizable):
             m._after_arena(arena, name + "." if name else "")
