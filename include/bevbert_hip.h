@@ -42,6 +42,10 @@ int bevbert_version(void); /* major*10000 + minor*100 + patch */
  * reported by the next launch check of any library in the process); returns the number of errors dropped. */
 int bevbert_hip_error_reset(void);
 const char* bevbert_arch(void);
+/* name of the kernel the calling thread's last bevbert_attn_fwd (backward = 0) / bevbert_attn_bwd (backward = 1) call was
+ * dispatched to ("attn_fwd4", "attn_bwd3", "attn_short_fwd", ...; "" before the first call).  The choice depends on
+ * shape, dtype, dropout and the BEVBERT_ATTN_* environment knobs; tests and bench.py use this to prove which path ran. */
+const char* bevbert_attn_last_path(int backward);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * K1  lift + BEV binning + deterministic scatter-mean.

@@ -571,6 +571,83 @@ def test_attention_short_key_kernels_with_dropout(ops, Lq, Lk, mk, small_fwd, mo
         assert rel_err(a, b_) < 3e-2, (name, rel_err(a, b_))
 
 
+@pytest.mark.parametrize("Lq,Lk,mk,p", [(80, 80, "neg", 0.1), (80, 80, None, 0.0), (36, 36, "inf", 0.1), (20, 20, "neg", 0.1), (20, 80, "neg", 0.1),
+                                         (80, 20, "inf", 0.1), (96, 96, "neg", 0.1), (1, 2, None, 0.1), (16, 16, None, 0.0), (65, 33, "neg", 0.3),
+                                         (5, 96, "neg", 0.1), (95, 7, None, 0.1), (441, 80, "neg", 0.1), (441, 80, "neg", 0.0), (300, 49, None, 0.1)])
+def test_attention_short_kernels_of_round_6(ops, Lq, Lk, mk, p, monkeypatch):
+    """attn_short.hip: the forward for key sequences up to 96 (any query count; keep bits hashed inline for small score
+    matrices, read from the caller's words for the 441 x 80 BEV <- text shape) and the one-pass backward for queries AND
+    keys up to 96 -- every tile-count instantiation (2, 3, 5, 6 on both axes), partial tiles, odd tile counts (the zero
+    half of the last 32-chunk), a single query against two keys -- against fp32 math under the exported mask; the library must
+    say it took these kernels (bevbert_attn_last_path), and with BEVBERT_ATTN_SHORT=0 the kernels of rounds 2-5."""
+    from vln_bevbert_amd import lib
+    L = lib.load()
+    B, dtype = 3, torch.bfloat16
+    q, k, v, km, _, nh = _make_attn_inputs(B, Lq, Lk, mk, False, dtype, seed=7 * Lq + Lk)
+    Lk2 = (Lk + 1) // 2 * 2
+    outs = {}
+    for arm in ("1", "0"):
+        monkeypatch.setenv("BEVBERT_ATTN_SHORT", arm)
+        ops.RT.new_step(4321 + Lq)
+        qi, ki, vi = (t.clone().requires_grad_(True) for t in (q, k, v))
+        o = ops._Attention.apply("sep", qi, ki, vi, km, None, nh, p, 2)
+        path_f = L.bevbert_attn_last_path(0).decode()
+        keep = None
+        if p > 0:
+            keep = ops.dropout_keep_mask(B * nh * Lq * Lk2, p, ops.RT.seed, 0, DEV).view(B, nh, Lq, Lk2)[..., :Lk]
+        qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+        orf = _attn_ref(qr, kr, vr, km, None, nh, keep, p)
+        assert float((o.float() - orf).abs().max()) < 1.5e-2 * max(1.0, float(orf.abs().max())), (arm, path_f)
+        do = torch.randn_like(orf).to(dtype)
+        o.backward(do)
+        torch.cuda.synchronize()
+        orf.backward(do.float())
+        for name, a, b_ in (("dq", qi.grad, qr.grad), ("dk", ki.grad, kr.grad), ("dv", vi.grad, vr.grad)):
+            assert bool(torch.isfinite(a).all()), (arm, name)
+            assert rel_err(a, b_) < 3e-2, (arm, name, rel_err(a, b_))
+        outs[arm] = (path_f, o.detach().clone(), qi.grad.clone())
+    assert outs["1"][0] == "attn_short_fwd" and outs["0"][0] != "attn_short_fwd", (outs["1"][0], outs["0"][0])
+    # the two generations agree far inside the bf16 gate (same mask, same arithmetic order up to the tiling)
+    assert float((outs["1"][1].float() - outs["0"][1].float()).abs().max()) < 2e-2 * max(1.0, float(outs["0"][1].float().abs().max()))
+
+
+def test_attention_short_backward_is_the_dispatched_kernel_and_leaves_other_rows_alone(ops):
+    """The backward dispatch (thread-local path record is read on the thread that issued the call) and the packed-QKV
+    strides the model uses: gradients land in their column slices of the packed buffers, nothing else is written."""
+    from vln_bevbert_amd import lib
+    from vln_bevbert_amd.lib import call, dtype_code, ptr, stream
+    import math
+    L = lib.load()
+    B, Lq, nh, H, p = 4, 80, 12, 768, 0.1
+    torch.manual_seed(3)
+    qkv = torch.randn(B, Lq, 3 * H, device=DEV).bfloat16()
+    q, k, v = qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:]
+    o = torch.empty(B, Lq, H, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, nh, Lq, device=DEV)
+    bits = torch.zeros(ops._drop_bits_words(B, nh, Lq, Lq), dtype=torch.int64, device=DEV)
+    st = ops._strides(q, k, v, o)
+    call("bevbert_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), None, None, st, B, nh, Lq, Lq, 64, 0.125, dtype_code(q), 0,
+         p, 11, 0, ptr(bits), 0, stream())
+    assert L.bevbert_attn_last_path(0) == b"attn_short_fwd"
+    do = torch.randn_like(o)
+    dqkv = torch.full_like(qkv, 7.0)
+    delta = torch.empty_like(lse)
+    stg = ops._strides(q, k, v, o)
+    # gradient buffers share the operand strides (include/bevbert_hip.h): the packed layout of the fused QKV projection
+    dq2, dk2, dv2 = dqkv[..., :H], dqkv[..., H:2 * H], dqkv[..., 2 * H:]
+    call("bevbert_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq2), ptr(dk2), ptr(dv2), None, None,
+         None, stg, B, nh, Lq, Lq, 64, 0.125, dtype_code(q), 0, p, 11, 0, ptr(bits), stream())
+    assert L.bevbert_attn_last_path(1) == b"attn_short_bwd"
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dqkv.float()).all()) and not bool((dqkv == 7.0).any())     # every element written exactly where it belongs
+    Lk2 = Lq
+    keep = ops.dropout_keep_mask(B * nh * Lq * Lk2, p, 11, 0, DEV).view(B, nh, Lq, Lk2)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    orf = _attn_ref(qr, kr, vr, None, None, nh, keep, p)
+    orf.backward(do.float())
+    assert rel_err(dq2, qr.grad) < 3e-2 and rel_err(dk2, kr.grad) < 3e-2 and rel_err(dv2, vr.grad) < 3e-2
+
+
 @pytest.mark.parametrize("B,Lq,Lk,mk,p,wgs", [(2, 441, 441, None, 0.1, "5"), (2, 441, 441, "neg", 0.0, "24"), (1, 300, 290, "inf", 0.1, "3"),
                                              (3, 500, 448, "neg", 0.1, "7"), (2, 257, 385, None, 0.1, "1")])
 def test_attention_persistent_forward_of_the_long_shapes(ops, B, Lq, Lk, mk, p, wgs, monkeypatch):

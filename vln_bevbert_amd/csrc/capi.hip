@@ -59,12 +59,22 @@ int attn_small_bwd(const AttnArgs& a, hipStream_t st);
 bool attn_small_bwd_supported(const AttnArgs& a);
 int attn_small_bwd2(const AttnArgs& a, hipStream_t st);
 bool attn_small_bwd2_supported(const AttnArgs& a);
+int attn_short_fwd(const AttnArgs& a, bool bits_ready, hipStream_t st);
+bool attn_short_fwd_supported(const AttnArgs& a, bool bits_ready);
+int attn_short_bwd(const AttnArgs& a, hipStream_t st);
+bool attn_short_bwd_supported(const AttnArgs& a);
 
 // The keep-bit workspace of a call holds the matrix three times: [forward layout | backward layout | per-lane layout of
 // attn_fwd4.hip], see attn_fwd2.hip
 static int64_t bits_words_one(int B, int nh, int Lq, int Lk) {
   return (int64_t)B * nh * ((Lq + 127) / 128 * 8) * ((Lk + 63) / 64) * 16;
 }
+
+// Which kernel the last bevbert_attn_fwd / _bwd call of this thread was dispatched to (the choice depends on shape,
+// dtype, dropout and the environment knobs): test / bench introspection, bevbert_attn_last_path().
+static thread_local const char* g_attn_path[2] = {"", ""};
+#define ATTN_PATH(dir, name, expr) (g_attn_path[dir] = (name), (expr))
+BEVBERT_API const char* bevbert_attn_last_path(int backward) { return g_attn_path[backward ? 1 : 0]; }
 
 static bool small_kernels_on() {
   const char* v = getenv("BEVBERT_ATTN_SMALL");
@@ -122,7 +132,11 @@ BEVBERT_API int bevbert_attn_fwd(const void* q, const void* k, const void* v, vo
     // BEVBERT_ATTN_SMALL=1 (read per call): short key sequences without a graph bias go to the one-tile-set kernels of
     // attn_small.hip.  Measured (r03y, B = 64, 80 x 80, p = 0.1): 17.6 us against 12.3 + 5.9 us (tiled forward + bit
     // generation), backward 30.6 against 27.7 us -- no gain, so the tiled kernels stay the default.
-    if (!gen1 && small_kernels_on() && attn_small_fwd_supported(a)) return attn_small_fwd(a, stream);
+    // round 6: key sequences up to 96 without a graph bias (text, panoramas, global map, BEV <- text): attn_short.hip, one
+    // round of workgroups per launch; BEVBERT_ATTN_SHORT=0 falls through to the kernels of rounds 2-5
+    if (!gen1 && !small_kernels_on() && attn_short_fwd_supported(a, bits_ready != 0))
+      return ATTN_PATH(0, "attn_short_fwd", attn_short_fwd(a, bits_ready != 0, stream));
+    if (!gen1 && small_kernels_on() && attn_small_fwd_supported(a)) return ATTN_PATH(0, "attn_small_fwd", attn_small_fwd(a, stream));
     // Small score matrices with dropout (text 80 x 80, panoramas 36 x 36, the global map): their kernels are bound by
     // launch latency, the inline hash of the round-2 forward hides in it, and that forward leaves the keep bits behind
     // for the backward anyway -- a separate bit-generation launch per site only adds launches (35 of 71 per three steps).
@@ -134,15 +148,15 @@ BEVBERT_API int bevbert_attn_fwd(const void* q, const void* k, const void* v, vo
         rc = attn_drop_bits(a, a.drop_bits, a.drop_bits_b, bits_l, stream);
         if (rc != BB_OK) return rc;
       }
-      if (attn_fwd4_supported(a, bits_l)) return attn_fwd4(a, bits_l, stream);
-      return attn_fwd2(a, stream);
+      if (attn_fwd4_supported(a, bits_l)) return ATTN_PATH(0, "attn_fwd4", attn_fwd4(a, bits_l, stream));
+      return ATTN_PATH(0, "attn_fwd2", attn_fwd2(a, stream));
     }
-    return attn_mfma_fwd(a, stream);
+    return ATTN_PATH(0, "attn_mfma_fwd", attn_mfma_fwd(a, stream));
   }
   // exact arithmetic: fp32 tensors on the fp32 matrix instructions (attn_f32.hip); bf16 storage / BEVBERT_ATTN_F32=simple on
   // the wave-per-row kernels
-  if (attn_f32_supported(a, dtype, false)) return attn_f32_fwd(a, stream);
-  return attn_simple_fwd(a, dtype, stream);
+  if (attn_f32_supported(a, dtype, false)) return ATTN_PATH(0, "attn_f32_fwd", attn_f32_fwd(a, stream));
+  return ATTN_PATH(0, "attn_simple_fwd", attn_simple_fwd(a, dtype, stream));
 }
 
 BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
@@ -169,20 +183,22 @@ BEVBERT_API int bevbert_attn_bwd(const void* q, const void* k, const void* v, co
     static const bool gen1 = [] { const char* v = getenv("BEVBERT_ATTN_BWD"); return v && v[0] == '1'; }();
     // query and key sequences up to 96 (80 x 80 text, 36 x 36 panoramas, 17 x 80 / 80 x 17 map <-> text): independent
     // query-owner / key-owner waves, attn_small.hip.  BEVBERT_ATTN_SMALL_BWD=0 keeps the single-pass kernel (A/B).
-    if (!split && !gen1 && im == 2 && small_bwd2_on() && attn_small_bwd2_supported(a)) return attn_small_bwd2(a, stream);
-    if (!split && !gen1 && small_kernels_on() && im == 2 && attn_small_bwd_supported(a)) return attn_small_bwd(a, stream);
+    if (!split && !gen1 && im == 2 && !small_kernels_on() && attn_short_bwd_supported(a))
+      return ATTN_PATH(1, "attn_short_bwd", attn_short_bwd(a, stream));
+    if (!split && !gen1 && im == 2 && small_bwd2_on() && attn_small_bwd2_supported(a)) return ATTN_PATH(1, "attn_small_bwd2", attn_small_bwd2(a, stream));
+    if (!split && !gen1 && small_kernels_on() && im == 2 && attn_small_bwd_supported(a)) return ATTN_PATH(1, "attn_small_bwd", attn_small_bwd(a, stream));
     // BEVBERT_ATTN_BWD3=0: the round-3 loop of the 7+1-wave kernel (attn_bwd2.hip) where the round-5 one (attn_bwd3.hip)
     // would run -- A/B measurements and the on-GPU cross-check
     static const bool gen3 = [] { const char* v = getenv("BEVBERT_ATTN_BWD3"); return !(v && v[0] == '0'); }();
-    if (!split && !gen1 && gen3 && im == 2 && attn_bwd3_supported(a)) return attn_bwd3(a, stream);
-    if (!split && !gen1 && im == 2 && attn_bwd2_supported(a)) return attn_bwd2(a, stream);
-    if (!split && im == 2 && attn_mfma_bwd1_supported(a)) return attn_mfma_bwd1(a, stream);
-    return attn_mfma_bwd(a, stream);
+    if (!split && !gen1 && gen3 && im == 2 && attn_bwd3_supported(a)) return ATTN_PATH(1, "attn_bwd3", attn_bwd3(a, stream));
+    if (!split && !gen1 && im == 2 && attn_bwd2_supported(a)) return ATTN_PATH(1, "attn_bwd2", attn_bwd2(a, stream));
+    if (!split && im == 2 && attn_mfma_bwd1_supported(a)) return ATTN_PATH(1, "attn_mfma_bwd1", attn_mfma_bwd1(a, stream));
+    return ATTN_PATH(1, "attn_mfma_bwd", attn_mfma_bwd(a, stream));
   }
   rc = attn_delta(a, delta_ws, dtype, stream);
   if (rc != BB_OK) return rc;
-  if (attn_f32_supported(a, dtype, true)) return attn_f32_bwd(a, stream);
-  return attn_simple_bwd(a, dtype, stream);
+  if (attn_f32_supported(a, dtype, true)) return ATTN_PATH(1, "attn_f32_bwd", attn_f32_bwd(a, stream));
+  return ATTN_PATH(1, "attn_simple_bwd", attn_simple_bwd(a, dtype, stream));
 }
 
 // Test hook: materialise the dropout keep-mask the kernels derive from (seed, offset + element index).

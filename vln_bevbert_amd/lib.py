@@ -19,7 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # instructions of the SIMD's other wave while plain ones do (scripts/probes/mfma_valu_overlap.hip,
 # profiles/r05_mfma_valu_overlap_probe.txt).  Measured on that kernel: no difference either way.
 EXTRA_FLAGS = {"attn_fwd4.hip": ["-fno-slp-vectorize"]}
-SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_f32.hip", "attn_mfma.hip", "attn_bwd1.hip", "attn_fwd2.hip", "attn_fwd4.hip", "attn_bwd2.hip", "attn_bwd3.hip", "attn_small.hip", "sap_loss.hip", "graph_nav.hip", "gemm.hip", "capi.hip"]
+SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_f32.hip", "attn_mfma.hip", "attn_bwd1.hip", "attn_fwd2.hip", "attn_fwd4.hip", "attn_bwd2.hip", "attn_bwd3.hip", "attn_small.hip", "attn_short.hip", "sap_loss.hip", "graph_nav.hip", "gemm.hip", "capi.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bevbert_hip.h")
 
 F32, BF16, F16 = 0, 1, 2
@@ -138,6 +138,8 @@ def load():
     lib.bevbert_last_error.restype = ctypes.c_char_p
     lib.bevbert_arch.restype = ctypes.c_char_p
     lib.bevbert_version.restype = _I
+    lib.bevbert_attn_last_path.restype = ctypes.c_char_p
+    lib.bevbert_attn_last_path.argtypes = [_I]
     lib.bevbert_hip_error_reset.restype = _I
     lib.bevbert_colsum_workspace_floats.restype = _I64
     lib.bevbert_colsum_workspace_floats.argtypes = [_I]

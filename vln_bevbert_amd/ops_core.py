@@ -36,6 +36,7 @@ class _Runtime:
 
     SEED = 0x5EED
     trace = None
+    paths = {}            # "bevbert_attn_fwd[Lq=..,Lk=..] -> kernel": count, filled while ``trace`` is armed
     scratch = None
 
     def __init__(self):
@@ -246,6 +247,9 @@ def call(name, *args):
     _raw_call(name, *args)
     e.record()
     RT.trace.setdefault(key, []).append((s, e, args))
+    if name in ("bevbert_attn_fwd", "bevbert_attn_bwd"):       # which kernel the library picked for this shape
+        path = lib.load().bevbert_attn_last_path(int(name.endswith("bwd"))).decode()
+        RT.paths[f"{key} -> {path}"] = RT.paths.get(f"{key} -> {path}", 0) + 1
 
 
 def _gemm(kind, fn, m, n, k):
