@@ -34,6 +34,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32: the fp32 vector rate (MI355X_MICROARCH.md)
 
 
+DEFAULT_RESIDUAL = "fp32"
+
 T_START = time.perf_counter()
 
 
@@ -67,9 +69,10 @@ def parse():
                     help="r2r = BASELINE.json configs[1] (the bench line); rxr (xlm-roberta vocabulary, use --txt-len 160) "
                          "and ce (continuous-environment fork) are side measurements")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--residual", default="", choices=["", "fp32"],
-                    help="bf16 run with an fp32 residual stream (torch.autocast's arithmetic: LayerNorm outputs and residual "
-                         "sums of the post-norm blocks stay fp32; side measurement, the bench line is plain bf16)")
+    ap.add_argument("--residual", default=DEFAULT_RESIDUAL, choices=["fp32", "bf16"],
+                    help="residual stream of the bf16 run: fp32 = torch.autocast's arithmetic (LayerNorm outputs and residual "
+                         "sums of the post-norm blocks stay fp32 next to the bf16 copy the GEMMs read: train_r2r.py:256-258), "
+                         "bf16 = every activation rounded to bf16 (twice the roundings of the reference's autocast run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-pass", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -733,7 +736,7 @@ def main():
                 cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--ragged", "--steps", "22", "--warmup", "11", "--no-side",
                        "--no-cpu-baseline", "--no-kernel-pass", "--no-fwd", "--config", a.config, "--batch", str(a.batch),
                        "--txt-len", str(a.txt_len), "--txt-len-min", str(a.txt_len_min), "--stream-steps", str(a.stream_steps),
-                       "--dtype", a.dtype]
+                       "--dtype", a.dtype, "--residual", a.residual]
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 d = json.loads([ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")][-1])
                 out["sustained_ragged"] = d.get("sustained")
@@ -782,15 +785,17 @@ def side_configs(a):
     one by one once the whole run has used its time budget."""
     import subprocess
     budget_s = float(os.environ.get("BEVBERT_BENCH_SIDE_BUDGET_S", "300"))
-    common = ["--steps", "11", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-pass", "--no-stream", "--no-side", "--no-fwd"]
+    common = ["--steps", "22", "--warmup", "11", "--no-cpu-baseline", "--no-kernel-pass", "--no-stream", "--no-side", "--no-fwd"]
     jobs = [("rxr_b32_len160", [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "rxr", "--txt-len", "160",
                                 "--batch", "32"] + common),
             ("ce_b64", [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "ce"] + common),
             # the reference's DEFAULT precision (configs/r2r_pretrain.json "fp16": false): fp32 tensors, fp32 library GEMMs,
             # attention on the fp32 matrix instructions (attn_f32.hip)
             ("r2r_b64_fp32", [sys.executable, os.path.join(ROOT, "bench.py"), "--dtype", "fp32"] + common),
-            # bf16 GEMM / attention operands around an fp32 residual stream: what torch.autocast computes (train_r2r.py:256-258)
-            ("r2r_b64_bf16_fp32_residual", [sys.executable, os.path.join(ROOT, "bench.py"), "--residual", "fp32"] + common),
+            # the other bf16 mode: every activation rounded to bf16 (the bench line of rounds 1-5) when the line runs the fp32
+            # residual stream of torch.autocast (train_r2r.py:256-258), and the other way round
+            ("r2r_b64_bf16_residual_" + ("bf16" if a.residual == "fp32" else "fp32"),
+             [sys.executable, os.path.join(ROOT, "bench.py"), "--residual", "bf16" if a.residual == "fp32" else "fp32"] + common),
             ("finetune_rollout_b32_15steps_infer", [sys.executable, os.path.join(ROOT, "scripts", "bench_nav.py"), "--batch", "32",
                                                     "--steps", "15", "--iters", "4", "--warmup", "3", "--mode", "infer"]),
             # the same rollout with the agent's action feedback: logits read back and argmaxed on the host every step

@@ -76,6 +76,13 @@ print(f"{'class':7s} {'calls/step':>10s} {'ms/step':>9s} {'avg_us':>9s} {'%':>6s
 for n, (c, t) in sorted(by_k.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"{cls(n):7s} {c / K:10.1f} {t / 1e6 / K:9.3f} {t / 1e3 / c:9.2f} {100 * t / tot:6.2f}  {n[:110]}")
 
+# every PyTorch eager kernel left in the step (<= 10 at::native launches per step)
+print()
+tk = [(n, c, t) for n, (c, t) in by_k.items() if cls(n) == "torch"]
+print(f"PyTorch eager kernels in the step: {sum(c for _, c, _ in tk) / K:.1f} launches/step, {sum(t for _, _, t in tk) / 1e6 / K:.3f} ms/step")
+for n, c, t in sorted(tk, key=lambda x: -x[2]):
+    print(f"  {c / K:6.1f} calls/step {t / 1e3 / c:8.2f} us avg {t / 1e6 / K:7.3f} ms/step  {n[:150]}")
+
 # The hand-written kernels per PROBLEM: one kernel symbol serves several shapes of a step (attn_bwd2_kernel: the 441 x 441
 # BEV self-attention and the 80 x 441 text <- BEV cross-attention share a symbol AND a launch grid).  The kernel trace
 # carries no kernel arguments, so launches are keyed by (symbol, grid) and then split into duration clusters (sorted

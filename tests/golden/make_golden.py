@@ -516,6 +516,92 @@ def gen_autocast_errors(ref, cfg, tag, B, seed, ragged, arrs, obj_tasks=None):
         print(f"   {k:60s} rel-L2 {l2:.3e}")
 
 
+FULLSIZE = dict(fwd_batch=64, fwd_seed=3000, bwd_batch=16, bwd_seed=3100, txt_len=80,
+                grad_keys=("bert.local_encoder.encoder.x_layers.0.visn_inter.dense.weight",
+                           "bert.lang_encoder.layer.0.attention.self.query.weight",
+                           "bert.local_encoder.bev_fts_embeddings.0.weight", "global_sap_head.net.0.weight",
+                           "bert.embeddings.word_embeddings.weight",
+                           "bert.global_encoder.encoder.x_layers.1.visual_attention.att.key.weight"))
+
+
+def gen_fullsize():
+    """BASELINE.json configs[1] at its real size through the REFERENCE: full R2R model, batch 64,
+    80 tokens -- per-sample SAP and MLM losses (forward, eval); batch 16 -- gradient norm and sub-sampled named
+    gradients; each in fp32 and under the reference's own autocast-bf16 (lift + splat in fp32 on both sides, as in
+    gen_autocast_errors), so that the bf16 gates of tests/test_gpu_model.py::test_full_size_parity_vs_oracle are held to the
+    reference's own error AT THIS SIZE.  Slow (minutes on 8 cores): run on its own with --fullsize."""
+    full = BevBertConfig()
+    ref = build_ref_pretrain(full)
+    F_ = FULLSIZE
+    arrs = {"fwd_batch": np.int64(F_["fwd_batch"]), "fwd_seed": np.int64(F_["fwd_seed"]), "bwd_batch": np.int64(F_["bwd_batch"]),
+            "bwd_seed": np.int64(F_["bwd_seed"]), "txt_len": np.int64(F_["txt_len"])}
+    orig = ref.lift_splat
+
+    def lift_fp32(batch):
+        with torch.autocast("cpu", enabled=False):
+            return orig(batch)
+
+    def forward_losses():
+        out = {}
+        with torch.no_grad():
+            for task in ("sap", "mlm"):
+                b = synthetic.make_batch(full, task, F_["fwd_batch"], seed=F_["fwd_seed"], txt_len=F_["txt_len"])
+                out[f"{task}_loss"] = ref(dict(b), task, True).float()
+        return out
+
+    def grads():
+        out = {}
+        for task in ("sap", "mlm"):
+            ref.zero_grad(set_to_none=True)
+            b = synthetic.make_batch(full, task, F_["bwd_batch"], seed=F_["bwd_seed"], txt_len=F_["txt_len"])
+            ref(dict(b), task, True).mean().backward()
+            for k, p_ in ref.named_parameters():
+                if k in F_["grad_keys"]:
+                    out[f"{task}_grad::{k}"] = None if p_.grad is None else sub(p_.grad.float(), 97 if p_.numel() > 4096 else 1)
+            out[f"{task}_grad_sqnorm"] = np.float64(sum(float((p_.grad.double() ** 2).sum()) for p_ in ref.parameters()
+                                                        if p_.grad is not None))
+        ref.zero_grad(set_to_none=True)
+        return out
+
+    import time
+    t0 = time.perf_counter()
+    want = forward_losses()
+    print(f"  reference fp32 forward at batch {F_['fwd_batch']}: {time.perf_counter() - t0:.1f} s")
+    t0 = time.perf_counter()
+    want_g = grads()
+    print(f"  reference fp32 forward + backward at batch {F_['bwd_batch']}: {time.perf_counter() - t0:.1f} s")
+    ref.lift_splat = lift_fp32
+    try:
+        t0 = time.perf_counter()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            got = forward_losses()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            got_g = grads()
+        print(f"  the same under autocast-bf16: {time.perf_counter() - t0:.1f} s")
+    finally:
+        del ref.lift_splat
+    for k, w in want.items():
+        arrs[k] = npy(w)
+        w64, g64 = npy(w).astype(np.float64), npy(got[k]).astype(np.float64)
+        scale = max(1e-6, np.abs(w64).max())
+        arrs[f"ref_autocast::{k}::max_rel"] = np.float64(np.abs(w64 - g64).max() / scale)
+        arrs[f"ref_autocast::{k}::mean_rel"] = np.float64(np.abs(w64 - g64).mean() / scale)
+        print(f"   {k:12s} n={w64.size:5d} reference autocast max-abs/absmax {np.abs(w64 - g64).max() / scale:.3e}")
+    for k, w in want_g.items():
+        if w is None:
+            continue
+        if k.endswith("_grad_sqnorm"):
+            arrs[k] = w
+            arrs[f"ref_autocast::{k}::rel"] = np.float64(abs(got_g[k] - w) / w)
+            continue
+        arrs[k] = np.asarray(w, dtype=np.float32)
+        w64, g64 = np.asarray(w, dtype=np.float64), np.asarray(got_g[k], dtype=np.float64)
+        l2 = np.linalg.norm(g64 - w64) / max(1e-12, np.linalg.norm(w64))
+        arrs[f"ref_autocast::{k}::rel_l2"] = np.float64(l2)
+        print(f"   {k:80s} reference autocast rel-L2 {l2:.3e}")
+    save("tasks_r2r_fullsize", **arrs)
+
+
 CURVE = dict(n_steps=100, batch=2, lr=1e-4, warmup=10, total=200, wd=0.01, betas=(0.9, 0.98), clip=5.0,
              ratio="mlm.5.sap.5.masksem.1", sampler_seed=1, batch_seed0=50)
 
@@ -876,6 +962,9 @@ def main():
         return
     if "--curve" in sys.argv:
         gen_curve()
+        return
+    if "--fullsize" in sys.argv:
+        gen_fullsize()
         return
     if "--modules" in sys.argv or "--autocast" in sys.argv:
         tiny = BevBertConfig.tiny()

@@ -298,3 +298,50 @@ def test_per_module_vectors():
     assert max_abs(R.layer_norm(sd, ip + ".layer_norm", emb), g["img_embed_sum_ln"]) < tol
     be = R.bev_input_embedding(sd, "bert.local_encoder", d["bf"], d["bp"], d["bn"])
     assert max_abs(be.reshape(-1)[::5], g["bev_input_embedding_sub"]) < tol
+
+
+def test_oracle_matches_the_reference_at_full_size():
+    """The oracle against the reference itself at BASELINE.json configs[1]'s real size (tests/golden/tasks_r2r_fullsize.npz,
+    make_golden.py --fullsize): batch 64, 80 tokens, full R2R model -- per-sample SAP and MLM losses; batch 16 -- gradient
+    norm and the sub-sampled named gradients.  bench.py's cpu_baseline times this oracle at these sizes; the GPU suite
+    compares the HIP path with the same file (test_full_size_parity_vs_reference).  ~20 s of CPU."""
+    import os
+    g = load_golden("tasks_r2r_fullsize")
+    cfg = BevBertConfig()
+    keys = "pretrain_state_dict_keys_r2r.txt"
+    sd = rule_state_dict(keys)
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+    try:
+        Bf, Bb, L = int(g["fwd_batch"]), int(g["bwd_batch"]), int(g["txt_len"])
+        for task in ("sap", "mlm"):
+            b = synthetic.make_batch(cfg, task, Bf, seed=int(g["fwd_seed"]), txt_len=L)
+            with torch.no_grad():
+                got = R.pretrain_forward(sd, cfg, b, task).numpy()
+            want = g[f"{task}_loss"]
+            assert got.shape == want.shape
+            assert max_abs(got, want) < FP32_TOL * max(1.0, float(np.abs(want).max())), (task, max_abs(got, want))
+        names = sorted({k.split("::", 1)[1] for k in g.files if "_grad::" in k and not k.startswith("ref_autocast")})
+        for task in ("sap", "mlm"):
+            b = synthetic.make_batch(cfg, task, Bb, seed=int(g["bwd_seed"]), txt_len=L)
+            osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+            osd["mlm_head.predictions.decoder.weight"] = osd["bert.embeddings.word_embeddings.weight"]
+            loss = R.pretrain_forward(osd, cfg, b, task).mean()
+            allp = list({id(v): v for v in osd.values()}.values())
+            grads = torch.autograd.grad(loss, allp, allow_unused=True)
+            sq = float(sum((x.double() ** 2).sum() for x in grads if x is not None))
+            ref_sq = float(g[f"{task}_grad_sqnorm"])
+            assert abs(sq - ref_sq) < 1e-3 * ref_sq, (task, sq, ref_sq)
+            by_id = {id(p_): x for p_, x in zip(allp, grads)}
+            for n in names:
+                gk = f"{task}_grad::{n}"
+                x = by_id[id(osd[n])]
+                if gk not in g.files:
+                    assert x is None, gk                      # the reference left .grad None for it as well
+                    continue
+                got = sub(x, 97 if x.numel() > 4096 else 1)
+                scale = max(1e-6, float(np.abs(g[gk]).max()))
+                assert max_abs(got, g[gk]) < 1e-3 * scale + 1e-7, (gk, max_abs(got, g[gk]), scale)
+            del grads, loss, osd
+    finally:
+        torch.set_num_threads(old)

@@ -231,6 +231,8 @@ class PretrainTrainer:
         # Measured in one call on one MI355X at batch 64: eager 18.83, graph with the weight-gradient stream only 19.32,
         # + branch stream 18.58 ms/step.  BEVBERT_GRAPH_BRANCHES=0 turns it off.
         self.graph_branches = os.environ.get("BEVBERT_GRAPH_BRANCHES", "1") == "1"
+        # the gradient-arena fill runs on a side stream beside the forward pass (arena.zero_grad); BEVBERT_OVERLAP_ZERO=0: in line
+        self.overlap_zero = os.environ.get("BEVBERT_OVERLAP_ZERO", "1") == "1" and arena.device.type == "cuda"
         self.graph_error = None            # set (and use_graphs cleared) if a capture ever fails
         self._graph_pool = None
         first_map = min(arena.slices[n][0] for n in arena.slices
@@ -397,11 +399,14 @@ class PretrainTrainer:
 
     def _forward_backward(self, task, batch):
         self._reset_map_hooks()
-        self.arena.zero_grad()
-        if isinstance(batch, StaticBatch):
-            loss = self.model.loss_mean(batch.tensors, task)
-        else:
-            loss = self.model(batch, task, compute_loss=True).mean()                 # train_r2r.py:263
+        self.arena.zero_grad(overlap=self.overlap_zero)
+        try:
+            if isinstance(batch, StaticBatch):
+                loss = self.model.loss_mean(batch.tensors, task)
+            else:
+                loss = self.model(batch, task, compute_loss=True).mean()             # train_r2r.py:263
+        finally:
+            self.arena.wait_zero()             # (also on an exception: a capture can only end with every stream joined)
         if self.reducer is not None and self.reducer.timeline is not None:           # bench.py's region timeline
             self.backward_start = torch.cuda.Event(enable_timing=True)
             self.backward_start.record()
