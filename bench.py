@@ -126,9 +126,9 @@ def algorithmic_work(key, args, esize):
     if key == "bevbert_layernorm_bwd":
         rows, H = args[11], args[12]
         return 0.0, rows * H * esize * (2 + (args[5] is not None) + (args[6] is not None))
-    if key == "bevbert_bias_gelu_fwd":
+    if key in ("bevbert_bias_gelu_fwd", "bevbert_bias_relu_fwd"):
         return 0.0, args[3] * args[4] * esize * 2
-    if key == "bevbert_bias_gelu_bwd":
+    if key in ("bevbert_bias_gelu_bwd", "bevbert_bias_relu_bwd"):
         return 0.0, args[6] * args[7] * esize * 3
     if key == "bevbert_colsum":
         return 0.0, args[3] * args[4] * esize

@@ -185,6 +185,16 @@ int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const 
 int bevbert_embedding_grad(const int64_t* ids, const void* d, float* table_grad, int rows, int H, int padding_idx,
                            int dtype, hipStream_t stream);
 
+/* Row selection of activations and its backward (the reference indexes with boolean masks / index tensors:
+ * pretrain_src/model/pretrain_cmt.py:254-256 masked tokens of the MLM head, :321-326 candidate cells of the SAP head, :403-410
+ * supervised cells of the semantic head).  rows_gather: out[i, :] = src[ids[i], :].  rows_scatter: out[t, :] (+)= sum of
+ * d[r, :] over the rows with ids[r] == t, for the ids that occur -- the caller zeroes ``out`` first (bevbert_zero);
+ * accumulate = 1 adds to what the row holds (a second selection from the same tensor).  Duplicate ids are summed by the
+ * first row of the id in ascending row order (no atomics, as bevbert_embedding_grad).  H % 4 == 0, H <= 1024. */
+int bevbert_rows_gather(const void* src, const int64_t* ids, void* out, int rows, int H, int dtype, hipStream_t stream);
+int bevbert_rows_scatter(const int64_t* ids, const void* d, void* out, int rows, int H, int dtype, int accumulate,
+                         hipStream_t stream);
+
 /* backward of nn.Embedding lookups on SMALL tables (vilmodel.py:452 nav_type_embedding, :567 gmap_step_embedding, the
  * token-type row): partials[s][t][:] = sum of d[r, :] over the rows r of slice s (rows_per_slice rows each) with
  * ids[r] == t; ceil(rows / rows_per_slice) slices of table_rows * H floats, folded into the table gradient by the
@@ -198,6 +208,11 @@ int bevbert_embedding_grad_sliced(const int64_t* ids, const void* d, float* part
  * encoder (transformer.py:178).  bwd: dx = dy * gelu'(x + bias) (dx may alias dy), dbias (C) written/accumulated. */
 int bevbert_bias_gelu_fwd(const void* x, const float* bias, void* y, int rows, int C, int dtype, hipStream_t stream);
 int bevbert_bias_gelu_bwd(const void* dy, const void* x, const float* bias, void* dx, float* dbias, float* workspace,
+                          int rows, int C, int dtype, int accumulate, hipStream_t stream);
+/* the same pair with ReLU: the prediction heads' Linear -> ReLU -> LayerNorm -> Linear (pretrain_src/model/pretrain_cmt.py:34-71;
+ * the Linear's bias rides on the activation kernel, its gradient on the activation's backward) */
+int bevbert_bias_relu_fwd(const void* x, const float* bias, void* y, int rows, int C, int dtype, hipStream_t stream);
+int bevbert_bias_relu_bwd(const void* dy, const void* x, const float* bias, void* dx, float* dbias, float* workspace,
                           int rows, int C, int dtype, int accumulate, hipStream_t stream);
 /* out[c] (+)= sum_r dy[r,c]: bias gradients of the projection GEMMs (autograd's grad.sum(0) in the reference). */
 int bevbert_colsum(const void* dy, float* out, float* workspace, int rows, int C, int dtype, int accumulate,
@@ -229,6 +244,9 @@ int bevbert_adamw_step(float* params, const float* grads, float* exp_avg, float*
                        const float* lr_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
                        hipStream_t stream);
 int bevbert_cast_f32(const float* src, void* dst, int64_t n, int dst_dtype, hipStream_t stream);
+/* zero ``bytes`` bytes on the stream with a memset command (optimizer.zero_grad() of the flat gradient arena,
+ * pretrain_src/train_r2r.py:313; a memset node when the step is captured) */
+int bevbert_zero(void* p, int64_t bytes, hipStream_t stream);
 /* sink[i] += sum_{s<S} partials[s*n + i]: reduction of the host-side split-K weight-gradient GEMMs (library batched
  * GEMM over S chunks of the token axis), fused with the accumulation into the fp32 gradient arena. */
 int bevbert_accum_partials(const void* partials, float* sink, int S, int64_t n, int dtype, hipStream_t stream);

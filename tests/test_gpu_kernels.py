@@ -286,6 +286,69 @@ def test_bias_gelu_fwd_bwd(ops, dtype):
     assert rel_err(bias.grad, br.grad) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(1280, 768), (64, 768), (4608, 768), (7, 40)])
+def test_bias_relu_fwd_bwd(ops, dtype, rows, C):
+    """The prediction heads' Linear -> ReLU (pretrain_cmt.py:34-71) with the Linear's bias on the activation kernel:
+    relu(x + bias) and its backward (dx = dy where x + bias > 0; the bias gradient is the column sum of dx)."""
+    torch.manual_seed(rows + C)
+    x = torch.randn(rows, C, device=DEV).to(dtype).requires_grad_(True)
+    bias = (0.3 * torch.randn(C, device=DEV)).requires_grad_(True)
+    y = ops.bias_relu(x, bias)
+    xr = x.detach().float().requires_grad_(True)
+    br = bias.detach().clone().requires_grad_(True)
+    yr = torch.relu(xr + br)
+    assert float((y.float() - yr).abs().max()) <= (0.0 if dtype == torch.float32 else 2 ** -8 * float(yr.abs().max()))
+    assert torch.equal(y == 0, yr == 0)
+    dy = torch.randn(rows, C, device=DEV).to(dtype)
+    y.backward(dy)
+    yr.backward(dy.float())
+    assert torch.equal(x.grad.float(), xr.grad.to(dtype).float())           # a selection: exact in either dtype
+    assert rel_err(bias.grad, br.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_take_rows_gather_and_deterministic_scatter(ops, dtype):
+    """ops.take_rows (index_select of activation rows + its backward): duplicates -- two candidate views in one BEV cell,
+    the zero-weight padding rows of a static batch that all point at row 0 -- are summed in row order without atomics,
+    bit-reproducibly; a second selection from the same tensor (the centre cell) lands in the same gradient tensor."""
+    torch.manual_seed(5)
+    N, H = 28224, 768
+    x = torch.randn(N, H, device=DEV).to(dtype).requires_grad_(True)
+    idx = torch.randint(0, N, (4608,), device=DEV)
+    idx[100:140] = idx[7]                                   # 41 duplicates of one row
+    idx[-300:] = 0                                          # padding rows
+    idx2 = torch.cat([idx[:5], torch.randint(0, N, (59,), device=DEV)])      # overlaps the first selection
+    a, b = ops.take_rows(x, idx, idx2)
+    assert torch.equal(a, x.detach()[idx]) and torch.equal(b, x.detach()[idx2])
+    da, db = torch.randn_like(a), torch.randn_like(b)
+    (a * da).sum().backward(retain_graph=True)
+    g1 = x.grad.clone()
+    x.grad = None
+    ((a * da).sum() + (b * db).sum()).backward()
+    g2 = x.grad.clone()
+    ref1 = torch.zeros(N, H, device=DEV, dtype=torch.float64).index_add_(0, idx, da.double())
+    ref2 = ref1.clone().index_add_(0, idx2, db.double())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(g1, ref1) < tol and rel_err(g2, ref2) < tol
+    untouched = torch.ones(N, dtype=torch.bool, device=DEV)
+    untouched[idx] = False
+    untouched[idx2] = False
+    assert float(g2[untouched].abs().max()) == 0.0
+    # bit-reproducible
+    x.grad = None
+    a2, b2 = ops.take_rows(x, idx, idx2)
+    ((a2 * da).sum() + (b2 * db).sum()).backward()
+    assert torch.equal(x.grad, g2)
+    # one selection, other widths
+    y = torch.randn(50, 40, device=DEV).to(dtype).requires_grad_(True)
+    ii = torch.tensor([3, 3, 49, 0, 3], device=DEV)
+    r = ops.take_rows(y, ii)
+    assert torch.equal(r, y.detach()[ii])
+    r.sum().backward()
+    assert float(y.grad[3].float().mean()) == 3.0 and float(y.grad[1].abs().max()) == 0.0
+
+
 def test_embed_sum_layernorm(ops):
     torch.manual_seed(3)
     V, H, B, L = 500, 768, 3, 17

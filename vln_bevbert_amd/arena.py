@@ -254,9 +254,11 @@ class ParamArena:
                     self._zero_stream = torch.cuda.Stream(self.device)
                 self._zero_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self._zero_stream):
-                    self.grads.zero_()
+                    call("bevbert_zero", ptr(self.grads), self.grads.numel() * 4, stream())
                 self._zero_pending = True
                 return
+            call("bevbert_zero", ptr(self.grads), self.grads.numel() * 4, stream())
+            return
         self.grads.zero_()
 
     def wait_zero(self):

@@ -421,7 +421,19 @@ __global__ __launch_bounds__(1024) void multi_finalize_kernel(const FinalizeTask
 // loaded once) and walks CONTIGUOUS rows with 8 independent loads in flight.  The first version -- a flat grid-stride
 // loop, one chunk per thread and iteration, the column recomputed as (i * 4) % C on a 64-bit index (~60 instructions
 // per chunk) -- ran at 3.2 TB/s.
-template <typename T>
+// ACT 0: erf-GELU (BertIntermediate, vilmodel.py:31-37); ACT 1: ReLU (the prediction heads' Linear - ReLU - LayerNorm - Linear,
+// pretrain_src/model/pretrain_cmt.py:34-71)
+template <typename T, int ACT> __device__ __forceinline__ float4 act4_of(float4 a, float4 b) {
+  if (ACT == 0) return gelu4_of<T>(a, b);
+  return make_float4(fmaxf(a.x + b.x, 0.f), fmaxf(a.y + b.y, 0.f), fmaxf(a.z + b.z, 0.f), fmaxf(a.w + b.w, 0.f));
+}
+template <typename T, int ACT> __device__ __forceinline__ float4 act_grad4_of(float4 d, float4 a, float4 b) {
+  if (ACT == 0) return gelu_grad4_of<T>(d, a, b);
+  return make_float4(a.x + b.x > 0.f ? d.x : 0.f, a.y + b.y > 0.f ? d.y : 0.f, a.z + b.z > 0.f ? d.z : 0.f,
+                     a.w + b.w > 0.f ? d.w : 0.f);
+}
+
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                             T* __restrict__ y, int rows, int C) {
   const int c0 = blockIdx.y * 1024 + threadIdx.x * 4;
@@ -436,9 +448,9 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict_
 #pragma unroll
     for (int k = 0; k < R; ++k) a[k] = ld4<T>(x + (size_t)(r + k) * C + c0);
 #pragma unroll
-    for (int k = 0; k < R; ++k) st4<T>(y + (size_t)(r + k) * C + c0, gelu4_of<T>(a[k], b));
+    for (int k = 0; k < R; ++k) st4<T>(y + (size_t)(r + k) * C + c0, act4_of<T, ACT>(a[k], b));
   }
-  for (; r < rows; ++r) st4<T>(y + (size_t)r * C + c0, gelu4_of<T>(ld4<T>(x + (size_t)r * C + c0), b));
+  for (; r < rows; ++r) st4<T>(y + (size_t)r * C + c0, act4_of<T, ACT>(ld4<T>(x + (size_t)r * C + c0), b));
 }
 
 // bf16, 16-byte accesses: a thread owns 8 columns (128 threads per 1024-column slice)
@@ -480,6 +492,7 @@ __global__ __launch_bounds__(128) void bias_gelu_fwd8_kernel(const bf16_raw* __r
 }
 
 // MODE 0: dx = dy * gelu'(x + bias) ; partial column sums of dx.   MODE 1: plain column sums of dy (no dx).
+// MODE 2: as 0 with ReLU (dx = dy where x + bias > 0).
 // Grid (row groups, column slices of 1024): thread t owns 4 columns and walks its row group 4 rows at a time
 // (8 independent loads per tensor in flight); partials[blockIdx.x][C].
 template <typename T, int MODE>
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(256) void colwise_bwd_kernel(const T* __restrict__ 
   if (c0 >= C) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (MODE == 0) b = *reinterpret_cast<const float4*>(bias + c0);
+  if (MODE != 1) b = *reinterpret_cast<const float4*>(bias + c0);
   // block b owns the CONTIGUOUS rows [b * rpb, (b + 1) * rpb): the eight rows a thread has in flight are neighbours
   const int rpb = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
   const int stride = 1;
@@ -502,12 +515,12 @@ __global__ __launch_bounds__(256) void colwise_bwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       d[k] = ld4<T>(dy + (size_t)(r + k * stride) * C + c0);
-      if (MODE == 0) a[k] = ld4<T>(x + (size_t)(r + k * stride) * C + c0);
+      if (MODE != 1) a[k] = ld4<T>(x + (size_t)(r + k * stride) * C + c0);
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-      if (MODE == 0) {
-        d[k] = gelu_grad4_of<T>(d[k], a[k], b);
+      if (MODE != 1) {
+        d[k] = act_grad4_of<T, MODE == 2 ? 1 : 0>(d[k], a[k], b);
         st4<T>(dx + (size_t)(r + k * stride) * C + c0, d[k]);
       }
       acc.x += d[k].x; acc.y += d[k].y; acc.z += d[k].z; acc.w += d[k].w;
@@ -515,9 +528,9 @@ __global__ __launch_bounds__(256) void colwise_bwd_kernel(const T* __restrict__ 
   }
   for (; r < rows; r += stride) {
     float4 d = ld4<T>(dy + (size_t)r * C + c0);
-    if (MODE == 0) {
+    if (MODE != 1) {
       const float4 a = ld4<T>(x + (size_t)r * C + c0);
-      d = gelu_grad4_of<T>(d, a, b);
+      d = act_grad4_of<T, MODE == 2 ? 1 : 0>(d, a, b);
       st4<T>(dx + (size_t)r * C + c0, d);
     }
     acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
@@ -599,9 +612,12 @@ __global__ __launch_bounds__(256) void multi_accum_kernel(const AccumTask* __res
 // (w0 + w1) + (w2 + w3) and the leader alone read-modify-writes the table row.  The result is a pure function of (ids, d).
 // rows^2 / 256 id comparisons per launch (5 120 rows: the id vector stays in L2).
 #define EG_MAXJ 4          // float4 column groups per lane: H <= 64 lanes * 4 floats * EG_MAXJ = 1024
-template <typename T>
+// TO / ACCUM: the destination rows are fp32 and accumulated into (embedding tables in the gradient arena), or of the
+// activations' type -- rows of a zero-initialised activation gradient, the backward of a row gather (bevbert_rows_scatter):
+// ACCUM false stores the id's sum, true adds it to what the row holds (a second scatter onto the same tensor).
+template <typename T, typename TO = float, bool ACCUM = true>
 __global__ __launch_bounds__(256) void embedding_grad_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d,
-                                                             float* __restrict__ table_grad, int rows, int H,
+                                                             TO* __restrict__ table_grad, int rows, int H,
                                                              int padding_idx) {
   __shared__ int s_flag;
   __shared__ float s_part[4][256 * EG_MAXJ];
@@ -647,15 +663,26 @@ __global__ __launch_bounds__(256) void embedding_grad_kernel(const int64_t* __re
 #pragma unroll
   for (int j = 0; j < EG_MAXJ; ++j) *reinterpret_cast<float4*>(&s_part[wave][(lane + 64 * j) * 4]) = acc[j];
   __syncthreads();
-  float* dst = table_grad + (size_t)id * H;
+  TO* dst = table_grad + (size_t)id * H;
   for (int c = tid * 4; c < H; c += 1024) {
     const float4 p0 = *reinterpret_cast<const float4*>(&s_part[0][c]), p1 = *reinterpret_cast<const float4*>(&s_part[1][c]);
     const float4 p2 = *reinterpret_cast<const float4*>(&s_part[2][c]), p3 = *reinterpret_cast<const float4*>(&s_part[3][c]);
-    float4 t = *reinterpret_cast<const float4*>(dst + c);
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACCUM) t = ld4<TO>(dst + c);
     t.x += (p0.x + p1.x) + (p2.x + p3.x); t.y += (p0.y + p1.y) + (p2.y + p3.y);
     t.z += (p0.z + p1.z) + (p2.z + p3.z); t.w += (p0.w + p1.w) + (p2.w + p3.w);
-    *reinterpret_cast<float4*>(dst + c) = t;
+    st4<TO>(dst + c, t);
   }
+}
+
+// out[i, :] = src[ids[i], :]: one workgroup per output row (index_select of activation rows: the masked tokens of the
+// MLM head, the candidate cells of the SAP head, the supervised cells of the semantic head)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_gather_kernel(const T* __restrict__ src, const int64_t* __restrict__ ids,
+                                                          T* __restrict__ out, int H) {
+  const int64_t id = ids[blockIdx.x];
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4)
+    st4<T>(out + (size_t)blockIdx.x * H + c, ld4<T>(src + (size_t)id * H + c));
 }
 
 // Small tables (2 .. ~128 rows: navigation types, step ids, token types) with MANY gradient rows: the atomic version
@@ -1048,46 +1075,77 @@ BEVBERT_API int bevbert_layernorm_res32_bwd(const void* dy16, const float* dy32,
   return BB_OK;
 }
 
-BEVBERT_API int bevbert_bias_gelu_fwd(const void* x, const float* bias, void* y, int rows, int C, int dtype,
-                                      hipStream_t stream) {
-  BB_REQUIRE(C % 4 == 0, "bias_gelu_fwd: C=%d must be a multiple of 4", C);
+static int bias_act_fwd(const void* x, const float* bias, void* y, int rows, int C, int dtype, int act, hipStream_t stream) {
+  BB_REQUIRE(C % 4 == 0, "bias_act_fwd: C=%d must be a multiple of 4", C);
+  BB_REQUIRE(act == 0 || act == 1, "bias_act_fwd: activation %d (0 erf-GELU, 1 ReLU)", act);
   if (rows <= 0) return BB_OK;
   const dim3 grid(elementwise_row_groups(rows), (C + 1023) / 1024);
-  if (dtype == BB_F32)
-    hipLaunchKernelGGL(bias_gelu_fwd_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, bias, (float*)y, rows, C);
-  else if (dtype == BB_BF16 && C % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0)   // 71 vs 76 us at 28224 x 3072
+  if (dtype == BB_F32 && act == 0)
+    hipLaunchKernelGGL((bias_gelu_fwd_kernel<float, 0>), grid, dim3(256), 0, stream, (const float*)x, bias, (float*)y, rows, C);
+  else if (dtype == BB_F32)
+    hipLaunchKernelGGL((bias_gelu_fwd_kernel<float, 1>), grid, dim3(256), 0, stream, (const float*)x, bias, (float*)y, rows, C);
+  else if (dtype == BB_BF16 && act == 0 && C % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0)   // 71 vs 76 us at 28224 x 3072
     hipLaunchKernelGGL(bias_gelu_fwd8_kernel, grid, dim3(128), 0, stream, (const bf16_raw*)x, bias, (bf16_raw*)y, rows, C);
+  else if (dtype == BB_BF16 && act == 0)
+    hipLaunchKernelGGL((bias_gelu_fwd_kernel<bf16_raw, 0>), grid, dim3(256), 0, stream, (const bf16_raw*)x, bias, (bf16_raw*)y, rows, C);
   else if (dtype == BB_BF16)
-    hipLaunchKernelGGL(bias_gelu_fwd_kernel<bf16_raw>, grid, dim3(256), 0, stream, (const bf16_raw*)x, bias, (bf16_raw*)y, rows, C);
+    hipLaunchKernelGGL((bias_gelu_fwd_kernel<bf16_raw, 1>), grid, dim3(256), 0, stream, (const bf16_raw*)x, bias, (bf16_raw*)y, rows, C);
   else {
-    bb_set_error("bias_gelu_fwd: dtype %d unsupported", dtype);
+    bb_set_error("bias_act_fwd: dtype %d unsupported", dtype);
     return BB_EUNSUPPORTED;
   }
-  BB_CHECK_LAUNCH("bias_gelu_fwd");
+  BB_CHECK_LAUNCH("bias_act_fwd");
   return BB_OK;
+}
+
+static int bias_act_bwd(const void* dy, const void* x, const float* bias, void* dx, float* dbias, float* workspace, int rows,
+                        int C, int dtype, int accumulate, int act, hipStream_t stream) {
+  BB_REQUIRE(C % 4 == 0, "bias_act_bwd: C=%d must be a multiple of 4", C);
+  BB_REQUIRE(act == 0 || act == 1, "bias_act_bwd: activation %d (0 erf-GELU, 1 ReLU)", act);
+  if (rows <= 0) return BB_OK;
+  const int nb = colwise_blocks(rows);
+  const dim3 grid(nb, (C + 1023) / 1024);
+  if (dtype == BB_F32 && act == 0)
+    hipLaunchKernelGGL((colwise_bwd_kernel<float, 0>), grid, dim3(256), 0, stream, (const float*)dy, (const float*)x, bias, (float*)dx, workspace, rows, C);
+  else if (dtype == BB_F32)
+    hipLaunchKernelGGL((colwise_bwd_kernel<float, 2>), grid, dim3(256), 0, stream, (const float*)dy, (const float*)x, bias, (float*)dx, workspace, rows, C);
+  else if (dtype == BB_BF16 && act == 0)
+    hipLaunchKernelGGL((colwise_bwd_kernel<bf16_raw, 0>), grid, dim3(256), 0, stream, (const bf16_raw*)dy, (const bf16_raw*)x, bias, (bf16_raw*)dx, workspace, rows, C);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL((colwise_bwd_kernel<bf16_raw, 2>), grid, dim3(256), 0, stream, (const bf16_raw*)dy, (const bf16_raw*)x, bias, (bf16_raw*)dx, workspace, rows, C);
+  else {
+    bb_set_error("bias_act_bwd: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("bias_act_bwd");
+  if (dbias) {
+    launch_finalize(workspace, nb, 1, C, dbias, nullptr, nullptr, accumulate, stream);
+    BB_CHECK_LAUNCH("bias_act_bwd finalize");
+  }
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_bias_gelu_fwd(const void* x, const float* bias, void* y, int rows, int C, int dtype,
+                                      hipStream_t stream) {
+  return bias_act_fwd(x, bias, y, rows, C, dtype, 0, stream);
 }
 
 BEVBERT_API int bevbert_bias_gelu_bwd(const void* dy, const void* x, const float* bias, void* dx, float* dbias,
                                       float* workspace, int rows, int C, int dtype, int accumulate,
                                       hipStream_t stream) {
-  BB_REQUIRE(C % 4 == 0, "bias_gelu_bwd: C=%d must be a multiple of 4", C);
-  if (rows <= 0) return BB_OK;
-  const int nb = colwise_blocks(rows);
-  const dim3 grid(nb, (C + 1023) / 1024);
-  if (dtype == BB_F32)
-    hipLaunchKernelGGL((colwise_bwd_kernel<float, 0>), grid, dim3(256), 0, stream, (const float*)dy, (const float*)x, bias, (float*)dx, workspace, rows, C);
-  else if (dtype == BB_BF16)
-    hipLaunchKernelGGL((colwise_bwd_kernel<bf16_raw, 0>), grid, dim3(256), 0, stream, (const bf16_raw*)dy, (const bf16_raw*)x, bias, (bf16_raw*)dx, workspace, rows, C);
-  else {
-    bb_set_error("bias_gelu_bwd: dtype %d unsupported", dtype);
-    return BB_EUNSUPPORTED;
-  }
-  BB_CHECK_LAUNCH("bias_gelu_bwd");
-  if (dbias) {
-    launch_finalize(workspace, nb, 1, C, dbias, nullptr, nullptr, accumulate, stream);
-    BB_CHECK_LAUNCH("bias_gelu_bwd finalize");
-  }
-  return BB_OK;
+  return bias_act_bwd(dy, x, bias, dx, dbias, workspace, rows, C, dtype, accumulate, 0, stream);
+}
+
+// The prediction heads' Linear -> ReLU (pretrain_src/model/pretrain_cmt.py:34-71) on the same kernels.
+BEVBERT_API int bevbert_bias_relu_fwd(const void* x, const float* bias, void* y, int rows, int C, int dtype,
+                                      hipStream_t stream) {
+  return bias_act_fwd(x, bias, y, rows, C, dtype, 1, stream);
+}
+
+BEVBERT_API int bevbert_bias_relu_bwd(const void* dy, const void* x, const float* bias, void* dx, float* dbias,
+                                      float* workspace, int rows, int C, int dtype, int accumulate,
+                                      hipStream_t stream) {
+  return bias_act_bwd(dy, x, bias, dx, dbias, workspace, rows, C, dtype, accumulate, 1, stream);
 }
 
 BEVBERT_API int bevbert_colsum(const void* dy, float* out, float* workspace, int rows, int C, int dtype, int accumulate,
@@ -1179,6 +1237,43 @@ BEVBERT_API int bevbert_accum_partials(const void* partials, float* sink, int S,
     return BB_EUNSUPPORTED;
   }
   BB_CHECK_LAUNCH("accum_partials");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_rows_gather(const void* src, const int64_t* ids, void* out, int rows, int H, int dtype,
+                                    hipStream_t stream) {
+  BB_REQUIRE(H % 4 == 0 && H > 0, "rows_gather: H=%d must be a positive multiple of 4", H);
+  if (rows <= 0) return BB_OK;
+  const int nt = H / 4 >= 256 ? 256 : (H / 4 + 63) / 64 * 64;
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL(rows_gather_kernel<float>, dim3(rows), dim3(nt), 0, stream, (const float*)src, ids, (float*)out, H);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL(rows_gather_kernel<bf16_raw>, dim3(rows), dim3(nt), 0, stream, (const bf16_raw*)src, ids, (bf16_raw*)out, H);
+  else {
+    bb_set_error("rows_gather: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("rows_gather");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_rows_scatter(const int64_t* ids, const void* d, void* out, int rows, int H, int dtype, int accumulate,
+                                     hipStream_t stream) {
+  BB_REQUIRE(H % 4 == 0 && H <= 256 * EG_MAXJ, "rows_scatter: H=%d must be a multiple of 4 and <= %d", H, 256 * EG_MAXJ);
+  if (rows <= 0) return BB_OK;
+  if (dtype == BB_F32 && accumulate)
+    hipLaunchKernelGGL((embedding_grad_kernel<float, float, true>), dim3(rows), dim3(256), 0, stream, ids, (const float*)d, (float*)out, rows, H, -1);
+  else if (dtype == BB_F32)
+    hipLaunchKernelGGL((embedding_grad_kernel<float, float, false>), dim3(rows), dim3(256), 0, stream, ids, (const float*)d, (float*)out, rows, H, -1);
+  else if (dtype == BB_BF16 && accumulate)
+    hipLaunchKernelGGL((embedding_grad_kernel<bf16_raw, bf16_raw, true>), dim3(rows), dim3(256), 0, stream, ids, (const bf16_raw*)d, (bf16_raw*)out, rows, H, -1);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL((embedding_grad_kernel<bf16_raw, bf16_raw, false>), dim3(rows), dim3(256), 0, stream, ids, (const bf16_raw*)d, (bf16_raw*)out, rows, H, -1);
+  else {
+    bb_set_error("rows_scatter: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("rows_scatter");
   return BB_OK;
 }
 

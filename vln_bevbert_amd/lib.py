@@ -92,9 +92,13 @@ _PROTOS = {
     "bevbert_layernorm_bwd_add": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U64, _I, _P],
     "bevbert_embed_sum_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _U64, _U64, _P],
     "bevbert_embedding_grad": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "bevbert_rows_gather": [_P, _P, _P, _I, _I, _I, _P],
+    "bevbert_rows_scatter": [_P, _P, _P, _I, _I, _I, _I, _P],
     "bevbert_embedding_grad_sliced": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "bevbert_bias_gelu_fwd": [_P, _P, _P, _I, _I, _I, _P],
     "bevbert_bias_gelu_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "bevbert_bias_relu_fwd": [_P, _P, _P, _I, _I, _I, _P],
+    "bevbert_bias_relu_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "bevbert_colsum": [_P, _P, _P, _I, _I, _I, _I, _P],
     "bevbert_segment_wsum": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "bevbert_grad_norm_clip": [_P, _I64, _F, _F, _P, _P, _P],
@@ -104,6 +108,7 @@ _PROTOS = {
     "bevbert_multi_finalize": [_P, _I, _P],
     "bevbert_multi_accum": [_P, _I, _P],
     "bevbert_cast_f32": [_P, _P, _I64, _I, _P],
+    "bevbert_zero": [_P, _I64, _P],
     "bevbert_accum_partials": [_P, _P, _I, _I64, _I, _P],
     "bevbert_dropout_keep_mask": [_P, _I64, _F, _U64, _U64, _P],
     "bevbert_gemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I, _I, _I, _F, _P,

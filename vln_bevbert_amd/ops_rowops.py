@@ -345,21 +345,25 @@ def cross_entropy_rows(logits, target):
 
 # ----------------------------------------------------------------------------- K4 bias + GELU
 class _BiasGelu(torch.autograd.Function):
+    """act(x + bias); ``act``: "gelu" (erf) or "relu" -- the C ABI has one entry pair per activation."""
+
     @staticmethod
-    def forward(ctx, x, bias):
+    def forward(ctx, x, bias, act="gelu"):
         assert x.is_contiguous()
         C = x.shape[-1]
         rows = x.numel() // C
         y = torch.empty_like(x)
-        call("bevbert_bias_gelu_fwd", ptr(x), ptr(_f32(bias)), ptr(y), rows, C, dtype_code(x), stream())
+        call(f"bevbert_bias_{act}_fwd", ptr(x), ptr(_f32(bias)), ptr(y), rows, C, dtype_code(x), stream())
         ctx.save_for_backward(x)
         ctx.bias = bias
+        ctx.act = act
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         bias = ctx.bias
+        entry = f"bevbert_bias_{ctx.act}_bwd"
         C = x.shape[-1]
         rows = x.numel() // C
         dy = dy.contiguous()
@@ -371,22 +375,70 @@ class _BiasGelu(torch.autograd.Function):
             if WgradStream.DEFER_FINALIZE:      # second reduction stage batched with the step's others (see _BiasDropResLN)
                 nb = _partial_rows(rows)
                 part = RT.scratch.alloc(nb * C * 4, dy.device)
-                call("bevbert_bias_gelu_bwd", ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), None, part, rows, C,
-                     dtype_code(dy), 1, stream())
+                call(entry, ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), None, part, rows, C, dtype_code(dy), 1, stream())
                 ReduceQueue.add(part, nb, 1, C, (ptr(sink), None, None))
-                return dx, None
-            call("bevbert_bias_gelu_bwd", ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), ptr(sink), ptr(ws), rows, C,
-                 dtype_code(dy), 1, stream())
-            return dx, None
+                return dx, None, None
+            call(entry, ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), ptr(sink), ptr(ws), rows, C, dtype_code(dy), 1, stream())
+            return dx, None, None
         db = torch.empty(C, dtype=torch.float32, device=dy.device)
-        call("bevbert_bias_gelu_bwd", ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), ptr(db), ptr(ws), rows, C,
-             dtype_code(dy), 0, stream())
-        return dx, db.to(bias.dtype)
+        call(entry, ptr(dy), ptr(x), ptr(_f32(bias)), ptr(dx), ptr(db), ptr(ws), rows, C, dtype_code(dy), 0, stream())
+        return dx, db.to(bias.dtype), None
+
+
+class _TakeRows(torch.autograd.Function):
+    """rows = x2d[idx] for one or two index vectors of ONE tensor (a second selection from the same activations -- the
+    centre cell next to the candidate cells of the SAP head -- shares the backward's zero-initialised gradient tensor:
+    autograd would otherwise materialise two dense gradients and add them)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, idx2=None):
+        assert x.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous()
+        H = x.shape[-1]
+        outs = []
+        for ix in (idx, idx2):
+            if ix is None:
+                continue
+            o = torch.empty((ix.numel(), H), dtype=x.dtype, device=x.device)
+            call("bevbert_rows_gather", ptr(x), ptr(ix), ptr(o), ix.numel(), H, dtype_code(x), stream())
+            outs.append(o)
+        ctx.save_for_backward(idx, idx2)
+        ctx.shape = x.shape
+        ctx.set_materialize_grads(False)       # an unused selection arrives as None, not as a dense zero tensor
+        return tuple(outs) if idx2 is not None else outs[0]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        idx, idx2 = ctx.saved_tensors
+        some = next((g for g in grads if g is not None), None)
+        if some is None:
+            return None, None, None
+        H = ctx.shape[-1]
+        dx = torch.empty(ctx.shape, dtype=some.dtype, device=some.device)
+        call("bevbert_zero", ptr(dx), dx.numel() * dx.element_size(), stream())
+        first = True
+        for ix, g in zip((idx, idx2), grads):
+            if ix is None or g is None:
+                continue
+            g = g.contiguous()
+            call("bevbert_rows_scatter", ptr(ix), ptr(g), ptr(dx), ix.numel(), H, dtype_code(g), 0 if first else 1, stream())
+            first = False
+        return dx, None, None
+
+
+def take_rows(x, idx, idx2=None):
+    """x.reshape(-1, H)[idx] (and [idx2]) -- pretrain_cmt.py:254-256,321-326,403-410; the backward is a memset and a
+    deterministic scatter (duplicate indices are summed in row order, no atomics)."""
+    return _TakeRows.apply(x.contiguous(), idx, idx2)
 
 
 def bias_gelu(x, bias):
     """gelu_erf(x + bias) -- vilmodel.py:31-37,177-180."""
     return _BiasGelu.apply(x, bias)
+
+
+def bias_relu(x, bias):
+    """relu(x + bias): the prediction heads' Linear -> ReLU (pretrain_cmt.py:34-71), the Linear's bias on the activation."""
+    return _BiasGelu.apply(x, bias, "relu")
 
 
 # ----------------------------------------------------------------------------- K5 embeddings

@@ -45,7 +45,11 @@ class _Head(nn.Module):
 
     def forward(self, x):
         l0, ln, l3 = self.net[0], self.net[2], self.net[3]
-        h = torch.relu(ops.linear(x, l0.weight, l0.bias))
+        if x.is_cuda and l0.weight.shape[0] % 4 == 0:
+            # bias + ReLU in one launch behind the GEMM (forward and backward: the bias gradient rides on the ReLU backward)
+            h = ops.bias_relu(ops.linear(x.contiguous(), l0.weight), l0.bias)
+        else:
+            h = torch.relu(ops.linear(x, l0.weight, l0.bias))
         h = ops.layernorm(h, ln.weight, ln.bias, 1e-12)
         return ops.linear(h, l3.weight, l3.bias)
 
@@ -300,7 +304,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             # loader-built positions of the masked tokens, padded to a fixed count (the padding re-reads row 0 and
             # carries zero weight): no nonzero() sync, no host->device copy inside the step, static GEMM shapes
             pos_in, n = st["mlm_pos"], st["mlm_n"]
-            masked = txt_embeds.reshape(-1, txt_embeds.shape[-1]).index_select(0, pos_in)
+            flat = txt_embeds.reshape(-1, txt_embeds.shape[-1])
+            masked = ops.take_rows(flat, pos_in) if flat.is_cuda else flat.index_select(0, pos_in)
             if compute_loss == "mean":
                 # cross-entropy straight from the head's logits (fp32 statistics, no fp32 copy of rows x vocabulary)
                 per_row = ops.cross_entropy_rows(self.mlm_head(masked), st["mlm_targets"])
@@ -343,11 +348,19 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             # static batch (loader-built fusion table on the device): the whole tail behind the heads -- masks, logit
             # fusion, three cross-entropies and their backward -- is one C-ABI launch each way (ops.sap_loss)
             cand_idxs = b["bev_cand_idxs"]
-            bi = torch.arange(cand_idxs.shape[0], device=cand_idxs.device)[:, None]
             graw = self.global_sap_head(gmap_embeds).squeeze(2)
-            lraw = self.local_sap_head(bev_embeds[bi, cand_idxs]).squeeze(2)
-            fraw = None if self.sap_fuse_linear is None else self.sap_fuse_linear(
-                torch.cat([gmap_embeds[:, 0], bev_embeds[:, center]], 1))
+            if "sap_cand_flat" in st:
+                # loader-built flat row numbers of the candidate cells and of the centre cell: one row gather each, and ONE
+                # zero-initialised gradient of the BEV states in backward (ops.take_rows) instead of an index_put, a slice
+                # gradient and their sum over 28 224 rows
+                Bc, Kc = cand_idxs.shape
+                cand, cen = ops.take_rows(bev_embeds.reshape(-1, bev_embeds.shape[-1]), st["sap_cand_flat"], st["sap_center_flat"])
+                cand = cand.view(Bc, Kc, -1)
+            else:
+                bi = torch.arange(cand_idxs.shape[0], device=cand_idxs.device)[:, None]
+                cand, cen = bev_embeds[bi, cand_idxs], bev_embeds[:, center]
+            lraw = self.local_sap_head(cand).squeeze(2)
+            fraw = None if self.sap_fuse_linear is None else self.sap_fuse_linear(torch.cat([gmap_embeds[:, 0], cen], 1))
             loss = ops.sap_loss(graw, lraw, fraw, b["gmap_visited_masks"], b["gmap_lens"], b["bev_nav_masks"],
                                 cand_idxs, st["sap_src"], st["sap_vis_c"], b["global_act_labels"],
                                 b["local_act_labels"])
@@ -398,7 +411,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             idx = torch.nonzero_static(flat, size=cap, fill_value=0).squeeze(1)
             count = flat.sum()
             valid = (torch.arange(cap, device=flat.device) < count).to(torch.float32)
-            masked = bev_embeds.reshape(-1, bev_embeds.shape[-1]).index_select(0, idx)
+            flat_e = bev_embeds.reshape(-1, bev_embeds.shape[-1])
+            masked = ops.take_rows(flat_e, idx) if flat_e.is_cuda else flat_e.index_select(0, idx)
             sem_logits = self.local_sem_head(masked).float()
             sem_labels = b["bev_sems"].reshape(-1, b["bev_sems"].shape[-1]).index_select(0, idx).float()
             per = F.binary_cross_entropy_with_logits(sem_logits, sem_labels, reduction="none")

@@ -81,6 +81,7 @@ class StaticBatch:
         if grid_store is not None:
             grid_store.attach(t, grid_keys)
         self.tensors = t
+        self._attach_masks()
         self._refresh_counts()
 
     @staticmethod
@@ -140,6 +141,19 @@ class StaticBatch:
                                                   batch["traj_cand_vpids"], batch["gmap_vpids"], n_views, G)
         n_src = Tp * n_views                       # the dummy panoramas are source rows no segment points at
         static = {}
+        # sequence masks and their additive fp32 forms (vilmodel.gen_seq_masks / neg_key_mask / the panorama encoder's
+        # key_padding_mask): pure functions of the length vectors the loader holds on the host -- built here, shipped with the
+        # batch, hung on the length tensors (``_attach_masks``); the step then has no arange / compare / cast launches for them
+        def seq_masks(lens_host, width, name, inf=False):
+            m = torch.arange(width)[None, :] < torch.as_tensor(lens_host).reshape(-1, 1)
+            static[name + "_masks"] = m
+            static[name + "_km"] = (1.0 - m.to(torch.float32)) * -10000.0
+            if inf:
+                static[name + "_km_inf"] = torch.zeros(m.shape, dtype=torch.float32).masked_fill(~m, float("-inf"))
+        seq_masks(batch["txt_lens"], Lp, "txt")
+        seq_masks(batch["gmap_lens"], G, "gmap")
+        if not has_obj:
+            seq_masks(view_lens, Vp, "pano", inf=True)
         sig = [task, B, txt_shape, (Tp, Vp) + tuple(batch["traj_view_img_fts"].shape[2:]), G]
         if batch.get("traj_obj_img_fts") is not None:      # buffers of a bucket must agree on the object-token layout too
             # (incl. the width of the joint [views | objects] token axis: the maximum of views + objects over the panoramas)
@@ -162,6 +176,11 @@ class StaticBatch:
             src, vis_c = sap_fusion_indices(batch["gmap_vpids"], vis, cand_vpids, G, K)
             static["sap_src"] = torch.from_numpy(src)
             static["sap_vis_c"] = torch.from_numpy(vis_c)
+            # flat row numbers (into the (B * cells, H) BEV states) of the candidate cells and of the centre cell
+            cells = cfg.bev_dim * cfg.bev_dim
+            base = torch.arange(B, dtype=torch.int64)[:, None] * cells
+            static["sap_cand_flat"] = (base + batch["bev_cand_idxs"].to(torch.int64)).reshape(-1).contiguous()
+            static["sap_center_flat"] = (base[:, 0] + (cells - 1) // 2).contiguous()
             sig.append(K)
         elif task.startswith("masksem"):
             static["sem_cap"] = _round_up(max(1, int(batch["bev_mrc_masks"].sum())), SEM_ROW_PAD)
@@ -202,6 +221,19 @@ class StaticBatch:
             t["grid_rows"].copy_(t["grid_store"].rows(grid_keys), non_blocking=True)
         self._refresh_counts()
         return self
+
+    def _attach_masks(self):
+        """Hang the loader-built masks on the device tensors the model derives them from (refills copy in place, so the
+        attributes stay valid for the life of the buffer set)."""
+        t, st = self.tensors, self.tensors["_static"]
+        for lens_key, name in (("txt_lens", "txt"), ("gmap_lens", "gmap"), ("traj_vp_view_lens", "pano")):
+            m = st.get(name + "_masks")
+            if m is None or not torch.is_tensor(t.get(lens_key)):
+                continue
+            m._km = st[name + "_km"]
+            if name + "_km_inf" in st:
+                m._km_inf = st[name + "_km_inf"]
+            t[lens_key]._seq_masks = m
 
     def _staged(self, key, v):
         """A pageable host tensor goes through a PINNED staging buffer this buffer set owns (allocated once per key): the

@@ -28,7 +28,13 @@ EARLY_BEV = __import__("os").environ.get("BEVBERT_EARLY_BEV", "0") == "1"     # 
 
 
 def gen_seq_masks(seq_lens, max_len):
-    """ops.py:36-44 with a host-known max_len (the reference calls max() on a device tensor -> sync)."""
+    """ops.py:36-44 with a host-known max_len (the reference calls max() on a device tensor -> sync).  A loader that knows
+    the lengths on the host ships the mask next to them (static_step.StaticBatch hangs it on the length tensor as
+    ``_seq_masks``, with the additive fp32 forms the attention kernels read on the mask itself): then no arange / compare /
+    cast / multiply launches are left inside the step for it."""
+    pre = getattr(seq_lens, "_seq_masks", None)
+    if pre is not None and pre.shape[1] == max_len:
+        return pre
     return torch.arange(max_len, device=seq_lens.device)[None, :] < seq_lens[:, None]
 
 
@@ -36,6 +42,9 @@ def neg_key_mask(masks, value=-10000.0):
     """ops.py:25-34 extend_neg_masks, kept as (N, L) fp32 -- the kernels broadcast over heads and queries."""
     if masks is None:
         return None
+    pre = getattr(masks, "_km", None)
+    if pre is not None and value == -10000.0:
+        return pre
     return ((1.0 - masks.to(torch.float32)) * value).contiguous()
 
 
@@ -454,9 +463,10 @@ class TransformerEncoder(nn.Module):
                                     config.hidden_dropout_prob) for _ in range(num_layers)])
         self.norm = nn.LayerNorm(config.hidden_size, eps=1e-12)      # ops.py:19-20
 
-    def forward(self, src, src_key_padding_mask):
-        km = None
-        if src_key_padding_mask is not None:      # boolean key_padding_mask -> -inf on padded keys (vilmodel.py:530-532)
+    def forward(self, src, src_key_padding_mask, key_mask=None):
+        """``key_mask``: the additive fp32 form of ``src_key_padding_mask`` (0 / -inf) if the caller has it already."""
+        km = key_mask
+        if km is None and src_key_padding_mask is not None:      # boolean key_padding_mask -> -inf on padded keys (vilmodel.py:530-532)
             km = torch.zeros(src_key_padding_mask.shape, dtype=torch.float32, device=src.device)
             km = km.masked_fill(src_key_padding_mask, float("-inf")).contiguous()
         src = src.contiguous()
@@ -544,7 +554,8 @@ class ImageEmbeddings(nn.Module):
         e = ops.dropout(e, self.drop_p, self.training)
         masks = gen_seq_masks(lens, e.shape[1])
         if self.pano_encoder is not None:
-            e = self.pano_encoder(e, masks.logical_not())
+            km = getattr(masks, "_km_inf", None)          # loader-built (static_step.StaticBatch)
+            e = self.pano_encoder(e, None if km is not None else masks.logical_not(), key_mask=km)
         return e, masks
 
     def forward(self, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types, traj_step_lens,
