@@ -185,6 +185,24 @@ int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* word, const 
 int bevbert_embedding_grad(const int64_t* ids, const void* d, float* table_grad, int rows, int H, int padding_idx,
                            int dtype, hipStream_t stream);
 
+/* Feature projections with a tiny inner dimension fused into their LayerNorm (pretrain_src/model/vilmodel.py:507-518
+ * loc_layer_norm(loc_linear(loc_fts)), :577-583 bev_pos_embeddings, :589-593 gmap_pos_embeddings):
+ *   y = (LayerNorm(feat W^T + bias) + post1) + table[idx]      feat (rows, K) fp32, K <= 16; weight (H, K) fp32 (nn.Linear
+ * layout); post1 (rows, H) and table (T, H) of ``dtype`` or NULL; idx (rows) int64 (with table).  mean / rstd (rows) are left
+ * for the backward, which RECOMPUTES feat W^T (no z tensor is stored, no dz tensor written): it adds the gradients of
+ * weight (H, K), bias, gamma, beta into the given fp32 buffers (NULL: skipped) through per-workgroup partial sums in
+ * ``workspace`` (bevbert_smallk_workspace_floats(rows, K, H) floats), folded in a fixed order.  d post1 = d table rows = dy.
+ * H in {256, 512, 768, 1024}; (K + 8) * H * 4 bytes must fit 64 KB of LDS. */
+int64_t bevbert_smallk_workspace_floats(int rows, int K, int H);
+int bevbert_smallk_linear_layernorm_fwd(const float* feat, const float* weight, const float* bias, const float* gamma,
+                                        const float* beta, const void* post1, const void* table, const int64_t* idx,
+                                        void* y, float* mean, float* rstd, int rows, int K, int H, float eps, int dtype,
+                                        hipStream_t stream);
+int bevbert_smallk_linear_layernorm_bwd(const void* dy, const float* feat, const float* weight, const float* bias,
+                                        const float* mean, const float* rstd, const float* gamma, float* dweight,
+                                        float* dbias, float* dgamma, float* dbeta, float* workspace, int rows, int K,
+                                        int H, int dtype, hipStream_t stream);
+
 /* Row selection of activations and its backward (the reference indexes with boolean masks / index tensors:
  * pretrain_src/model/pretrain_cmt.py:254-256 masked tokens of the MLM head, :321-326 candidate cells of the SAP head, :403-410
  * supervised cells of the semantic head).  rows_gather: out[i, :] = src[ids[i], :].  rows_scatter: out[t, :] (+)= sum of

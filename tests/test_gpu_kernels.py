@@ -349,6 +349,59 @@ def test_take_rows_gather_and_deterministic_scatter(ops, dtype):
     assert float(y.grad[3].float().mean()) == 3.0 and float(y.grad[1].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,K,T", [(1280, 7, 100), (28224, 10, 2), (11520, 7, 3), (13, 10, 2), (4097, 12, 5)])
+def test_smallk_linear_layernorm_plus(ops, dtype, rows, K, T):
+    """smallk.hip: (LayerNorm(feat W^T + b) + post1) + table[idx] with the K <= 16 projection recomputed inside the row
+    kernels (vilmodel.py:507-518, 577-583, 589-593), against the fp32 torch composition: outputs, and the gradients the
+    backward adds into the arena (weight, bias, gamma, beta, table) and returns (post1).  Deterministic: a second backward
+    gives the same bits."""
+    from vln_bevbert_amd.arena import ParamArena
+    torch.manual_seed(rows + K)
+    H = 768
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin, self.ln, self.emb = torch.nn.Linear(K, H), torch.nn.LayerNorm(H, eps=1e-12), torch.nn.Embedding(T, H)
+    m = M()
+    with torch.no_grad():
+        m.ln.weight.uniform_(0.5, 1.5); m.ln.bias.normal_(0, 0.3)
+    ref = {n: p.detach().clone().to(DEV).requires_grad_(True) for n, p in m.named_parameters()}
+    arena = ParamArena(m, DEV, dtype)
+    feat = torch.randn(rows, K, device=DEV)
+    post1 = torch.randn(rows, H, device=DEV).to(dtype).requires_grad_(True)
+    idx = torch.randint(0, T, (rows,), device=DEV)
+    assert ops.smallk_linear_layernorm_plus_supported(feat, m.lin, m.ln, post1, m.emb)
+    dy = torch.randn(rows, H, device=DEV).to(dtype)
+
+    def run():
+        arena.grads.zero_()
+        post1.grad = None
+        ops.RT.scratch.reset()
+        y = ops.smallk_linear_layernorm_plus(feat, m.lin, m.ln, 1e-12, post1, m.emb, idx)
+        y.backward(dy)
+        arena.sync()
+        torch.cuda.synchronize()
+        return y.detach().clone(), arena.grads.clone(), post1.grad.clone()
+    y, g, dp = run()
+    # reference composition (fp32; the table rows in the compute dtype, as the kernel reads them)
+    tbl = ref["emb.weight"].to(dtype).float() if dtype != torch.float32 else ref["emb.weight"]
+    z = feat @ ref["lin.weight"].t() + ref["lin.bias"]
+    yr = torch.nn.functional.layer_norm(z, (H,), ref["ln.weight"], ref["ln.bias"], 1e-12) + post1.detach().float() + tbl[idx]
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert float((y.float() - yr).abs().max()) < tol * max(1.0, float(yr.abs().max()))
+    yr.backward(dy.float())
+    gt = 2e-4 if dtype == torch.float32 else 2e-2
+    for n in ("lin.weight", "lin.bias", "ln.weight", "ln.bias", "emb.weight"):
+        o, k = arena.slices[n]
+        got = g[o:o + k].view(ref[n].shape)
+        assert rel_err(got, ref[n].grad) < gt, (n, rel_err(got, ref[n].grad))
+    assert torch.equal(dp, dy)                                   # d post1 = dy
+    y2, g2, _ = run()
+    assert torch.equal(y2, y) and torch.equal(g2, g)
+
+
 def test_embed_sum_layernorm(ops):
     torch.manual_seed(3)
     V, H, B, L = 500, 768, 3, 17

@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert set(lib._PROTOS) | {"bevbert_last_error", "bevbert_version", "bevbert_arch", "bevbert_hip_error_reset",
                                "bevbert_colsum_workspace_floats", "bevbert_gemm_plan_count", "bevbert_gemm_rejected_count",
                                "bevbert_gemm_plan", "bevbert_colsum_partial_rows", "bevbert_gemm_tuning_export",
-                               "bevbert_attn_drop_bits_words", "bevbert_attn_last_path",
+                               "bevbert_attn_drop_bits_words", "bevbert_attn_last_path", "bevbert_smallk_workspace_floats",
                                "bevbert_gemm_tuning_import"} == set(syms)
 
 

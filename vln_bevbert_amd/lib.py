@@ -19,7 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # instructions of the SIMD's other wave while plain ones do (scripts/probes/mfma_valu_overlap.hip,
 # profiles/r05_mfma_valu_overlap_probe.txt).  Measured on that kernel: no difference either way.
 EXTRA_FLAGS = {"attn_fwd4.hip": ["-fno-slp-vectorize"]}
-SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_f32.hip", "attn_mfma.hip", "attn_bwd1.hip", "attn_fwd2.hip", "attn_fwd4.hip", "attn_bwd2.hip", "attn_bwd3.hip", "attn_small.hip", "attn_short.hip", "sap_loss.hip", "graph_nav.hip", "gemm.hip", "capi.hip"]
+SOURCES = ["splat.hip", "rowops.hip", "attn_simple.hip", "attn_f32.hip", "attn_mfma.hip", "attn_bwd1.hip", "attn_fwd2.hip", "attn_fwd4.hip", "attn_bwd2.hip", "attn_bwd3.hip", "attn_small.hip", "attn_short.hip", "smallk.hip", "sap_loss.hip", "graph_nav.hip", "gemm.hip", "capi.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bevbert_hip.h")
 
 F32, BF16, F16 = 0, 1, 2
@@ -93,6 +93,8 @@ _PROTOS = {
     "bevbert_embed_sum_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _U64, _U64, _P],
     "bevbert_embedding_grad": [_P, _P, _P, _I, _I, _I, _I, _P],
     "bevbert_rows_gather": [_P, _P, _P, _I, _I, _I, _P],
+    "bevbert_smallk_linear_layernorm_fwd": [_P] * 11 + [_I, _I, _I, _F, _I, _P],
+    "bevbert_smallk_linear_layernorm_bwd": [_P] * 12 + [_I, _I, _I, _I, _P],
     "bevbert_rows_scatter": [_P, _P, _P, _I, _I, _I, _I, _P],
     "bevbert_embedding_grad_sliced": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "bevbert_bias_gelu_fwd": [_P, _P, _P, _I, _I, _I, _P],
@@ -156,6 +158,8 @@ def load():
     lib.bevbert_gemm_tuning_import.argtypes = [ctypes.c_char_p]
     lib.bevbert_attn_drop_bits_words.restype = _I64
     lib.bevbert_attn_drop_bits_words.argtypes = [_I, _I, _I, _I]
+    lib.bevbert_smallk_workspace_floats.restype = _I64
+    lib.bevbert_smallk_workspace_floats.argtypes = [_I, _I, _I]
     lib.bevbert_colsum_partial_rows.restype = _I
     lib.bevbert_colsum_partial_rows.argtypes = [_I]
     lib.bevbert_gemm_plan.restype = _I

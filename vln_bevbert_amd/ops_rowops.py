@@ -227,6 +227,70 @@ def bias_layernorm_plus(x, bias, gamma, beta, eps, post1, post2=None):
                                 None if post2 is None else post2.contiguous())
 
 
+class _SmallKLinearLN(torch.autograd.Function):
+    """y = (LayerNorm(feat W^T + b) + post1) + table[idx] with K = feat.shape[-1] <= 16 (smallk.hip): the projection is
+    recomputed inside the LayerNorm kernels, forward and backward; parameter gradients go straight into the arena."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, gamma, beta, eps, post1, table, table_c, idx):
+        K, H = feat.shape[-1], weight.shape[0]
+        rows = feat.numel() // K
+        assert feat.dtype == torch.float32 and feat.is_contiguous() and weight.shape == (H, K)
+        assert post1.is_contiguous() and post1.shape[-1] == H and post1.numel() == rows * H
+        need_grad = any(ctx.needs_input_grad)
+        y = torch.empty_like(post1)
+        mean = torch.empty(rows, dtype=torch.float32, device=feat.device) if need_grad else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=feat.device) if need_grad else None
+        if idx is not None:
+            idx = idx.contiguous()
+            assert idx.dtype == torch.int64 and idx.numel() == rows and table_c.dtype == post1.dtype
+        call("bevbert_smallk_linear_layernorm_fwd", ptr(feat), ptr(weight), ptr(bias), ptr(_f32(gamma)), ptr(_f32(beta)),
+             ptr(post1), ptr(table_c) if idx is not None else None, ptr(idx), ptr(y), ptr(mean), ptr(rstd), rows, K, H,
+             float(eps), dtype_code(y), stream())
+        ctx.save_for_backward(feat, mean, rstd, idx)
+        ctx.params = (weight, bias, gamma, beta, table)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        feat, mean, rstd, idx = ctx.saved_tensors
+        weight, bias, gamma, beta, table = ctx.params
+        dy = dy.contiguous()
+        K, H = feat.shape[-1], weight.shape[0]
+        rows = feat.numel() // K
+        sinks = []
+        for p in (weight, bias, gamma, beta):
+            s = _sink(p) if (p is not None and p.requires_grad) else None
+            if s is not None:
+                _mark_touched(p)
+            sinks.append(s)
+        ws = RT.scratch.alloc(int(lib.load().bevbert_smallk_workspace_floats(rows, K, H)) * 4, dy.device)
+        call("bevbert_smallk_linear_layernorm_bwd", ptr(dy), ptr(feat), ptr(weight), ptr(bias), ptr(mean), ptr(rstd),
+             ptr(_f32(gamma)), ptr(sinks[0]), ptr(sinks[1]), ptr(sinks[2]), ptr(sinks[3]), ws, rows, K, H, dtype_code(dy),
+             stream())
+        if idx is not None and table.requires_grad:
+            _mark_touched(table)
+            embedding_grad_small(idx.reshape(-1), dy.reshape(-1, H), _sink(table), table.shape[0])
+        return None, None, None, None, None, None, dy, None, None, None
+
+
+def smallk_linear_layernorm_plus_supported(feat, lin, ln, post1, emb=None):
+    """The fused kernels take over when everything lives where they expect it: device tensors, fp32 master parameters in
+    the gradient arena (their gradients are accumulated in place), a hidden width the row kernels are instantiated for."""
+    H, K = lin.weight.shape
+    ps = [lin.weight, lin.bias, ln.weight, ln.bias] + ([emb.weight] if emb is not None else [])
+    return (feat.is_cuda and K <= 16 and H in (256, 512, 768, 1024) and (K + 8) * H * 4 + 512 <= 65536
+            and WgradStream.DEFER_FINALIZE and all(p.dtype == torch.float32 and (not p.requires_grad or _sink(p) is not None) for p in ps)
+            and post1.dtype in (torch.float32, torch.bfloat16))
+
+
+def smallk_linear_layernorm_plus(feat, lin, ln, eps, post1, emb=None, idx=None):
+    """(LN(lin(feat)) + post1) + emb(idx) -- vilmodel.py:507-518, 577-583, 589-593."""
+    tc = None if emb is None else _compute(emb.weight)
+    return _SmallKLinearLN.apply(feat.to(torch.float32).contiguous(), lin.weight, lin.bias, ln.weight, ln.bias, eps,
+                                 post1.contiguous(), None if emb is None else emb.weight, tc, idx)
+
+
 def layernorm(x, gamma, beta, eps):
     return _BiasDropResLN.apply(x.contiguous(), None, None, gamma, beta, eps, 0.0, False, None, None)
 

@@ -150,6 +150,7 @@ class StaticBatch:
             static[name + "_km"] = (1.0 - m.to(torch.float32)) * -10000.0
             if inf:
                 static[name + "_km_inf"] = torch.zeros(m.shape, dtype=torch.float32).masked_fill(~m, float("-inf"))
+        static["bev_nav_long"] = batch["bev_nav_masks"].to(torch.int64)      # index into LocalBEVEncoder.nav_type_embedding
         seq_masks(batch["txt_lens"], Lp, "txt")
         seq_masks(batch["gmap_lens"], G, "gmap")
         if not has_obj:
@@ -234,6 +235,8 @@ class StaticBatch:
             if name + "_km_inf" in st:
                 m._km_inf = st[name + "_km_inf"]
             t[lens_key]._seq_masks = m
+        if torch.is_tensor(t.get("bev_nav_masks")) and "bev_nav_long" in st:
+            t["bev_nav_masks"]._long = st["bev_nav_long"]
 
     def _staged(self, key, v):
         """A pageable host tensor goes through a PINNED staging buffer this buffer set owns (allocated once per key): the

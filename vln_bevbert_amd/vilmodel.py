@@ -539,10 +539,15 @@ class ImageEmbeddings(nn.Module):
             idx = torch.where(pos < vl, pos, torch.where(pos < tl, V + pos - vl, torch.full_like(pos, V + O)))
             pool = torch.cat([e, eo, e.new_zeros(e.shape[0], 1, e.shape[2])], 1)
             e = torch.gather(pool, 1, idx[..., None].expand(-1, -1, e.shape[2]))
-        loc = _small_k_linear(loc_fts, self.loc_linear, cd)
-        # ((e + LN(loc)) + nav_type) + token_type: the first two sums ride on the store of LN(loc)
-        e = ops.bias_layernorm_plus(loc, self.loc_linear.bias, self.loc_layer_norm.weight, self.loc_layer_norm.bias, 1e-12,
-                                    e, embedding_lookup(self.nav_type_embedding, nav_types))
+        # ((e + LN(loc_linear(loc))) + nav_type) + token_type: the first two sums ride on the store of the LayerNorm; with
+        # arena parameters the K = 7 projection itself is computed inside that kernel too (ops.smallk_linear_layernorm_plus)
+        if ops.smallk_linear_layernorm_plus_supported(loc_fts, self.loc_linear, self.loc_layer_norm, e, self.nav_type_embedding):
+            e = ops.smallk_linear_layernorm_plus(loc_fts, self.loc_linear, self.loc_layer_norm, 1e-12, e,
+                                                 self.nav_type_embedding, nav_types)
+        else:
+            loc = _small_k_linear(loc_fts, self.loc_linear, cd)
+            e = ops.bias_layernorm_plus(loc, self.loc_linear.bias, self.loc_layer_norm.weight, self.loc_layer_norm.bias, 1e-12,
+                                        e, embedding_lookup(self.nav_type_embedding, nav_types))
         if getattr(type_embed_layer.weight, "main_grad", None) is not None or not type_embed_layer.weight.requires_grad:
             # + token-type row 1 as the broadcast bias of the final LayerNorm (added in fp32 inside the kernel; its gradient
             # is the kernel's deterministic column reduction: ops.RowOfTable)
@@ -621,10 +626,15 @@ class LocalBEVEncoder(nn.Module):
         x = ops.linear(bev_fts.to(cd), lin.weight)
         e = ops.bias_dropout_residual_layernorm(x, lin.bias, None, ln.weight, ln.bias, 1e-12)
         lin, ln = self.bev_pos_embeddings[0], self.bev_pos_embeddings[1]
+        nav_idx = getattr(bev_nav_masks, "_long", None)            # loader-built (static_step.StaticBatch)
+        if nav_idx is None:
+            nav_idx = bev_nav_masks.long()
+        # (e + LN(pos)) + nav_type in the LayerNorm's own launch (and the K = 10 projection with it: smallk.hip)
+        if ops.smallk_linear_layernorm_plus_supported(bev_pos_fts, lin, ln, e, self.nav_type_embedding):
+            return ops.smallk_linear_layernorm_plus(bev_pos_fts, lin, ln, 1e-12, e, self.nav_type_embedding, nav_idx)
         pos = _small_k_linear(bev_pos_fts, lin, cd)
-        # (e + LN(pos)) + nav_type in the LayerNorm's own launch
         return ops.bias_layernorm_plus(pos, lin.bias, ln.weight, ln.bias, 1e-12, e,
-                                       embedding_lookup(self.nav_type_embedding, bev_nav_masks.long()))
+                                       embedding_lookup(self.nav_type_embedding, nav_idx))
 
     def with_objects(self, bev_embeds, bev_masks, obj_embeds, obj_masks):
         """vilmodel.py:601-606: object tokens are appended to the BEV cells (an all-ones BEV mask may come as None)."""
@@ -699,6 +709,9 @@ class GlobalMapEncoder(nn.Module):
 
     def pos_step_embedding(self, gmap_img_fts, gmap_step_ids, gmap_pos_fts):
         lin, ln = self.gmap_pos_embeddings[0], self.gmap_pos_embeddings[1]
+        if ops.smallk_linear_layernorm_plus_supported(gmap_pos_fts, lin, ln, gmap_img_fts, self.gmap_step_embeddings):
+            return ops.smallk_linear_layernorm_plus(gmap_pos_fts, lin, ln, 1e-12, gmap_img_fts, self.gmap_step_embeddings,
+                                                    gmap_step_ids)
         pos = _small_k_linear(gmap_pos_fts, lin, gmap_img_fts.dtype)
         # (LN(pos) + img) + step embedding on the store of the LayerNorm: one rounding of the sum in bf16 instead of three
         # (vilmodel.py:589-593 adds the same three terms)
