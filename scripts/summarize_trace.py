@@ -47,12 +47,14 @@ def cls(name):
     if any(k in n for k in ("attn_", "ln_fwd", "ln_bwd", "bev_", "colwise", "colsum", "bias_gelu", "gather_wsum",
                             "adamw", "sumsq", "clip_coef", "cast_f32", "keep_mask", "accum_partials", "dropout_add",
                             "embedding_grad", "multi_accum", "multi_finalize", "sap_loss", "ce_fwd", "ce_bwd", "gm_",
-                            "colsum_finalize")):
+                            "colsum_finalize", "ln_res32", "smallk_", "rows_gather", "rows_scatter")):
         return "custom"
     if any(k in n for k in ("cijk", "gemm", "tensile", "hipblaslt", "rocblas")):
         return "gemm"
     if "nccl" in n or "rccl" in n:
         return "rccl"
+    if "rocclr_fillbuffer" in n or "rocclr_copybuffer" in n:
+        return "memop"
     return "torch"
 
 

@@ -493,6 +493,55 @@ def test_graph_bias_gradient_is_deterministic(ops):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graph_bias_shared_by_the_layers_of_an_encoder(ops, dtype):
+    """ops.graph_bias (sprel_linear over the pairwise node distances, vilmodel.py:575-577): one forward launch hands a view
+    to every x-layer; each layer's attention backward leaves its per-head bias gradients in a shared buffer and ONE launch
+    reduces them to d sprel_linear.weight / .bias in the arena -- against the torch composition through the fp32 attention
+    reference, for three layers."""
+    from vln_bevbert_amd.arena import ParamArena
+    torch.manual_seed(4)
+    B, G, nh, L = 5, 20, 12, 3
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.sprel_linear = torch.nn.Linear(1, 1)
+    m = M()
+    w0, b0 = float(m.sprel_linear.weight), float(m.sprel_linear.bias)
+    arena = ParamArena(m, DEV, torch.float32)
+    dists = torch.rand(B, G, G, device=DEV) * 3
+    km = torch.zeros(B, G, device=DEV)
+    km[1, 15:] = -10000.0
+    qkv = [tuple(torch.randn(B, G, 768, device=DEV).to(dtype) for _ in range(3)) for _ in range(L)]
+    do = [torch.randn(B, G, 768, device=DEV).to(dtype) for _ in range(L)]
+    biases = ops.graph_bias(dists, m.sprel_linear.weight, m.sprel_linear.bias, L, nh)
+    assert len(biases) == L and all(float((x - (dists * w0 + b0)).abs().max()) < 1e-6 for x in biases)      # (the kernel fuses the multiply-add)
+
+    def run():
+        arena.grads.zero_()
+        bs = ops.graph_bias(dists, m.sprel_linear.weight, m.sprel_linear.bias, L, nh)
+        tot = 0
+        for (q, k, v), bi, d in zip(qkv, bs, do):
+            tot = tot + (ops.attention(q, k, v, km, bi, nh, impl=2 if dtype == torch.bfloat16 else 1).float() * d.float()).sum()
+        tot.backward()
+        torch.cuda.synchronize()
+        return arena.grads.clone()
+    g = run()
+    wr = torch.tensor(w0, device=DEV, requires_grad=True)
+    br = torch.tensor(b0, device=DEV, requires_grad=True)
+    tot = 0
+    for (q, k, v), d in zip(qkv, do):
+        tot = tot + (_attn_ref(q.float(), k.float(), v.float(), km, dists * wr + br, nh) * d.float()).sum()
+    tot.backward()
+    ow, _ = arena.slices["sprel_linear.weight"]
+    ob, _ = arena.slices["sprel_linear.bias"]
+    tol = 1e-3 if dtype == torch.float32 else 5e-2
+    assert abs(float(g[ow]) - float(wr.grad)) < tol * max(1.0, abs(float(wr.grad))), (float(g[ow]), float(wr.grad))
+    assert abs(float(g[ob]) - float(br.grad)) < tol * max(1.0, abs(float(wr.grad))), (float(g[ob]), float(br.grad))
+    assert torch.equal(run(), g)                           # fixed summation order
+
+
 @pytest.mark.parametrize("dtype,fuse", [(torch.float32, True), (torch.float32, False), (torch.bfloat16, True)])
 def test_fused_sap_loss_tail_matches_the_torch_composition(ops, dtype, fuse):
     """ops.sap_loss == pretrain_cmt.forward_sap's tail written with torch ops (masked fills, fuse_sap_logits, three

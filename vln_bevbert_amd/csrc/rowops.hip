@@ -829,6 +829,61 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(const TI* __restrict__
   }
 }
 
+// Graph-aware attention bias of the global-map encoder (vilmodel.py:543-546, 575-577: sprel_linear = nn.Linear(1, 1) on
+// the pairwise node distances): bias = dists * w + b with w, b read from the parameters in device memory; and its backward
+// over the per-head, per-layer bias gradients the attention kernels leave: dw = sum dbias * dists, db = sum dbias.  One
+// workgroup, a fixed summation order (the tensors are a few MB and the global-map branch runs beside the BEV encoder).
+__global__ __launch_bounds__(256) void graph_bias_fwd_kernel(const float* __restrict__ dists, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ out, int n) {
+  const float ww = *w, bb = *b;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = dists[i] * ww + bb;
+}
+__global__ __launch_bounds__(1024) void graph_bias_bwd_kernel(const float* __restrict__ dbias, const float* __restrict__ dists,
+                                                              int64_t n, int per_sample, int64_t per_layer, int nh_gg, int gg,
+                                                              float* __restrict__ dw, float* __restrict__ db) {
+  // dbias: (layers, B, nh, G, G); element e -> sample (e % per_layer) / nh_gg, pair e % gg
+  float sw = 0.f, sb = 0.f;
+  for (int64_t e = threadIdx.x; e < n; e += 1024) {
+    const float d = dbias[e];
+    const int64_t r = e % per_layer;
+    const int smp = (int)(r / nh_gg), qk = (int)(r % gg);
+    sw = fmaf(d, dists[(size_t)smp * per_sample + qk], sw);
+    sb += d;
+  }
+  __shared__ float s_w[16], s_b[16];
+  sw = wave_sum(sw);
+  sb = wave_sum(sb);
+  if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = sw; s_b[threadIdx.x >> 6] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tw = 0.f, tb = 0.f;
+    for (int i = 0; i < 16; ++i) { tw += s_w[i]; tb += s_b[i]; }
+    if (dw) *dw += tw;
+    if (db) *db += tb;
+  }
+}
+
+BEVBERT_API int bevbert_graph_bias_fwd(const float* dists, const float* w, const float* b, float* out, int64_t n,
+                                       hipStream_t stream) {
+  BB_REQUIRE(n >= 0 && n < 2147483647 && w != nullptr && b != nullptr, "graph_bias_fwd: bad arguments");
+  if (n == 0) return BB_OK;
+  int nb = (int)((n + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(graph_bias_fwd_kernel, dim3(nb), dim3(256), 0, stream, dists, w, b, out, (int)n);
+  BB_CHECK_LAUNCH("graph_bias_fwd");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_graph_bias_bwd(const float* dbias, const float* dists, int layers, int B, int nh, int G, float* dw,
+                                       float* db, hipStream_t stream) {
+  BB_REQUIRE(layers > 0 && B > 0 && nh > 0 && G > 0, "graph_bias_bwd: empty problem");
+  const int64_t per_layer = (int64_t)B * nh * G * G;
+  hipLaunchKernelGGL(graph_bias_bwd_kernel, dim3(1), dim3(1024), 0, stream, dbias, dists, per_layer * layers, G * G, per_layer,
+                     nh * G * G, G * G, dw, db);
+  BB_CHECK_LAUNCH("graph_bias_bwd");
+  return BB_OK;
+}
+
 // =============================================================================================
 // C ABI
 // =============================================================================================

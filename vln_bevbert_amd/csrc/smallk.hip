@@ -227,22 +227,25 @@ __global__ __launch_bounds__(256) void smallk_ln_bwd_kernel(const T* __restrict_
   }
 }
 
-// grid (H / 256, K + 3): plane p of column c summed over the workgroups in ascending order, added to the destination
+// grid (H / 64, K + 3), 256 threads: plane p of 64 columns; wave w sums the workgroups b = w, w + 4, ... in ascending
+// order, the four partial sums are folded pairwise -- a fixed order -- and added to the destination
 __global__ __launch_bounds__(256) void smallk_finalize_kernel(const float* __restrict__ partials, int nblocks, int K, int H,
                                                               float* __restrict__ dW, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ dbias) {
-  const int c = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;
-  if (c >= H) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblocks; b += 4) {
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, p = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f;
+  int b = wave;
+  for (; b + 4 < nblocks; b += 8) {
     s0 += partials[((size_t)b * (K + 3) + p) * H + c];
-    s1 += partials[((size_t)(b + 1) * (K + 3) + p) * H + c];
-    s2 += partials[((size_t)(b + 2) * (K + 3) + p) * H + c];
-    s3 += partials[((size_t)(b + 3) * (K + 3) + p) * H + c];
+    s1 += partials[((size_t)(b + 4) * (K + 3) + p) * H + c];
   }
-  for (; b < nblocks; ++b) s0 += partials[((size_t)b * (K + 3) + p) * H + c];
-  const float s = (s0 + s1) + (s2 + s3);
+  for (; b < nblocks; b += 4) s0 += partials[((size_t)b * (K + 3) + p) * H + c];
+  s_part[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave != 0) return;
+  const float s = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
   if (p < K) {
     if (dW != nullptr) dW[(size_t)c * K + p] += s;
   } else {
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void smallk_finalize_kernel(const float* __res
 
 static int sk_bwd_blocks(int rows) {
   const int tiles = (rows + SK_R - 1) / SK_R;
-  return tiles < 512 ? (tiles < 1 ? 1 : tiles) : 512;
+  return tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256;
 }
 
 BEVBERT_API int64_t bevbert_smallk_workspace_floats(int rows, int K, int H) {
@@ -314,7 +317,7 @@ BEVBERT_API int bevbert_smallk_linear_layernorm_bwd(const void* dy, const float*
   }
 #undef GO
   BB_CHECK_LAUNCH("smallk_linear_layernorm_bwd");
-  hipLaunchKernelGGL(smallk_finalize_kernel, dim3((H + 255) / 256, K + 3), dim3(256), 0, stream, workspace, nb, K, H,
+  hipLaunchKernelGGL(smallk_finalize_kernel, dim3(H / 64, K + 3), dim3(256), 0, stream, workspace, nb, K, H,
                      dweight, dgamma, dbeta, dbias);
   BB_CHECK_LAUNCH("smallk_linear_layernorm_bwd finalize");
   return BB_OK;

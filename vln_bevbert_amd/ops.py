@@ -34,4 +34,4 @@ from .ops_rowops import (  # noqa: F401
     cross_entropy_rows, dropout, dropout_keep_mask, embed_sum_layernorm, embedding_grad_small, layernorm, pixel_scale, sap_loss,
     sap_loss_supported, segment_wsum)
 from .ops_attention import (  # noqa: F401
-    _Attention, _strides, attention, attention_cross, attention_self, attn_drop_bits)
+    _Attention, _strides, attention, attention_cross, attention_self, attn_drop_bits, graph_bias)

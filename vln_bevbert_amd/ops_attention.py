@@ -6,7 +6,7 @@ import os as _os
 import torch
 
 from .lib import dtype_code, ptr, stream
-from .ops_core import ATTN_BITS, HEAD_DIM, RT, _drop_bits_words, call
+from .ops_core import ATTN_BITS, HEAD_DIM, RT, _drop_bits_words, _mark_touched, _sink, call
 
 
 # ----------------------------------------------------------------------------- K2 attention
@@ -61,6 +61,7 @@ class _Attention(torch.autograd.Function):
         ctx.save_for_backward(a, b_, c_, key_mask, bias, o, lse, bits)
         ctx.cfg = (mode, nh, float(drop_p), RT.seed, off, impl, scale)
         ctx.kv_slot = getattr(b_, "_kv_grad_slot", None) if mode == "cross" else None     # see hoisted_kv
+        ctx.bias_slot = getattr(bias, "_dbias_slot", None) if bias is not None else None    # see graph_bias
         return o
 
     @staticmethod
@@ -90,14 +91,80 @@ class _Attention(torch.autograd.Function):
         B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
         delta = torch.empty(B, nh, Lq, dtype=torch.float32, device=q.device)
         # the bias is shared by the heads: the kernels store per-head gradients (no atomics), summed here in a fixed order
-        dbias_h = torch.zeros(B, nh, Lq, Lk, dtype=torch.float32, device=q.device) \
-            if (bias is not None and ctx.needs_input_grad[5]) else None
+        slot = ctx.bias_slot
+        if bias is not None and ctx.needs_input_grad[5] and slot is not None and Lq == Lk:
+            dbias_h = slot[0].slot(slot[1], B, Lq, q.device)       # shared (layers, B, nh, G, G) buffer, zeroed once
+        else:
+            slot = None
+            dbias_h = torch.zeros(B, nh, Lq, Lk, dtype=torch.float32, device=q.device) \
+                if (bias is not None and ctx.needs_input_grad[5]) else None
         assert do.shape == o.shape
         call("bevbert_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk),
              ptr(dv), ptr(dbias_h), ptr(key_mask), ptr(bias), _strides(q, k, v, o), B, nh, Lq, Lk, HEAD_DIM, scale,
              dtype_code(q), impl, drop_p, seed, off, ptr(bits), stream())
-        dbias = None if dbias_h is None else dbias_h.sum(1)
+        if slot is not None:
+            dbias = slot[0].dummy            # the real gradient sits in the holder; _GraphBias.backward reduces it
+        else:
+            dbias = None if dbias_h is None else dbias_h.sum(1)
         return (None,) + grads + (None, dbias, None, None, None)
+
+
+class _BiasGradHolder:
+    """Per-head gradients of one graph bias used by several attention layers: (layers, B, nh, G, G) fp32, zeroed once (the
+    kernels write the valid entries only), filled slot by slot by the attention backward of each layer, reduced to the two
+    scalars of sprel_linear by ONE launch (_GraphBias.backward) -- instead of, per layer, a zero fill, a head sum and
+    autograd's addition of the layers' gradients, followed by three reductions."""
+
+    def __init__(self, layers, nh):
+        self.layers, self.nh, self.buf, self.dummy = layers, nh, None, None
+
+    def slot(self, i, B, G, device):
+        if self.buf is None:
+            self.buf = torch.empty(self.layers, B, self.nh, G, G, dtype=torch.float32, device=device)
+            call("bevbert_zero", ptr(self.buf), self.buf.numel() * 4, stream())
+            self.dummy = torch.empty((), dtype=torch.float32, device=device).expand(B, G, G)    # never read: a shape for autograd
+        return self.buf[i]
+
+
+class _GraphBias(torch.autograd.Function):
+    """bias = dists * w + b (vilmodel.py:575-577 sprel_linear), handed out once per attention layer."""
+
+    @staticmethod
+    def forward(ctx, dists, weight, bias, layers, nh):
+        dists = dists.to(torch.float32).contiguous()
+        out = torch.empty_like(dists)
+        call("bevbert_graph_bias_fwd", ptr(dists), ptr(weight), ptr(bias), ptr(out), dists.numel(), stream())
+        ctx.save_for_backward(dists)
+        ctx.params = (weight, bias)
+        ctx.holder = _BiasGradHolder(layers, nh)
+        return tuple(out.view_as(out) for _ in range(layers))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (dists,) = ctx.saved_tensors
+        weight, bias = ctx.params
+        h = ctx.holder
+        if h.buf is None:
+            return None, None, None, None, None
+        sinks = []
+        for p in (weight, bias):
+            s = _sink(p) if p.requires_grad else None
+            if s is not None:
+                _mark_touched(p)
+            sinks.append(s)
+        B, G = dists.shape[0], dists.shape[-1]
+        call("bevbert_graph_bias_bwd", ptr(h.buf), ptr(dists), h.layers, B, h.nh, G, ptr(sinks[0]), ptr(sinks[1]), stream())
+        return None, None, None, None, None
+
+
+def graph_bias(dists, weight, bias, layers, nh):
+    """Per-layer views of the graph bias dists * w + b; each carries the slot its attention backward writes to."""
+    outs = _GraphBias.apply(dists, weight, bias, layers, nh)
+    holder = outs[0].grad_fn.holder if hasattr(outs[0].grad_fn, "holder") else None
+    if holder is not None:
+        for i, o in enumerate(outs):
+            o._dbias_slot = (holder, i)
+    return outs
 
 
 def attention_self(qkv, key_mask, bias, nh, drop_p=0.0, training=False):

@@ -393,7 +393,8 @@ class CrossmodalEncoder(_Finalizable):
         if kvs is None:
             kvs = self.hoist_kv(txt_embeds)
         for k, (layer, kv) in enumerate(zip(self.x_layers, kvs)):
-            img_embeds = layer(txt_embeds, tm, self._watch(k, img_embeds), im, graph_sprels=graph_sprels, ctx_kv=kv)
+            sp = graph_sprels[k] if isinstance(graph_sprels, (tuple, list)) else graph_sprels      # per-layer views: ops.graph_bias
+            img_embeds = layer(txt_embeds, tm, self._watch(k, img_embeds), im, graph_sprels=sp, ctx_kv=kv)
         return img_embeds
 
     def forward_lang2visn(self, txt_embeds, txt_key_mask, visn_feats, visn_key_mask, kvs=None):
@@ -724,10 +725,17 @@ class GlobalMapEncoder(nn.Module):
         return self.pos_step_embedding(img, gmap_step_ids, gmap_pos_fts), gen_seq_masks(gmap_lens, G)
 
     def sprels(self, gmap_pair_dists):
+        """(B, G, G) fp32 additive bias; with arena parameters on the GPU a tuple with one view per x-layer (ops.graph_bias:
+        one launch forward, one launch for the gradients of all layers)."""
         if self.sprel_linear is None:
             return None
-        w, b = ops.use_param(self.sprel_linear.weight).view(()), ops.use_param(self.sprel_linear.bias).view(())
-        return (gmap_pair_dists.float() * w + b).contiguous()          # (B, G, G) fp32 additive bias
+        lw, lb = self.sprel_linear.weight, self.sprel_linear.bias
+        if gmap_pair_dists.is_cuda and all(p.dtype == torch.float32 and (not p.requires_grad or ops._sink(p) is not None) for p in (lw, lb)):
+            n_layers = self.encoder.num_x_layers
+            nh = self.encoder.x_layers[0].visn_self_att.self.num_attention_heads
+            return ops.graph_bias(gmap_pair_dists, lw, lb, n_layers, nh)
+        w, b = ops.use_param(lw).view(()), ops.use_param(lb).view(())
+        return (gmap_pair_dists.float() * w + b).contiguous()
 
     def forward(self, txt_embeds, txt_masks, gmap_embeds, gmap_masks, gmap_pair_dists, txt_kvs=None):
         return self.encoder(txt_embeds, txt_masks, gmap_embeds, gmap_masks, graph_sprels=self.sprels(gmap_pair_dists),
