@@ -150,9 +150,10 @@ int bevbert_layernorm_res32_fwd(const void* x, const float* bias, const void* re
                                 float* rstd, int rows, int H, float eps, float drop_p, uint64_t seed, uint64_t offset,
                                 hipStream_t stream);
 int bevbert_layernorm_res32_bwd(const void* dy16, const float* dy32, const float* z32, const float* mean,
-                                const float* rstd, const float* gamma, float* dz32, void* dx16, float* dgamma,
+                                const float* rstd, const float* gamma, void* dz, void* dx16, float* dgamma,
                                 float* dbeta, float* dbias, float* workspace, int rows, int H, float drop_p, uint64_t seed,
-                                uint64_t offset, int accumulate, hipStream_t stream);
+                                uint64_t offset, int accumulate, int dz_dtype,
+                                hipStream_t stream);
 int64_t bevbert_colsum_workspace_floats(int total_cols);
 /* Split form of the parameter-gradient reductions: bevbert_layernorm_bwd / bevbert_bias_gelu_bwd called with NULL
  * dgamma/dbeta/dbias leave per-block partial sums [bevbert_colsum_partial_rows(rows)][nwhich][C] (nwhich = 3 for
@@ -202,6 +203,18 @@ int bevbert_smallk_linear_layernorm_bwd(const void* dy, const float* feat, const
                                         const float* mean, const float* rstd, const float* gamma, float* dweight,
                                         float* dbias, float* dgamma, float* dbeta, float* workspace, int rows, int K,
                                         int H, int dtype, hipStream_t stream);
+
+/* column sums for any column count (C % 4 != 0: the 30 522-wide vocabulary bias, the 1-wide prediction heads):
+ * out[c] (+)= sum_r dy[r][c], fixed summation order. */
+int bevbert_colsum_any(const void* dy, float* out, int rows, int C, int dtype, int accumulate, hipStream_t stream);
+
+/* loss.mean() of the step (pretrain_src/train_r2r.py:263) over a static batch's rows: *out = sum_i w[i] x[i] / denom (w NULL:
+ * ones -- zero for the padding rows of a static batch; denom_dev, if given, is read from device memory: the row count of
+ * the batch that currently sits in the buffers); bwd: dx[i] = w[i] * *dout / denom. */
+int bevbert_weighted_mean_fwd(const float* x, const float* w, const float* denom_dev, float denom, int n, float* out,
+                              hipStream_t stream);
+int bevbert_weighted_mean_bwd(const float* dout, const float* w, const float* denom_dev, float denom, int n, float* dx,
+                              hipStream_t stream);
 
 /* Graph-aware attention bias of the global-map encoder (pretrain_src/model/vilmodel.py:543-546,575-577: sprel_linear =
  * nn.Linear(1, 1) over the pairwise node distances).  fwd: out[i] = dists[i] * *w + *b (w, b: the parameters in device

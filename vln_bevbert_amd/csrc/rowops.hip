@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void ln_res32_bwd_kernel(const bf16_raw* __res
                                                            float* __restrict__ dz_out, bf16_raw* __restrict__ dx_out,
                                                            float* __restrict__ partials, int rows, float drop_p,
                                                            uint32_t drop_thr, uint32_t drop_key,
-                                                           const uint32_t* __restrict__ salt) {
+                                                           const uint32_t* __restrict__ salt, int dz_bf16) {
+  // dz_bf16: dz_out is a bf16 tensor (the residual was a bf16 tensor -- where an fp32 residual stream starts)
   constexpr int H = NV * 256;
   if (drop_p > 0.f) drop_key = bb_salted(drop_key, salt);
   __shared__ float4 s_red[3][4][NV * 64];
@@ -325,7 +326,10 @@ __global__ __launch_bounds__(256) void ln_res32_bwd_kernel(const bf16_raw* __res
       o.y = rs * (d[i].y - s1 - xh[i].y * s2);
       o.z = rs * (d[i].z - s1 - xh[i].z * s2);
       o.w = rs * (d[i].w - s1 - xh[i].w * s2);
-      if (dz_out != nullptr) st4<float>(dz_out + (size_t)row * H + col, o);
+      if (dz_out != nullptr) {
+        if (dz_bf16) st4<bf16_raw>(reinterpret_cast<bf16_raw*>(dz_out) + (size_t)row * H + col, o);
+        else st4<float>(dz_out + (size_t)row * H + col, o);
+      }
       if (drop_p > 0.f) {
         const uint32_t pr = ((uint32_t)row * H + col) >> 1;
         const uint32_t b0 = bb_pair_bits(drop_key, pr), b1 = bb_pair_bits(drop_key, pr + 1);
@@ -829,6 +833,109 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(const TI* __restrict__
   }
 }
 
+// Column sums for ANY column count (the 30 522-wide vocabulary bias, the 1-wide heads: C % 4 != 0 rules out the float4
+// kernels above): out[c] (+)= sum_r dy[r][c].  Wide: workgroup = 64 columns x 4 row groups, folded pairwise.  Narrow
+// (C <= 4): the whole workgroup walks the rows.  Fixed summation order in both.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_any_kernel(const T* __restrict__ dy, float* __restrict__ out, int rows, int C,
+                                                         int accumulate) {
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (C <= 4) {
+    for (int c = 0; c < C; ++c) {
+      float s = 0.f;
+      for (int r = threadIdx.x; r < rows; r += 256) s += io<T>::ld(dy + (size_t)r * C + c);
+      s = wave_sum(s);
+      if (lane == 0) s_part[wave][0] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const float t = (s_part[0][0] + s_part[1][0]) + (s_part[2][0] + s_part[3][0]);
+        out[c] = accumulate ? out[c] + t : t;
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  const int c = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    int r = wave;
+    for (; r + 12 < rows; r += 16) {
+      s0 += io<T>::ld(dy + (size_t)r * C + c);
+      s1 += io<T>::ld(dy + (size_t)(r + 4) * C + c);
+      s2 += io<T>::ld(dy + (size_t)(r + 8) * C + c);
+      s3 += io<T>::ld(dy + (size_t)(r + 12) * C + c);
+    }
+    for (; r < rows; r += 4) s0 += io<T>::ld(dy + (size_t)r * C + c);
+  }
+  s_part[wave][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    const float t = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+BEVBERT_API int bevbert_colsum_any(const void* dy, float* out, int rows, int C, int dtype, int accumulate,
+                                   hipStream_t stream) {
+  BB_REQUIRE(rows >= 0 && C > 0, "colsum_any: rows=%d C=%d", rows, C);
+  if (rows == 0) return BB_OK;
+  const dim3 grid(C <= 4 ? 1 : (C + 63) / 64);
+  if (dtype == BB_F32)
+    hipLaunchKernelGGL(colsum_any_kernel<float>, grid, dim3(256), 0, stream, (const float*)dy, out, rows, C, accumulate);
+  else if (dtype == BB_BF16)
+    hipLaunchKernelGGL(colsum_any_kernel<bf16_raw>, grid, dim3(256), 0, stream, (const bf16_raw*)dy, out, rows, C, accumulate);
+  else {
+    bb_set_error("colsum_any: dtype %d unsupported", dtype);
+    return BB_EUNSUPPORTED;
+  }
+  BB_CHECK_LAUNCH("colsum_any");
+  return BB_OK;
+}
+
+// loss.mean() of the step (pretrain_src/train_r2r.py:263) with the zero-weight padding rows of a static batch:
+// out = sum_i w[i] * x[i] / denom   (w NULL: all ones; denom from device memory when denom_dev is given -- the number of
+// real rows of the batch that currently sits in the buffers).  One workgroup (n is at most a few thousand), fixed order.
+__global__ __launch_bounds__(1024) void weighted_mean_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ denom_dev, float denom, int n,
+                                                                 float* __restrict__ out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) s += (w ? w[i] : 1.0f) * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    *out = t / (denom_dev ? *denom_dev : denom);
+  }
+}
+__global__ __launch_bounds__(256) void weighted_mean_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                                const float* __restrict__ denom_dev, float denom, int n,
+                                                                float* __restrict__ dx) {
+  const float g = *dout / (denom_dev ? *denom_dev : denom);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dx[i] = (w ? w[i] : 1.0f) * g;
+}
+
+BEVBERT_API int bevbert_weighted_mean_fwd(const float* x, const float* w, const float* denom_dev, float denom, int n,
+                                          float* out, hipStream_t stream) {
+  BB_REQUIRE(n > 0 && x != nullptr && out != nullptr, "weighted_mean_fwd: empty input");
+  hipLaunchKernelGGL(weighted_mean_fwd_kernel, dim3(1), dim3(1024), 0, stream, x, w, denom_dev, denom, n, out);
+  BB_CHECK_LAUNCH("weighted_mean_fwd");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_weighted_mean_bwd(const float* dout, const float* w, const float* denom_dev, float denom, int n,
+                                          float* dx, hipStream_t stream) {
+  BB_REQUIRE(n > 0 && dout != nullptr && dx != nullptr, "weighted_mean_bwd: empty input");
+  int nb = (n + 255) / 256;
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(weighted_mean_bwd_kernel, dim3(nb), dim3(256), 0, stream, dout, w, denom_dev, denom, n, dx);
+  BB_CHECK_LAUNCH("weighted_mean_bwd");
+  return BB_OK;
+}
+
 // Graph-aware attention bias of the global-map encoder (vilmodel.py:543-546, 575-577: sprel_linear = nn.Linear(1, 1) on
 // the pairwise node distances): bias = dists * w + b with w, b read from the parameters in device memory; and its backward
 // over the per-head, per-layer bias gradients the attention kernels leave: dw = sum dbias * dists, db = sum dbias.  One
@@ -1106,9 +1213,11 @@ BEVBERT_API int bevbert_layernorm_res32_fwd(const void* x, const float* bias, co
 }
 
 BEVBERT_API int bevbert_layernorm_res32_bwd(const void* dy16, const float* dy32, const float* z32, const float* mean,
-                                            const float* rstd, const float* gamma, float* dz32, void* dx16, float* dgamma,
+                                            const float* rstd, const float* gamma, void* dz, void* dx16, float* dgamma,
                                             float* dbeta, float* dbias, float* workspace, int rows, int H, float drop_p,
-                                            uint64_t seed, uint64_t offset, int accumulate, hipStream_t stream) {
+                                            uint64_t seed, uint64_t offset, int accumulate, int dz_dtype,
+                                            hipStream_t stream) {
+  BB_REQUIRE(dz_dtype == BB_F32 || dz_dtype == BB_BF16, "layernorm_res32_bwd: dz dtype %d (fp32 or bf16)", dz_dtype);
   BB_REQUIRE(H % 256 == 0 && H / 256 <= 4, "layernorm_res32_bwd: H=%d must be 256, 512, 768 or 1024", H);
   BB_REQUIRE(dy16 != nullptr || dy32 != nullptr, "layernorm_res32_bwd: no output gradient");
   if (rows <= 0) return BB_OK;
@@ -1116,7 +1225,8 @@ BEVBERT_API int bevbert_layernorm_res32_bwd(const void* dy16, const float* dy32,
   const uint32_t thr = bb_drop_threshold(drop_p);
 #define GO(N)                                                                                                          \
   hipLaunchKernelGGL((ln_res32_bwd_kernel<N>), dim3(nb), dim3(256), 0, stream, (const bf16_raw*)dy16, dy32, z32, mean, rstd, \
-                     gamma, dz32, (bf16_raw*)dx16, workspace, rows, drop_p, thr, bb_site_key(seed, offset), bb_step_salt())
+                     gamma, (float*)dz, (bf16_raw*)dx16, workspace, rows, drop_p, thr, bb_site_key(seed, offset), bb_step_salt(), \
+                     dz_dtype == BB_BF16 ? 1 : 0)
   switch (H / 256) {
     case 1: GO(1); break;
     case 2: GO(2); break;

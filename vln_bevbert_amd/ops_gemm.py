@@ -266,6 +266,7 @@ class _Linear(torch.autograd.Function):
         # tap: the input ALSO feeds a residual connection.  It is handed back as a second output, so that the residual's
         # gradient arrives HERE and is folded into the input-gradient GEMM (dx = dy W + d_res, beta = 1) -- autograd would
         # otherwise add the two gradients of x with a separate elementwise kernel (~50 of them per training step)
+        ctx.set_materialize_grads(False)      # (y, tap): an unused output arrives as None, not as dense zeros
         return (y, x.view_as(x)) if tap else y
 
     @staticmethod
@@ -285,14 +286,18 @@ class _Linear(torch.autograd.Function):
         if weight.requires_grad and w_sink is None:
             gw = _linear_wgrad(dy2, x2).to(weight.dtype)
         if bias is not None and bias.requires_grad and (b_sink is None or C % 4 != 0):
-            if C % 4 != 0:                                  # e.g. the 1-wide heads: a library reduction is fine
-                s = dy2.float().sum(0)
-                if b_sink is not None:
+            if C % 4 != 0:                                  # the 1-wide heads, the 30 522-wide vocabulary bias
+                dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+                if b_sink is not None and dyc.is_cuda:
                     _mark_touched(bias)
-                    b_sink.add_(s)
+                    call("bevbert_colsum_any", ptr(dyc), ptr(b_sink), dyc.shape[0], C, dtype_code(dyc), 1, stream())
+                    b_sink = None
+                elif b_sink is not None:
+                    _mark_touched(bias)
+                    b_sink.add_(dy2.float().sum(0))
                     b_sink = None
                 else:
-                    gb = s.to(bias.dtype)
+                    gb = dy2.float().sum(0).to(bias.dtype)
             else:
                 ws = RT.workspace(dy.device, 512 * C)
                 dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
@@ -349,6 +354,7 @@ class _LinearPacked(torch.autograd.Function):
         ctx.packed = (pw, pb)
         y = _gemm("fwd", lambda: _linear_fwd(x, pw.compute, pb.compute), x.numel() // x.shape[-1],
                   pw.compute.shape[0], pw.compute.shape[1])
+        ctx.set_materialize_grads(False)
         return (y, x.view_as(x)) if tap else y          # residual tap: see _Linear.forward
 
     @staticmethod

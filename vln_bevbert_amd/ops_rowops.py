@@ -58,6 +58,7 @@ class _BiasDropResLN(torch.autograd.Function):
         ctx.cfg = (rows, H, float(drop_p), RT.seed, off, residual is not None)
         ctx.posts = (post1 is not None, post2 is not None)
         ctx.return_z = return_z
+        ctx.set_materialize_grads(False)       # (y, z): the unused one arrives as None, not as a dense zero tensor
         if return_z:
             # pre-norm blocks (transformer.py:170-182): z = residual + dropout(x + bias) is the NEW residual stream and
             # y = LayerNorm(z) feeds the next sub-layer; the gradient arriving at z is added to LayerNorm's input gradient
@@ -145,6 +146,7 @@ class _BiasDropResLN32(torch.autograd.Function):
         ctx.save_for_backward(z32, mean, rstd)
         ctx.params = (bias, gamma, beta)
         ctx.cfg = (rows, H, float(drop_p), RT.seed, off, residual.dtype)
+        ctx.set_materialize_grads(False)       # an unused output arrives as None (backward handles it), not as dense zeros
         return y16, y32
 
     @staticmethod
@@ -157,7 +159,7 @@ class _BiasDropResLN32(torch.autograd.Function):
             dy32 = torch.zeros_like(z32)
         dy16 = dy16.contiguous() if dy16 is not None else None
         dy32 = dy32.contiguous() if dy32 is not None else None
-        dz32 = torch.empty_like(z32)
+        dz32 = torch.empty(z32.shape, dtype=res_dtype, device=dev)     # the residual's gradient, in the residual's dtype
         dx16 = torch.empty(z32.shape, dtype=torch.bfloat16, device=dev)
         outs = []
         for p in (gamma, beta, bias):
@@ -177,14 +179,15 @@ class _BiasDropResLN32(torch.autograd.Function):
             nb = _partial_rows(rows)
             part = RT.scratch.alloc(nb * 3 * H * 4, dev)
             call("bevbert_layernorm_res32_bwd", ptr(dy16), ptr(dy32), ptr(z32), ptr(mean), ptr(rstd), ptr(_f32(gamma)),
-                 ptr(dz32), ptr(dx16), None, None, None, part, rows, H, drop_p, seed, off, 1, stream())
+                 ptr(dz32), ptr(dx16), None, None, None, part, rows, H, drop_p, seed, off, 1, dtype_code(dz32), stream())
             ReduceQueue.add(part, nb, 3, H, (ptr(dg), ptr(db), ptr(dbi)))
         else:
             ws = RT.workspace(dev, lib.load().bevbert_colsum_workspace_floats(3 * H))
             call("bevbert_layernorm_res32_bwd", ptr(dy16), ptr(dy32), ptr(z32), ptr(mean), ptr(rstd), ptr(_f32(gamma)),
-                 ptr(dz32), ptr(dx16), ptr(dg), ptr(db), ptr(dbi), ptr(ws), rows, H, drop_p, seed, off, ag, stream())
+                 ptr(dz32), ptr(dx16), ptr(dg), ptr(db), ptr(dbi), ptr(ws), rows, H, drop_p, seed, off, ag, dtype_code(dz32),
+                 stream())
         cast = lambda r, p: None if r is None else r.to(p.dtype)
-        gres = dz32 if res_dtype == torch.float32 else dz32.to(torch.bfloat16)      # (a bf16 residual: where a stream starts)
+        gres = dz32
         return dx16, cast(rbi, bias) if bias is not None else None, gres, cast(rg, gamma), cast(rb, beta), None, None
 
 
@@ -202,13 +205,14 @@ def bias_dropout_residual_layernorm(x, bias, residual, gamma, beta, eps, drop_p=
 
 
 def bias_dropout_residual_prenorm(x, bias, residual, gamma, beta, eps, drop_p=0.0, training=False):
-    """(LayerNorm(z), z) with z = residual + dropout(x + bias): one launch for the residual add of a pre-norm block AND the
+    """(LayerNorm(z), z) with z = residual + dropout(x + bias) (residual None: z = dropout(x + bias), the dropout in front of
+    a pre-norm stack): one launch for the residual add of a pre-norm block AND the
     LayerNorm that opens the next sub-layer (transformer.py:170-182); backward likewise (the gradient reaching z from the
     rest of the stream is folded into the LayerNorm backward kernel).  Inference / no-grad callers get the two tensors
     from the same launch too."""
     p = float(drop_p) if training else 0.0
-    if not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad)):
-        assert x.is_contiguous() and residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype
+    if not (torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))):
+        assert x.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.shape == x.shape and residual.dtype == x.dtype))
         H = x.shape[-1]
         rows = x.numel() // H
         y, z = torch.empty_like(x), torch.empty_like(x)
@@ -449,6 +453,39 @@ class _BiasGelu(torch.autograd.Function):
         return dx, db.to(bias.dtype), None
 
 
+class _WeightedMean(torch.autograd.Function):
+    """sum_i w[i] x[i] / denom as ONE launch each way (loss.mean() of the step, train_r2r.py:263, with the zero-weight
+    padding rows of a static batch): x fp32 (n), w fp32 (n) or None, denom a device scalar or a Python number."""
+
+    @staticmethod
+    def forward(ctx, x, w, denom):
+        x = x.contiguous()
+        assert x.dtype == torch.float32 and x.dim() == 1 and (w is None or (w.dtype == torch.float32 and w.shape == x.shape))
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        dd = denom if torch.is_tensor(denom) else None
+        call("bevbert_weighted_mean_fwd", ptr(x), ptr(w), ptr(dd), 1.0 if dd is not None else float(denom), x.numel(), ptr(out),
+             stream())
+        ctx.w, ctx.denom, ctx.n = w, denom, x.numel()
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous().to(torch.float32)
+        dx = torch.empty(ctx.n, dtype=torch.float32, device=dout.device)
+        dd = ctx.denom if torch.is_tensor(ctx.denom) else None
+        call("bevbert_weighted_mean_bwd", ptr(dout), ptr(ctx.w), ptr(dd), 1.0 if dd is not None else float(ctx.denom), ctx.n,
+             ptr(dx), stream())
+        return dx, None, None
+
+
+def weighted_mean(x, w=None, denom=None):
+    """(w * x).sum() / denom; denom defaults to the number of elements (plain mean)."""
+    if not x.is_cuda:
+        s = (x if w is None else x * w).sum()
+        return s / (x.numel() if denom is None else denom)
+    return _WeightedMean.apply(x, w, x.numel() if denom is None else denom)
+
+
 class _TakeRows(torch.autograd.Function):
     """rows = x2d[idx] for one or two index vectors of ONE tensor (a second selection from the same activations -- the
     centre cell next to the candidate cells of the SAP head -- shares the backward's zero-initialised gradient tensor:
@@ -560,14 +597,18 @@ class _EmbedLN(torch.autograd.Function):
             call("bevbert_layernorm_bwd", ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(_f32(gamma)), ptr(dz), None,
                  ptr(rg), ptr(rb), None, ptr(ws), rows, H, dtype_code(dy), 0.0, 0, 0, 0, stream())
         dz2 = dz.reshape(rows, H)
-        dzf = dz2.float()
+        dzf = dz2          # (kept alive by the deferred closures below)
 
         def word_grad(t):
             call("bevbert_embedding_grad", ptr(ids), ptr(dz2), ptr(t), rows, H, pad_idx, dtype_code(dz2), stream())
 
-        makers = ((word, word_grad),
-                  (pos, lambda t: _on_launch_stream(lambda: t[:L].add_(dzf.view(B, L, H).sum(0)))),
-                  (typ, lambda t: _on_launch_stream(lambda: t[type_index].add_(dzf.sum(0)))))
+        def pos_grad(t):        # position p receives the sum over the batch: column sums of dz viewed as (B, L * H)
+            call("bevbert_colsum_any", ptr(dz2), ptr(t), B, L * H, dtype_code(dz2), 1, stream())
+
+        def typ_grad(t):        # (only when the LayerNorm backward's third column sum could not take it, see styp)
+            call("bevbert_colsum_any", ptr(dz2), ptr(t[type_index]), rows, H, dtype_code(dz2), 1, stream())
+
+        makers = ((word, word_grad), (pos, pos_grad), (typ, typ_grad))
         outs, deferred = [], []
         for p, make in makers:
             if not p.requires_grad:
@@ -680,7 +721,8 @@ def bev_lift_bin(depths, T_c2w, T_w2c, S_w2c, pix, dim, res, depth_scale=10.0, y
     P = V * hw * hw
     dev = depths.device
     cell = torch.empty(B, P, dtype=torch.int32, device=dev)
-    order = torch.zeros(B, P, dtype=torch.int32, device=dev)
+    order = torch.empty(B, P, dtype=torch.int32, device=dev)
+    call("bevbert_zero", ptr(order), order.numel() * 4, stream())       # (dropped points leave their slots unwritten)
     cell_start = torch.empty(B, dim * dim + 1, dtype=torch.int32, device=dev)
     f = lambda t: t.contiguous().float()
     d, a, b_, c_ = f(depths), f(T_c2w), f(T_w2c), f(S_w2c)
@@ -726,7 +768,7 @@ def bev_splat_mean(feat, order, cell_start, K, out_dtype=None, sems=None, n_clas
             sem_dense = sems.contiguous().to(torch.float64)
             S = sems.shape[-1]
         out_sem = torch.empty(B, K, S, dtype=torch.uint8, device=feat.device)
-        out_mask = torch.empty(B, K, dtype=torch.uint8, device=feat.device)
+        out_mask = torch.empty(B, K, dtype=torch.bool, device=feat.device)     # the kernel writes the bytes 0 / 1
     call("bevbert_bev_splat_mean", ptr(feat), dtype_code(feat), ptr(order), ptr(cell_start), ptr(out),
          dtype_code(out_dtype), B, P, K, C, ptr(sem_ids), ptr(sem_dense), S, ptr(out_sem), ptr(out_mask),
          ptr(rows.contiguous() if rows is not None else None), R, stream())

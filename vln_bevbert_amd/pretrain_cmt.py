@@ -207,7 +207,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         bev_pos_fts = torch.cat([bev_gpos_fts.expand(-1, K, -1), polar[None].expand(B, -1, -1)], dim=-1)
         batch.update({
             "bev_fts": bev_fts,
-            "bev_masks": torch.ones(B, K, dtype=torch.bool, device=dev),           # pretrain_cmt.py:152
+            "bev_masks": self._all_ones(B, K, dev),                                # pretrain_cmt.py:152
             "bev_pos_fts": bev_pos_fts,
             "bev_sems": bev_sems,
             "bev_sem_masks": None if bev_sem_masks is None else bev_sem_masks.bool(),
@@ -215,6 +215,15 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             "_bev_cell": cell,
         })
         return batch
+
+    def _all_ones(self, B, K, dev):
+        """The all-ones BEV mask of pretrain_cmt.py:152, built once per shape (it is read-only: the kernels skip it, see
+        ``_bev_masks_all_ones``) instead of filled every step."""
+        c = self.__dict__.setdefault("_ones_cache", {})
+        t = c.get((B, K, dev))
+        if t is None:
+            t = c[(B, K, dev)] = torch.ones(B, K, dtype=torch.bool, device=dev)
+        return t
 
     def drop_feats(self, batch):
         # fp32 loader features leave the dropout in the compute dtype (the cast the input projections need anyway)
@@ -309,7 +318,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             if compute_loss == "mean":
                 # cross-entropy straight from the head's logits (fp32 statistics, no fp32 copy of rows x vocabulary)
                 per_row = ops.cross_entropy_rows(self.mlm_head(masked), st["mlm_targets"])
-                return (per_row * st["mlm_valid"]).sum() / st["mlm_n_dev"]     # row count of the batch in the buffers
+                return ops.weighted_mean(per_row, st["mlm_valid"], st["mlm_n_dev"])     # / row count of the batch in the buffers
             scores = self.mlm_head(masked).float()
             scores = scores[:n]
             if compute_loss:
@@ -364,7 +373,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             loss = ops.sap_loss(graw, lraw, fraw, b["gmap_visited_masks"], b["gmap_lens"], b["bev_nav_masks"],
                                 cand_idxs, st["sap_src"], st["sap_vis_c"], b["global_act_labels"],
                                 b["local_act_labels"])
-            return loss.mean() if compute_loss == "mean" else loss
+            return ops.weighted_mean(loss) if compute_loss == "mean" else loss
         if self.sap_fuse_linear is None:
             fuse_weights = 0.5
         else:

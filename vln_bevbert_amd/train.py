@@ -410,7 +410,14 @@ class PretrainTrainer:
         if self.reducer is not None and self.reducer.timeline is not None:           # bench.py's region timeline
             self.backward_start = torch.cuda.Event(enable_timing=True)
             self.backward_start.record()
-        loss.backward()
+        if loss.is_cuda and loss.dim() == 0:
+            # the seed gradient of backward(): one persistent device scalar instead of a ones_like fill per step
+            one = self.__dict__.get("_one")
+            if one is None or one.dtype != loss.dtype or one.device != loss.device:
+                one = self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+            loss.backward(gradient=one)
+        else:
+            loss.backward()
         self.arena.sync()                      # side-stream work has written its gradients
         self.reducer.finish()
         return loss.detach()

@@ -464,14 +464,20 @@ class TransformerEncoder(nn.Module):
                                     config.hidden_dropout_prob) for _ in range(num_layers)])
         self.norm = nn.LayerNorm(config.hidden_size, eps=1e-12)      # ops.py:19-20
 
-    def forward(self, src, src_key_padding_mask, key_mask=None):
-        """``key_mask``: the additive fp32 form of ``src_key_padding_mask`` (0 / -inf) if the caller has it already."""
+    def forward(self, src, src_key_padding_mask, key_mask=None, in_drop_p=None):
+        """``key_mask``: the additive fp32 form of ``src_key_padding_mask`` (0 / -inf) if the caller has it already.
+        ``in_drop_p``: the caller's dropout on ``src`` has NOT been applied yet -- it is drawn inside the launch of the first
+        block's norm1 (the dropped tensor is the residual stream: without this its two consumers, norm1 and the first
+        residual add, cost a dropout launch forward and a gradient-sum launch backward)."""
         km = key_mask
         if km is None and src_key_padding_mask is not None:      # boolean key_padding_mask -> -inf on padded keys (vilmodel.py:530-532)
             km = torch.zeros(src_key_padding_mask.shape, dtype=torch.float32, device=src.device)
             km = km.masked_fill(src_key_padding_mask, float("-inf")).contiguous()
         src = src.contiguous()
         h = None
+        if in_drop_p:
+            n1 = self.layers[0].norm1
+            h, src = ops.bias_dropout_residual_prenorm(src, None, None, n1.weight, n1.bias, 1e-5, in_drop_p, True)
         for i, layer in enumerate(self.layers):
             nxt = self.layers[i + 1].norm1 if i + 1 < len(self.layers) else self.norm
             eps = 1e-5 if i + 1 < len(self.layers) else 1e-12
@@ -557,11 +563,14 @@ class ImageEmbeddings(nn.Module):
         else:       # plain-tensor parameters (no arena): the torch composition
             e = e + embedding_lookup(type_embed_layer, torch.ones(1, 1, dtype=torch.long, device=e.device))
             e = ops.layernorm(e, self.layer_norm.weight, self.layer_norm.bias, 1e-12)
-        e = ops.dropout(e, self.drop_p, self.training)
+        fuse_drop = self.pano_encoder is not None and self.training and self.drop_p > 0 and e.is_cuda
+        if not fuse_drop:
+            e = ops.dropout(e, self.drop_p, self.training)
         masks = gen_seq_masks(lens, e.shape[1])
         if self.pano_encoder is not None:
             km = getattr(masks, "_km_inf", None)          # loader-built (static_step.StaticBatch)
-            e = self.pano_encoder(e, None if km is not None else masks.logical_not(), key_mask=km)
+            e = self.pano_encoder(e, None if km is not None else masks.logical_not(), key_mask=km,
+                                  in_drop_p=self.drop_p if fuse_drop else None)
         return e, masks
 
     def forward(self, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types, traj_step_lens,
