@@ -219,10 +219,10 @@ int bevbert_weighted_mean_bwd(const float* dout, const float* w, const float* de
 /* Graph-aware attention bias of the global-map encoder (pretrain_src/model/vilmodel.py:543-546,575-577: sprel_linear =
  * nn.Linear(1, 1) over the pairwise node distances).  fwd: out[i] = dists[i] * *w + *b (w, b: the parameters in device
  * memory).  bwd: *dw += sum dbias * dists, *db += sum dbias over the (layers, B, nh, G, G) per-head bias gradients the
- * attention backward leaves for every layer that used the bias (dists: (B, G, G)); one workgroup, fixed summation order. */
+ * attention backward leaves for every layer that used the bias (dists: (B, G, G)); two stages, fixed summation order. */
 int bevbert_graph_bias_fwd(const float* dists, const float* w, const float* b, float* out, int64_t n, hipStream_t stream);
 int bevbert_graph_bias_bwd(const float* dbias, const float* dists, int layers, int B, int nh, int G, float* dw, float* db,
-                           hipStream_t stream);
+                           float* workspace /* 1024 floats */, hipStream_t stream);
 
 /* Row selection of activations and its backward (the reference indexes with boolean masks / index tensors:
  * pretrain_src/model/pretrain_cmt.py:254-256 masked tokens of the MLM head, :321-326 candidate cells of the SAP head, :403-410

@@ -64,6 +64,19 @@ def main():
                                     ptr(dx) if p > 0 else None, None, None, None, ptr(ws), rows, H, BF16, p, 1, 0, 0, stream()))
             nb = rows * H * 2 * (4 if p > 0 else 3)
             print(json.dumps({"kernel": "ln_bwd", "rows": rows, "p": p, "us": round(t, 2), "bytes": nb, "mark": _mark_idx[0], "GBps": round(nb / t / 1e3, 1)}), flush=True)
+        # the fp32-residual-stream pair (bench default since round 6): x bf16 + residual fp32 -> y bf16, y fp32, z fp32;
+        # backward dy bf16 + dy fp32 + z fp32 -> dz fp32 + dx bf16
+        r32 = torch.randn(rows, H, device=dev)
+        y32, z32, dy32, dz32 = (torch.empty(rows, H, device=dev) for _ in range(4))
+        for p in (0.1, 0.0):
+            t = timeit(lambda: call("bevbert_layernorm_res32_fwd", ptr(x), ptr(bias), ptr(r32), 0, ptr(gamma), ptr(beta), ptr(y),
+                                    ptr(y32), ptr(z32), ptr(mean), ptr(rstd), rows, H, 1e-12, p, 1, 0, stream()))
+            nb = rows * H * (2 + 4 + 2 + 4 + 4)
+            print(json.dumps({"kernel": "ln_res32_fwd", "rows": rows, "p": p, "us": round(t, 2), "bytes": nb, "mark": _mark_idx[0], "GBps": round(nb / t / 1e3, 1)}), flush=True)
+            t = timeit(lambda: call("bevbert_layernorm_res32_bwd", ptr(dy), ptr(dy32), ptr(z32), ptr(mean), ptr(rstd), ptr(gamma),
+                                    ptr(dz32), ptr(dx), None, None, None, ptr(ws), rows, H, p, 1, 0, 0, 0, stream()))
+            nb = rows * H * (2 + 4 + 4 + 4 + 2)
+            print(json.dumps({"kernel": "ln_res32_bwd", "rows": rows, "p": p, "us": round(t, 2), "bytes": nb, "mark": _mark_idx[0], "GBps": round(nb / t / 1e3, 1)}), flush=True)
         C = 3072
         xi = torch.randn(rows, C, device=dev).bfloat16()
         yi, dyi, dxi = torch.empty_like(xi), torch.randn(rows, C, device=dev).bfloat16(), torch.empty_like(xi)

@@ -47,7 +47,7 @@ def cls(name):
     if any(k in n for k in ("attn_", "ln_fwd", "ln_bwd", "bev_", "colwise", "colsum", "bias_gelu", "gather_wsum",
                             "adamw", "sumsq", "clip_coef", "cast_f32", "keep_mask", "accum_partials", "dropout_add",
                             "embedding_grad", "multi_accum", "multi_finalize", "sap_loss", "ce_fwd", "ce_bwd", "gm_",
-                            "colsum_finalize", "ln_res32", "smallk_", "rows_gather", "rows_scatter")):
+                            "colsum_finalize", "ln_res32", "smallk_", "rows_gather", "rows_scatter", "graph_bias", "weighted_mean", "colsum_any")):
         return "custom"
     if any(k in n for k in ("cijk", "gemm", "tensile", "hipblaslt", "rocblas")):
         return "gemm"

@@ -945,28 +945,37 @@ __global__ __launch_bounds__(256) void graph_bias_fwd_kernel(const float* __rest
   const float ww = *w, bb = *b;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = dists[i] * ww + bb;
 }
-__global__ __launch_bounds__(1024) void graph_bias_bwd_kernel(const float* __restrict__ dbias, const float* __restrict__ dists,
-                                                              int64_t n, int per_sample, int64_t per_layer, int nh_gg, int gg,
-                                                              float* __restrict__ dw, float* __restrict__ db) {
+// stage 1: workgroup g sums a contiguous run of elements -> partials[g] = (sum dbias * dists, sum dbias); stage 2: one
+// wave folds the partials in ascending order and adds them to the two gradients
+__global__ __launch_bounds__(256) void graph_bias_bwd_kernel(const float* __restrict__ dbias, const float* __restrict__ dists,
+                                                             uint32_t n, uint32_t per_sample, uint32_t per_layer,
+                                                             uint32_t nh_gg, uint32_t gg, float2* __restrict__ partials) {
   // dbias: (layers, B, nh, G, G); element e -> sample (e % per_layer) / nh_gg, pair e % gg
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
   float sw = 0.f, sb = 0.f;
-  for (int64_t e = threadIdx.x; e < n; e += 1024) {
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += 256) {
     const float d = dbias[e];
-    const int64_t r = e % per_layer;
-    const int smp = (int)(r / nh_gg), qk = (int)(r % gg);
-    sw = fmaf(d, dists[(size_t)smp * per_sample + qk], sw);
+    const uint32_t r = e % per_layer;
+    sw = fmaf(d, dists[(r / nh_gg) * per_sample + r % gg], sw);
     sb += d;
   }
-  __shared__ float s_w[16], s_b[16];
+  __shared__ float s_w[4], s_b[4];
   sw = wave_sum(sw);
   sb = wave_sum(sb);
   if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = sw; s_b[threadIdx.x >> 6] = sb; }
   __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = make_float2((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]), (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]));
+}
+__global__ __launch_bounds__(64) void graph_bias_finalize_kernel(const float2* __restrict__ partials, int nb,
+                                                                 float* __restrict__ dw, float* __restrict__ db) {
+  float sw = 0.f, sb = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 64) { sw += partials[i].x; sb += partials[i].y; }
+  sw = wave_sum(sw);
+  sb = wave_sum(sb);
   if (threadIdx.x == 0) {
-    float tw = 0.f, tb = 0.f;
-    for (int i = 0; i < 16; ++i) { tw += s_w[i]; tb += s_b[i]; }
-    if (dw) *dw += tw;
-    if (db) *db += tb;
+    if (dw) *dw += sw;
+    if (db) *db += sb;
   }
 }
 
@@ -982,12 +991,17 @@ BEVBERT_API int bevbert_graph_bias_fwd(const float* dists, const float* w, const
 }
 
 BEVBERT_API int bevbert_graph_bias_bwd(const float* dbias, const float* dists, int layers, int B, int nh, int G, float* dw,
-                                       float* db, hipStream_t stream) {
-  BB_REQUIRE(layers > 0 && B > 0 && nh > 0 && G > 0, "graph_bias_bwd: empty problem");
-  const int64_t per_layer = (int64_t)B * nh * G * G;
-  hipLaunchKernelGGL(graph_bias_bwd_kernel, dim3(1), dim3(1024), 0, stream, dbias, dists, per_layer * layers, G * G, per_layer,
-                     nh * G * G, G * G, dw, db);
+                                       float* db, float* workspace, hipStream_t stream) {
+  BB_REQUIRE(layers > 0 && B > 0 && nh > 0 && G > 0 && workspace != nullptr, "graph_bias_bwd: empty problem or no workspace");
+  const int64_t per_layer = (int64_t)B * nh * G * G, n = per_layer * layers;
+  BB_REQUIRE(n < 2147483647, "graph_bias_bwd: %lld elements do not fit 31 bits", (long long)n);
+  int nb = (int)((n + 4095) / 4096);
+  if (nb > 512) nb = 512;                                 // workspace: 2 * 512 floats
+  hipLaunchKernelGGL(graph_bias_bwd_kernel, dim3(nb), dim3(256), 0, stream, dbias, dists, (uint32_t)n, (uint32_t)(G * G),
+                     (uint32_t)per_layer, (uint32_t)(nh * G * G), (uint32_t)(G * G), reinterpret_cast<float2*>(workspace));
   BB_CHECK_LAUNCH("graph_bias_bwd");
+  hipLaunchKernelGGL(graph_bias_finalize_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const float2*>(workspace), nb, dw, db);
+  BB_CHECK_LAUNCH("graph_bias_bwd finalize");
   return BB_OK;
 }
 
@@ -1089,18 +1103,19 @@ BEVBERT_API int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* 
   return BB_OK;
 }
 
-static int partial_blocks(int rows, int per_block) {
-  int nb = (rows + per_block - 1) / per_block;
-  if (nb > 512) nb = 512;
-  return nb < 1 ? 1 : nb;
-}
-
-// row groups of the column kernels: enough blocks to fill the chip, >= 16 rows each, <= 512 partial rows
+// row groups of the column kernels (and of the LayerNorm backward, whose partial rows go through the same second stage):
+// enough blocks to fill the chip, <= 512 partial rows.  Rows per block: 16 from 8 192 rows up (the 28 224-row BEV
+// problems: 512 blocks); below that the kernels are latency-bound -- a wave walks its rows one after the other, every row
+// a dependent load -> reduce -> store chain -- and 10 rows per block (two or three per wave; 512 blocks for the 5 120 text
+// rows instead of 320) shortens that chain.  BEVBERT_ROWS_PER_BLOCK overrides (A/B measurements).
 static int colwise_blocks(int rows) {
-  int nb = (rows + 15) / 16;
+  static const int env = [] { const char* v = getenv("BEVBERT_ROWS_PER_BLOCK"); return v ? atoi(v) : 0; }();
+  const int per = env > 0 ? env : (rows >= 8192 ? 16 : 10);
+  int nb = (rows + per - 1) / per;
   if (nb > 512) nb = 512;
   return nb < 1 ? 1 : nb;
 }
+static int partial_blocks(int rows, int) { return colwise_blocks(rows); }
 
 // row groups of a purely elementwise row kernel (no partial rows to bound): 8 rows each, at most 4096 groups
 static int elementwise_row_groups(int rows) {

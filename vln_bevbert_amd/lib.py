@@ -97,7 +97,7 @@ _PROTOS = {
     "bevbert_embedding_grad": [_P, _P, _P, _I, _I, _I, _I, _P],
     "bevbert_rows_gather": [_P, _P, _P, _I, _I, _I, _P],
     "bevbert_graph_bias_fwd": [_P, _P, _P, _P, _I64, _P],
-    "bevbert_graph_bias_bwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "bevbert_graph_bias_bwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "bevbert_smallk_linear_layernorm_fwd": [_P] * 11 + [_I, _I, _I, _F, _I, _P],
     "bevbert_smallk_linear_layernorm_bwd": [_P] * 12 + [_I, _I, _I, _I, _P],
     "bevbert_rows_scatter": [_P, _P, _P, _I, _I, _I, _I, _P],

@@ -153,7 +153,8 @@ class _GraphBias(torch.autograd.Function):
                 _mark_touched(p)
             sinks.append(s)
         B, G = dists.shape[0], dists.shape[-1]
-        call("bevbert_graph_bias_bwd", ptr(h.buf), ptr(dists), h.layers, B, h.nh, G, ptr(sinks[0]), ptr(sinks[1]), stream())
+        ws = torch.empty(1024, dtype=torch.float32, device=dists.device)
+        call("bevbert_graph_bias_bwd", ptr(h.buf), ptr(dists), h.layers, B, h.nh, G, ptr(sinks[0]), ptr(sinks[1]), ptr(ws), stream())
         return None, None, None, None, None
 
 
