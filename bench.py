@@ -177,6 +177,37 @@ def algorithmic_work(key, args, esize):
         return 0.0, args[2] * (4 + size_of[args[3]])
     if key == "bevbert_accum_partials":
         return 0.0, args[2] * args[3] * size_of[args[4]] + 8 * args[3]
+    if key == "bevbert_layernorm_res32_fwd":        # x bf16 + residual (fp32 | bf16) in; y bf16, y fp32 (, z fp32) out
+        rows, H = args[11], args[12]
+        return 0.0, rows * H * (2 + size_of[args[3]] + 2 + 4 + (4 if args[8] is not None else 0))
+    if key == "bevbert_layernorm_res32_bwd":        # dy bf16, dy fp32, z fp32 in; dz (fp32 | bf16), dx bf16 out
+        rows, H = args[12], args[13]
+        return 0.0, rows * H * ((2 if args[0] is not None else 0) + (4 if args[1] is not None else 0) + 4
+                                + (size_of[args[18]] if args[6] is not None else 0) + (2 if args[7] is not None else 0))
+    if key == "bevbert_smallk_linear_layernorm_fwd":    # feat in; post1, gathered table row in; y out (no z)
+        rows, K, H = args[11], args[12], args[13]
+        e = size_of[args[15]]
+        return 0.0, rows * (K * 4 + H * e * (1 + (args[5] is not None) + (args[6] is not None)))
+    if key == "bevbert_smallk_linear_layernorm_bwd":    # dy and feat in; nothing but the parameter gradients out
+        rows, K, H = args[12], args[13], args[14]
+        return 0.0, rows * (K * 4 + H * size_of[args[15]])
+    if key == "bevbert_rows_gather":
+        return 0.0, args[3] * args[4] * size_of[args[5]] * 2 + args[3] * 8
+    if key == "bevbert_rows_scatter":
+        return 0.0, args[3] * args[4] * size_of[args[5]] * 2 + args[3] * 8
+    if key == "bevbert_zero":
+        return 0.0, float(args[1])
+    if key == "bevbert_colsum_any":
+        return 0.0, args[2] * args[3] * size_of[args[4]]
+    if key in ("bevbert_graph_bias_fwd",):
+        return 0.0, args[4] * 8.0
+    if key == "bevbert_graph_bias_bwd":
+        return 0.0, args[2] * args[3] * args[4] * args[5] * args[5] * 4.0
+    if key in ("bevbert_weighted_mean_fwd", "bevbert_weighted_mean_bwd"):
+        return 0.0, args[4] * 8.0
+    if key == "bevbert_bev_lift_bin":               # depths + poses in; cell ids, sorted order, cell starts out
+        B, V, hw, dim = args[5], args[6], args[7], args[9]
+        return 0.0, B * (V * hw * hw * (4 + 4 + 4) + V * 64 + (dim * dim + 1) * 4)
     if key == "bevbert_segment_wsum":               # lower bound: the edge count lives in the device CSR
         return 0.0, args[5] * args[6] * size_of[args[7]] * 2
     return 0.0, 0.0
@@ -802,9 +833,10 @@ def side_configs(a):
             ("finetune_rollout_b32_15steps_infer_feedback", [sys.executable, os.path.join(ROOT, "scripts", "bench_nav.py"),
                                                              "--batch", "32", "--steps", "15", "--iters", "4", "--warmup", "3",
                                                              "--mode", "infer", "--feedback"]),
-            # training rollout: 15 forwards, ONE backward through all of them, clip + AdamW (agent.py:339-420); eager issue
+            # training rollout: 15 forwards, ONE backward through all of them, clip + AdamW (agent.py:339-420): forward and
+            # backward graph per step of the episode (nav_static.NavTrainRunner)
             ("finetune_rollout_b32_15steps_train", [sys.executable, os.path.join(ROOT, "scripts", "bench_nav.py"), "--batch", "32",
-                                                    "--steps", "15", "--iters", "3", "--warmup", "2", "--mode", "train"])]
+                                                    "--steps", "15", "--iters", "3", "--warmup", "3", "--mode", "train"])]
     res = {}
     for name, cmd in jobs:
         if time.perf_counter() - T_START > budget_s:

@@ -29,7 +29,7 @@ from vln_bevbert_amd.feature_store import GridFeatureStore  # noqa: E402
 from vln_bevbert_amd.graph_map import GraphMapBatch  # noqa: E402
 from vln_bevbert_amd.graph_map_dev import DeviceGraphMap  # noqa: E402
 from vln_bevbert_amd.nav_model import VLNBert  # noqa: E402
-from vln_bevbert_amd.nav_static import NavGraphRunner  # noqa: E402
+from vln_bevbert_amd.nav_static import NavGraphRunner, NavTrainRunner  # noqa: E402
 from vln_bevbert_amd.pretrain_cmt import bevpos_polar  # noqa: E402
 
 
@@ -92,13 +92,19 @@ def main():
                      "view_lens": torch.full((B,), 36, dtype=torch.long, device=dev), "obj_lens": None})
     pix, polar = ops.pixel_scale(cfg.grid_hw, dev), bevpos_polar(cfg.bev_dim, dev)
     t_book = [0.0]
-    runner = NavGraphRunner(model) if a.mode == "infer" else None
-    use_graphs = [runner is not None and not a.no_graphs]
+    # infer: captured forward steps (nav_static.NavGraphRunner); train: forward + backward graphs per step of the episode
+    # (nav_static.NavTrainRunner; --no-graphs runs the same segments eagerly)
+    runner = NavGraphRunner(model) if a.mode == "infer" else NavTrainRunner(model, arena, graphs=not a.no_graphs)
+    use_graphs = [a.mode == "train" or not a.no_graphs]
+    if a.mode == "train":
+        a.warmup = max(a.warmup, runner.eager_uses + 1)      # eager episodes + the capture episode stay out of the timed region
 
     trace = []
 
     on_device = a.map == "device"
     actions = []
+
+    runner_box = [runner]
 
     def episode():
         start = [ob["viewpoint"] for ob in obs_all[0]]
@@ -120,6 +126,7 @@ def main():
                     gm.update_graph(obs, ended_all[t - 1])
                 gm.set_step_ids(obs, t, ended)
             t_book[0] += time.perf_counter() - h0
+            runner = runner_box[0]
             pe, pm = runner.panorama(pano[t]) if use_graphs[0] else model("panorama", pano[t])
             avg = (pe * pm[..., None]).sum(1) / pm.sum(1, keepdim=True)                       # agent.py:478-479
             h0 = time.perf_counter()
@@ -153,6 +160,7 @@ def main():
         return loss
 
     last_loss = [None]
+    grads_only = [False]
 
     def iteration(i):
         ops.RT.new_step(1000 + i)
@@ -160,12 +168,54 @@ def main():
             with torch.no_grad():
                 episode()
         else:
+            rn = runner_box[0]
+            rn.begin_episode()
+            if rn.capturing:                # the capture episode: forward graphs in rollout order, then the backward graphs
+                episode()                   # in reverse; nothing of its backward executes, so it does not train
+                rn.end_capture()
+                if rn.graph_error is not None:
+                    print("capture failed:", rn.graph_error, getattr(rn, "graph_traceback", ""), file=sys.stderr, flush=True)
+                return
             arena.zero_grad()
             loss = episode() / B
             loss.backward()
+            arena.sync()
+            if grads_only[0]:
+                last_loss[0] = loss.detach()
+                return
             arena.clip_and_step(1e-5, max_norm=40.0)
             last_loss[0] = loss.detach()
 
+    if a.check and a.mode == "train":
+        # captured training rollout against the same segments issued eagerly: from the same parameters and optimiser state,
+        # two training episodes, then the gradients of a third -- the arena must agree BIT FOR BIT (same kernels, same
+        # arguments, the deferred weight-gradient / reduction work flushed at the same points in the same order)
+        iteration(0)                                         # primes the optimiser state (and the library's GEMM plans)
+        torch.cuda.synchronize()
+        keep = {k: getattr(arena, k).clone() for k in ("params", "exp_avg", "exp_avg_sq", "chunk_steps")}
+        got = {}
+        for name, graphs in (("eager", False), ("graphs", True)):
+            for k, v in keep.items():
+                getattr(arena, k).copy_(v)
+            arena.sync_shadow()
+            runner_box[0] = NavTrainRunner(model, arena, graphs=graphs)
+            seeds = [11, 12] + ([13] if graphs else []) + [14]          # (the capture episode of the graph arm does not train)
+            for j, sd in enumerate(seeds):
+                grads_only[0] = j == len(seeds) - 1
+                iteration(sd)
+            torch.cuda.synchronize()
+            got[name] = (arena.grads.clone(), float(last_loss[0]), dict(runner_box[0].stats), runner_box[0].captured_graphs(),
+                         runner_box[0].graph_error)
+            grads_only[0] = False
+        g0, g1 = got["eager"][0], got["graphs"][0]
+        same = bool(torch.equal(g0, g1))
+        rel = float((g0.double() - g1.double()).norm() / g0.double().norm().clamp_min(1e-30))
+        print(json.dumps({"check": "ok" if (same and got["graphs"][3] > 0 and got["graphs"][4] is None) else "FAILED",
+                          "mode": "train", "batch": B, "steps": T, "dtype": a.dtype, "gradients_bitwise_equal": same,
+                          "gradient_rel_l2_diff": rel, "loss_eager": got["eager"][1], "loss_graphs": got["graphs"][1],
+                          "captured_graphs": got["graphs"][3], "runner": got["graphs"][2], "graph_error": got["graphs"][4],
+                          "grad_norm": float(g0.double().norm())}))
+        return
     if a.check:
         runs = []
         for _ in range(2):
@@ -249,7 +299,7 @@ def main():
                       "text_kv_cache": bool(use_graphs[0] and runner.text_cache and any("g_kv" in v for v in runner.shared.values())),
                       "step_launch": ("hipGraph replay per mode and shape bucket (%d graphs, %d replays, %d eager calls)"
                                       % (runner.captured_graphs(), runner.stats["replays"], runner.stats["eager"]))
-                      if use_graphs[0] else "eager",
+                      if (use_graphs[0] and runner.captured_graphs()) else "eager",
                       "graph_error": runner.graph_error if runner is not None else None}))
 
 

@@ -1049,12 +1049,31 @@ def test_training_rollout_backward_through_all_steps(env, which):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "bench_nav.py"), "--batch", "8", "--steps", "6", "--iters", "2",
-                        "--warmup", "1", "--mode", "train", "--map", which], capture_output=True, text=True, timeout=600,
+                        "--warmup", "1", "--mode", "train", "--no-graphs", "--map", which], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, BEVBERT_SCRATCH_MB="256"))      # a small ring: the pass needs several buffers
     assert p.returncode == 0, p.stderr[-2000:]
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["map"] == which and rec["step_launch"] == "eager" and rec["ms_per_nav_step"] > 0, rec
     assert rec["final_loss"] is not None and np.isfinite(rec["final_loss"]) and rec["final_loss"] > 0, rec
+
+
+def test_captured_training_rollout_equals_the_eager_one_bit_for_bit(env):
+    """nav_static.NavTrainRunner: a training rollout with one forward and one backward hipGraph per
+    (step of the episode, shape bucket) -- activations in the graphs' pool from a step's forward replay to its backward
+    replay, the deferred weight-gradient / reduction work of a segment flushed inside its backward graph -- against the
+    same segments issued eagerly: after two training episodes from the same state the gradient arena of the third episode
+    is bit-identical (scripts/bench_nav.py --mode train --check), and the graphs really were replayed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "bench_nav.py"), "--batch", "8", "--steps", "6", "--mode", "train",
+                        "--check"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["check"] == "ok" and rec["gradients_bitwise_equal"], rec
+    assert rec["graph_error"] is None and rec["captured_graphs"] >= 2 * 2 * 6 and rec["runner"]["replays"] >= 2 * 2 * 6, rec
+    assert rec["loss_eager"] == rec["loss_graphs"] and rec["grad_norm"] > 0, rec
 
 
 def test_host_feed_ships_a_step_of_host_arrays_in_one_copy(env):

@@ -27,6 +27,7 @@ def call(name, *args):
     return ops.call(name, *args)
 
 CHUNK = 1024
+_ZERO_KERNEL = __import__("os").environ.get("BEVBERT_ZERO_KERNEL", "0") == "1"      # A/B: fill kernel instead of a memset command
 NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")   # optim/misc.py:14 (substring match)
 
 
@@ -254,7 +255,10 @@ class ParamArena:
                     self._zero_stream = torch.cuda.Stream(self.device)
                 self._zero_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self._zero_stream):
-                    call("bevbert_zero", ptr(self.grads), self.grads.numel() * 4, stream())
+                    if _ZERO_KERNEL:
+                        self.grads.zero_()
+                    else:
+                        call("bevbert_zero", ptr(self.grads), self.grads.numel() * 4, stream())
                 self._zero_pending = True
                 return
             call("bevbert_zero", ptr(self.grads), self.grads.numel() * 4, stream())
