@@ -113,6 +113,8 @@ def parse():
 
 def algorithmic_work(key, args, esize):
     """(flops, bytes) one launch of a traced C-ABI call is worth ALGORITHMICALLY."""
+    if "[rows=" in key:                      # the row kernels are traced per problem size (ops_core.call)
+        key = key.split("[")[0]
     if key.startswith("bevbert_attn_fwd"):
         B, nh, Lq, Lk = args[8], args[9], args[10], args[11]
         return 4.0 * B * nh * Lq * Lk * 64, (2 * Lq + 2 * Lk) * nh * 64 * B * esize
@@ -688,7 +690,7 @@ def main():
             # time the many short text launches of the forward would win)
             key, top = max(cand, key=lambda kv: (max(kv[1]["gflop"], kv[1]["mb"] * 1e-3) / max(kv[1]["launches"], 1), kv[1]["ms"]))
             traffic = traffic_source = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
-            for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", name)) as f:
                         traffic = json.load(f).get(key)

@@ -233,6 +233,10 @@ class Branches:
 # that a caller (a test, bench.py) that swaps them reaches every module of the package.
 
 
+_ROWS_ARG = {"bevbert_layernorm_res32_fwd": 11, "bevbert_layernorm_res32_bwd": 12, "bevbert_bias_dropout_residual_layernorm_fwd": 9,
+             "bevbert_layernorm_bwd": 11, "bevbert_layernorm_bwd_add": 12, "bevbert_bias_gelu_fwd": 3, "bevbert_bias_gelu_bwd": 6}
+
+
 def call(name, *args):
     """C-ABI call; when RT.trace is armed, bracket the launch with HIP events on the launching stream."""
     if RT.trace is None:
@@ -242,6 +246,8 @@ def call(name, *args):
         key = f"{name}[Lq={args[10]},Lk={args[11]}]"
     elif name == "bevbert_attn_bwd":
         key = f"{name}[Lq={args[16]},Lk={args[17]}]"
+    elif name in _ROWS_ARG:                     # the row kernels by problem size too (5 120 text rows vs 28 224 BEV rows)
+        key = f"{name}[rows={args[_ROWS_ARG[name]]}]"
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     _raw_call(name, *args)
