@@ -121,6 +121,12 @@ def bf16_grad_close(got, ref, what, tag=None):
     factor = _GATE["factor"]
     if _GATE["suffix"] == "_res32" and ref_l2 > RES32_NOISY_REF:
         factor = max(factor, RES32_NOISY_FACTOR)
+    if what.endswith("sprel_linear.weight"):
+        # ONE number: the sum of B x heads x G x G x layers signed terms (d bias x distance) that nearly cancel.  The same code
+        # measured 0.096, 0.164 (round 5) and 0.13 - 0.22 (round 6) on different boxes -- the library picks its GEMM algorithms
+        # by timing on the box, and their rounding decides where the cancellation lands; the reference's own autocast run is
+        # 0.099 off.  Held to the plain-bf16 factor in either mode.
+        factor = max(factor, REF_FACTOR)
     gate = min(BF16_GRAD_CEIL_OVERRIDE.get(f"{tag}::{what}", BF16_GRAD_CEIL), max(BF16_GRAD_FLOOR, factor * ref_l2))
     _record("grad" + _GATE["suffix"], f"{tag}::{what}", rel_l2=l2, ref_rel_l2=ref_l2, gate=gate)
     assert l2 < gate, (tag, what, f"relative L2 {l2:.3e} (gate {gate:.3e} = min(ceiling, max({BF16_GRAD_FLOOR}, {factor} x "
