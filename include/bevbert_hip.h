@@ -216,6 +216,18 @@ int bevbert_weighted_mean_fwd(const float* x, const float* w, const float* denom
 int bevbert_weighted_mean_bwd(const float* dout, const float* w, const float* denom_dev, float denom, int n, float* dx,
                               hipStream_t stream);
 
+/* Semantic head's loss (pretrain_src/model/pretrain_cmt.py:391-441).  sem_select: row numbers of the cells with mask1 (and
+ * mask2, if given) set, compacted in ascending order into idx (cap entries; padding: row 0), valid[i] = 1 for the real ones,
+ * *denom = count x classes -- one workgroup, no host sync for the data-dependent count.  bce_rows_fwd: out[r] = sum over the
+ * C classes of binary_cross_entropy_with_logits(logits[r, c], labels[idx[r], c]) (labels uint8 {0, 1}; idx NULL: row r);
+ * bce_rows_bwd: dlogits[r, c] = (sigmoid(logits[r, c]) - label) * g[r]. */
+int bevbert_sem_select(const uint8_t* mask1, const uint8_t* mask2, int n, int cap, int classes, int64_t* idx, float* valid,
+                       float* denom, hipStream_t stream);
+int bevbert_bce_rows_fwd(const void* logits, const uint8_t* labels, const int64_t* idx, float* out, int rows, int C, int dtype,
+                         hipStream_t stream);
+int bevbert_bce_rows_bwd(const void* logits, const uint8_t* labels, const int64_t* idx, const float* g, void* dlogits, int rows,
+                         int C, int dtype, hipStream_t stream);
+
 /* Graph-aware attention bias of the global-map encoder (pretrain_src/model/vilmodel.py:543-546,575-577: sprel_linear =
  * nn.Linear(1, 1) over the pairwise node distances).  fwd: out[i] = dists[i] * *w + *b (w, b: the parameters in device
  * memory).  bwd: *dw += sum dbias * dists, *db += sum dbias over the (layers, B, nh, G, G) per-head bias gradients the

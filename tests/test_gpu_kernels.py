@@ -402,6 +402,41 @@ def test_smallk_linear_layernorm_plus(ops, dtype, rows, K, T):
     assert torch.equal(y2, y) and torch.equal(g2, g)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_semantic_head_loss_select_and_bce(ops, dtype):
+    """ops.sem_select + ops.bce_rows + ops.weighted_mean (pretrain_cmt.py:391-441 on a static batch): the cells with both
+    masks set, compacted in ascending order into a fixed capacity (padding row 0 / weight 0), the divisor count x classes,
+    the per-row BCE-with-logits sums read through the index, and the weighted mean -- against the torch composition,
+    forward and gradient; also an empty selection and one that exceeds the capacity."""
+    torch.manual_seed(9)
+    N, C, cap = 28224, 40, 4608
+    m1 = torch.rand(N, device=DEV) < 0.4
+    m2 = torch.rand(N, device=DEV) < 0.35
+    labels = (torch.rand(N, C, device=DEV) < 0.1).to(torch.uint8)
+    idx, valid, denom = ops.sem_select(m1, m2, cap, C)
+    want = torch.nonzero(m1 & m2).squeeze(1)
+    n = int(want.numel())
+    assert 0 < n < cap and torch.equal(idx[:n], want) and int(idx[n:].abs().max()) == 0
+    assert float(valid.sum()) == n and bool((valid[:n] == 1).all()) and float(denom) == n * C
+    logits = (2 * torch.randn(cap, C, device=DEV)).to(dtype).requires_grad_(True)
+    loss = ops.weighted_mean(ops.bce_rows(logits, labels, idx), valid, denom)
+    lr = logits.detach().float().requires_grad_(True)
+    per = torch.nn.functional.binary_cross_entropy_with_logits(lr, labels[idx].float(), reduction="none")
+    ref = (per * valid[:, None]).sum() / (n * C)
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    loss.backward()
+    ref.backward()
+    assert rel_err(logits.grad, lr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert float(logits.grad[n:].float().abs().max()) == 0.0            # padding rows carry no gradient
+    # one mask only; nothing selected; more cells than the capacity (the first ``cap`` in order, the divisor still the count)
+    idx1, valid1, denom1 = ops.sem_select(m1, None, N, C)
+    assert torch.equal(idx1[:int(m1.sum())], torch.nonzero(m1).squeeze(1)) and float(denom1) == float(m1.sum()) * C
+    idx0, valid0, denom0 = ops.sem_select(torch.zeros(N, dtype=torch.bool, device=DEV), None, 64, C)
+    assert float(valid0.sum()) == 0 and float(denom0) == 0 and int(idx0.abs().max()) == 0
+    idx2, valid2, denom2 = ops.sem_select(torch.ones(N, dtype=torch.bool, device=DEV), None, 100, C)
+    assert torch.equal(idx2, torch.arange(100, device=DEV)) and float(valid2.sum()) == 100 and float(denom2) == N * C
+
+
 def test_embed_sum_layernorm(ops):
     torch.manual_seed(3)
     V, H, B, L = 500, 768, 3, 17

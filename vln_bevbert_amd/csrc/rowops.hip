@@ -936,6 +936,102 @@ BEVBERT_API int bevbert_weighted_mean_bwd(const float* dout, const float* w, con
   return BB_OK;
 }
 
+// Semantic head (pretrain_cmt.py:391-441, MaskSEM / SEM): the supervised cells are those of a boolean mask (two masks ANDed
+// for MaskSEM) -- a data-dependent count only the device knows.  sem_select: ONE workgroup compacts their row numbers into a
+// fixed-capacity index (padding: row 0, weight 0), and leaves the weights and the divisor of the mean (count x classes).
+// bce_rows: sum over the classes of binary_cross_entropy_with_logits for the selected rows, labels read through the index.
+__global__ __launch_bounds__(1024) void sem_select_kernel(const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2, int n,
+                                                         int cap, int classes, int64_t* __restrict__ idx,
+                                                         float* __restrict__ valid, float* __restrict__ denom) {
+  __shared__ int s_cnt[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024, lo = t * per, hi = min(n, lo + per);
+  int c = 0;
+  for (int i = lo; i < hi; ++i) c += (m1[i] != 0) && (m2 == nullptr || m2[i] != 0);
+  s_cnt[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {       // inclusive scan (Hillis-Steele; 10 rounds on 1024 counters)
+    const int v = (t >= off) ? s_cnt[t - off] : 0;
+    __syncthreads();
+    s_cnt[t] += v;
+    __syncthreads();
+  }
+  const int total = s_cnt[1023];
+  int pos = s_cnt[t] - c;
+  for (int i = lo; i < hi; ++i)
+    if ((m1[i] != 0) && (m2 == nullptr || m2[i] != 0)) {
+      if (pos < cap) idx[pos] = i;
+      ++pos;
+    }
+  const int kept = total < cap ? total : cap;
+  for (int i = t; i < cap; i += 1024) {
+    if (i >= kept) idx[i] = 0;
+    valid[i] = i < kept ? 1.0f : 0.0f;
+  }
+  if (t == 0) *denom = (float)total * (float)classes;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bce_rows_fwd_kernel(const T* __restrict__ x, const uint8_t* __restrict__ labels,
+                                                           const int64_t* __restrict__ idx, float* __restrict__ out, int rows,
+                                                           int C) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint8_t* lab = labels + (size_t)(idx ? idx[row] : row) * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = io<T>::ld(x + (size_t)row * C + c), y = lab[c] ? 1.0f : 0.0f;
+    s += fmaxf(v, 0.f) - v * y + log1pf(__expf(-fabsf(v)));       // the numerically stable form torch uses
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bce_rows_bwd_kernel(const T* __restrict__ x, const uint8_t* __restrict__ labels,
+                                                           const int64_t* __restrict__ idx, const float* __restrict__ g,
+                                                           T* __restrict__ dx, int rows, int C) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint8_t* lab = labels + (size_t)(idx ? idx[row] : row) * C;
+  const float gr = g[row];
+  for (int c = lane; c < C; c += 64) {
+    const float v = io<T>::ld(x + (size_t)row * C + c), y = lab[c] ? 1.0f : 0.0f;
+    io<T>::st(dx + (size_t)row * C + c, (1.0f / (1.0f + __expf(-v)) - y) * gr);
+  }
+}
+
+BEVBERT_API int bevbert_sem_select(const uint8_t* mask1, const uint8_t* mask2, int n, int cap, int classes, int64_t* idx,
+                                   float* valid, float* denom, hipStream_t stream) {
+  BB_REQUIRE(mask1 != nullptr && n > 0 && cap > 0 && classes > 0, "sem_select: bad arguments");
+  hipLaunchKernelGGL(sem_select_kernel, dim3(1), dim3(1024), 0, stream, mask1, mask2, n, cap, classes, idx, valid, denom);
+  BB_CHECK_LAUNCH("sem_select");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_bce_rows_fwd(const void* logits, const uint8_t* labels, const int64_t* idx, float* out, int rows,
+                                     int C, int dtype, hipStream_t stream) {
+  BB_REQUIRE(rows >= 0 && C > 0, "bce_rows_fwd: rows=%d C=%d", rows, C);
+  if (rows == 0) return BB_OK;
+  const dim3 grid((rows + 3) / 4);
+  if (dtype == BB_F32) hipLaunchKernelGGL(bce_rows_fwd_kernel<float>, grid, dim3(256), 0, stream, (const float*)logits, labels, idx, out, rows, C);
+  else if (dtype == BB_BF16) hipLaunchKernelGGL(bce_rows_fwd_kernel<bf16_raw>, grid, dim3(256), 0, stream, (const bf16_raw*)logits, labels, idx, out, rows, C);
+  else { bb_set_error("bce_rows_fwd: dtype %d unsupported", dtype); return BB_EUNSUPPORTED; }
+  BB_CHECK_LAUNCH("bce_rows_fwd");
+  return BB_OK;
+}
+
+BEVBERT_API int bevbert_bce_rows_bwd(const void* logits, const uint8_t* labels, const int64_t* idx, const float* g, void* dlogits,
+                                     int rows, int C, int dtype, hipStream_t stream) {
+  BB_REQUIRE(rows >= 0 && C > 0, "bce_rows_bwd: rows=%d C=%d", rows, C);
+  if (rows == 0) return BB_OK;
+  const dim3 grid((rows + 3) / 4);
+  if (dtype == BB_F32) hipLaunchKernelGGL(bce_rows_bwd_kernel<float>, grid, dim3(256), 0, stream, (const float*)logits, labels, idx, g, (float*)dlogits, rows, C);
+  else if (dtype == BB_BF16) hipLaunchKernelGGL(bce_rows_bwd_kernel<bf16_raw>, grid, dim3(256), 0, stream, (const bf16_raw*)logits, labels, idx, g, (bf16_raw*)dlogits, rows, C);
+  else { bb_set_error("bce_rows_bwd: dtype %d unsupported", dtype); return BB_EUNSUPPORTED; }
+  BB_CHECK_LAUNCH("bce_rows_bwd");
+  return BB_OK;
+}
+
 // Graph-aware attention bias of the global-map encoder (vilmodel.py:543-546, 575-577: sprel_linear = nn.Linear(1, 1) on
 // the pairwise node distances): bias = dists * w + b with w, b read from the parameters in device memory; and its backward
 // over the per-head, per-layer bias gradients the attention kernels leave: dw = sum dbias * dists, db = sum dbias.  One

@@ -90,6 +90,9 @@ _PROTOS = {
     "bevbert_layernorm_res32_fwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U64, _P],
     "bevbert_layernorm_res32_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U64, _I, _I, _P],
     "bevbert_colsum_any": [_P, _P, _I, _I, _I, _I, _P],
+    "bevbert_sem_select": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "bevbert_bce_rows_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "bevbert_bce_rows_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "bevbert_weighted_mean_fwd": [_P, _P, _P, _F, _I, _P, _P],
     "bevbert_weighted_mean_bwd": [_P, _P, _P, _F, _I, _P, _P],
     "bevbert_layernorm_bwd_add": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U64, _I, _P],

@@ -30,7 +30,7 @@ from .ops_gemm import (  # noqa: F401
     linear_res, load_gemm_tuning_table, save_gemm_tuning_table)
 from .ops_rowops import (  # noqa: F401
     SegmentCSR, _BiasDropResLN, _BiasDropResLN32, _BiasGelu, _CrossEntropy, _DropoutAdd, _EmbedLN, _SapLoss,
-    _SegmentWsum, bev_bin_points, bev_lift_bin, bev_splat_mean, bias_dropout_residual_layernorm, bias_dropout_residual_prenorm, bias_gelu, bias_relu, take_rows, weighted_mean, bias_layernorm_plus, smallk_linear_layernorm_plus, smallk_linear_layernorm_plus_supported,
+    _SegmentWsum, bev_bin_points, bev_lift_bin, bev_splat_mean, bias_dropout_residual_layernorm, bias_dropout_residual_prenorm, bias_gelu, bias_relu, take_rows, weighted_mean, bce_rows, sem_select, bias_layernorm_plus, smallk_linear_layernorm_plus, smallk_linear_layernorm_plus_supported,
     cross_entropy_rows, dropout, dropout_keep_mask, embed_sum_layernorm, embedding_grad_small, layernorm, pixel_scale, sap_loss,
     sap_loss_supported, segment_wsum)
 from .ops_attention import (  # noqa: F401

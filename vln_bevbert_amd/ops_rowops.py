@@ -486,6 +486,49 @@ def weighted_mean(x, w=None, denom=None):
     return _WeightedMean.apply(x, w, x.numel() if denom is None else denom)
 
 
+class _BceRows(torch.autograd.Function):
+    """per_row[r] = sum_c binary_cross_entropy_with_logits(logits[r, c], labels[idx[r], c]) -- the semantic head's loss
+    (pretrain_cmt.py:391-441) with the uint8 label rows read through the selection index, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, idx):
+        logits = logits.contiguous()
+        rows, C = logits.shape
+        assert labels.dtype == torch.uint8 and labels.is_contiguous() and labels.shape[-1] == C
+        out = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        call("bevbert_bce_rows_fwd", ptr(logits), ptr(labels), ptr(idx), ptr(out), rows, C, dtype_code(logits), stream())
+        ctx.save_for_backward(logits, labels, idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, idx = ctx.saved_tensors
+        rows, C = logits.shape
+        dx = torch.empty_like(logits)
+        call("bevbert_bce_rows_bwd", ptr(logits), ptr(labels), ptr(idx), ptr(g.contiguous().float()), ptr(dx), rows, C,
+             dtype_code(logits), stream())
+        return dx, None, None
+
+
+def bce_rows(logits, labels, idx=None):
+    return _BceRows.apply(logits, labels, idx)
+
+
+@torch.no_grad()
+def sem_select(mask1, mask2, cap, classes):
+    """(idx int64 (cap), valid fp32 (cap), denom fp32 scalar) of the cells with mask1 & mask2 set (bool / uint8 tensors);
+    see include/bevbert_hip.h bevbert_sem_select."""
+    m1 = mask1.reshape(-1).contiguous()
+    m2 = None if mask2 is None else mask2.reshape(-1).contiguous()
+    assert m1.dtype in (torch.bool, torch.uint8) and (m2 is None or (m2.dtype in (torch.bool, torch.uint8) and m2.numel() == m1.numel()))
+    dev = m1.device
+    idx = torch.empty(cap, dtype=torch.int64, device=dev)
+    valid = torch.empty(cap, dtype=torch.float32, device=dev)
+    denom = torch.empty((), dtype=torch.float32, device=dev)
+    call("bevbert_sem_select", ptr(m1), ptr(m2), m1.numel(), cap, classes, ptr(idx), ptr(valid), ptr(denom), stream())
+    return idx, valid, denom
+
+
 class _TakeRows(torch.autograd.Function):
     """rows = x2d[idx] for one or two index vectors of ONE tensor (a second selection from the same activations -- the
     centre cell next to the candidate cells of the SAP head -- shares the backward's zero-initialised gradient tensor:

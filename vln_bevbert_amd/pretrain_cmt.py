@@ -408,7 +408,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             return loss.mean() if compute_loss == "mean" else loss
         return global_logits, local_logits, fused_logits, b["global_act_labels"], b["local_act_labels"]
 
-    def _sem_common(self, b, sel, compute_loss):
+    def _sem_common(self, b, sel, compute_loss, sel2=None):
         bev_embeds = self.bert.forward_sem(*self._cmt_args(b), sem_pred_token=self.sem_pred_token, **self._host_kw(b))
         st = b.get("_static")
         if st is not None and compute_loss == "mean":
@@ -416,16 +416,26 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             # on which cells the splat filled) are compacted into a fixed number of rows >= the count (the loader knows
             # an upper bound: the number of masked cells); the padding re-reads row 0 and carries zero weight
             cap = st["sem_cap"]
-            flat = sel.reshape(-1)
+            sems = b["bev_sems"].reshape(-1, b["bev_sems"].shape[-1])
+            flat_e = bev_embeds.reshape(-1, bev_embeds.shape[-1])
+            if flat_e.is_cuda and sems.dtype == torch.uint8:
+                # one launch compacts the supervised cells (both masks) into the fixed-capacity index and leaves the weights and
+                # the divisor; the loss reads the label rows through the index (ops.bce_rows) and is averaged by one launch
+                idx, valid, denom = ops.sem_select(sel, sel2, cap, sems.shape[-1])
+                masked = ops.take_rows(flat_e, idx)
+                per_row = ops.bce_rows(self.local_sem_head(masked), sems.contiguous(), idx)
+                return ops.weighted_mean(per_row, valid, denom)
+            flat = (sel if sel2 is None else sel & sel2).reshape(-1)
             idx = torch.nonzero_static(flat, size=cap, fill_value=0).squeeze(1)
             count = flat.sum()
             valid = (torch.arange(cap, device=flat.device) < count).to(torch.float32)
-            flat_e = bev_embeds.reshape(-1, bev_embeds.shape[-1])
-            masked = ops.take_rows(flat_e, idx) if flat_e.is_cuda else flat_e.index_select(0, idx)
+            masked = flat_e.index_select(0, idx)
             sem_logits = self.local_sem_head(masked).float()
-            sem_labels = b["bev_sems"].reshape(-1, b["bev_sems"].shape[-1]).index_select(0, idx).float()
+            sem_labels = sems.index_select(0, idx).float()
             per = F.binary_cross_entropy_with_logits(sem_logits, sem_labels, reduction="none")
             return (per * valid[:, None]).sum() / (count.to(torch.float32) * per.shape[1])
+        if sel2 is not None:
+            sel = sel & sel2
         masked = bev_embeds[sel]                               # data-dependent row count: one sync, as the reference
         sem_logits = self.local_sem_head(masked).float()
         sem_labels = b["bev_sems"][sel].float()
@@ -440,4 +450,4 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def forward_masksem(self, b, compute_loss):
         mrc = b["bev_mrc_masks"]
         b["bev_fts"] = b["bev_fts"].detach().masked_fill(mrc.unsqueeze(-1), 0)        # pretrain_cmt.py:423-424
-        return self._sem_common(b, b["bev_sem_masks"] & mrc, compute_loss)
+        return self._sem_common(b, b["bev_sem_masks"], compute_loss, sel2=mrc)
