@@ -922,6 +922,11 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     for t in tasks:
         synthetic.collate(samples[:a.batch] if len(samples) >= a.batch else (samples * a.batch)[:a.batch], cfg, t, rng, sems_as="ids")
     collate_ms = 1000.0 * (time.perf_counter() - t0) / len(tasks)
+    # with a live loader the gradient-arena fill stays in line at the start of the step: beside the loader's host->device
+    # copies the side-stream fill costs what it hides (round 6, same box: sustained 17.92 in line vs 18.14 ms beside the forward;
+    # resident batches 17.89 vs 17.58).  The buffer sets of this run are captured with the setting in force here.
+    overlap_zero_was = trainer.overlap_zero
+    trainer.overlap_zero = os.environ.get("BEVBERT_OVERLAP_ZERO_SUSTAINED", "0") == "1" and overlap_zero_was
     mgr = BucketManager(cfg, dev, depth=2, max_buckets=64, grid_store=store)
     # warm-up: every (bucket, buffer set) has to be seen GRAPH_WARMUP + 1 times before its step is a replay
     per_task_uses = {t: max(1, cycle.count(t)) for t in tasks}
@@ -980,6 +985,8 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
            "h2d_MB_per_step": round(st.get("bytes_h2d", 0) / n / 1e6, 2)}
     if plans0 is not None:
         res["gemm_plans_added"] = ops.gemm_plan_count() - plans0
+    res["arena_fill"] = "beside the forward (side stream)" if trainer.overlap_zero else "in line"
+    trainer.overlap_zero = overlap_zero_was
     del store
     return res
 

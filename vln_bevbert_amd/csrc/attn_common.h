@@ -46,6 +46,7 @@ struct AttnArgs {
   void *dq, *dk, *dv;      // same strides as q/k/v
   float* dbias;            // (B, nh, Lq, Lk) fp32 per-head bias gradients (every element written once, no atomics; the
                            // caller folds the heads in a fixed order), or null
+  int dbg;                 // timing ablations of attn_short.hip (BEVBERT_SHORT_DBG; results WRONG): 1 no output stores, 2 no O loads
 };
 
 // XCD-aware decode of a 1-D grid: hardware places workgroup id on XCD id % 8, each XCD has a private L2.  Work items

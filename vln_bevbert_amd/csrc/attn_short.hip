@@ -260,7 +260,7 @@ __global__ __launch_bounds__(384) void attn_short_bwd_kernel(AttnArgs a) {
       if (row < a.Lq) {
         qv[i] = ld_frag_global(qp, a.ldq, row, ch * 8);
         dv[i] = ld_frag_global(dop, a.ldo, row, ch * 8);
-        ov[i] = ld_frag_global(op, a.ldo, row, ch * 8);
+        if (!(a.dbg & 2)) ov[i] = ld_frag_global(op, a.ldo, row, ch * 8);
       }
     }
 #pragma unroll
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(384) void attn_short_bwd_kernel(AttnArgs a) {
   __syncthreads();
   if (w < NKT) {
     const int key = t * 16 + c;
-    if (key < a.Lk) {
+    if (key < a.Lk && !((a.dbg & 1) && lane != 0)) {
       bf16_raw* dkp = (bf16_raw*)a.dk + (size_t)b * a.bsk + (size_t)key * a.ldk + h * ATTN_D;
       bf16_raw* dvp = (bf16_raw*)a.dv + (size_t)b * a.bsv + (size_t)key * a.ldv + h * ATTN_D;
 #pragma unroll
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(384) void attn_short_bwd_kernel(AttnArgs a) {
       }
     }
     const int qrow = qt * 16 + c;
-    if (qrow < a.Lq) {
+    if (qrow < a.Lq && !((a.dbg & 1) && lane != 0)) {
       bf16_raw* dqp = (bf16_raw*)a.dq + (size_t)b * a.bsq + (size_t)qrow * a.ldq + h * ATTN_D;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -470,6 +470,8 @@ static void sh_launch_bwd_q(const AttnArgs& a, int nqt, dim3 grid, hipStream_t s
 
 int attn_short_bwd(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
+  static const int dbg = [] { const char* v = getenv("BEVBERT_SHORT_DBG"); return v ? atoi(v) : 0; }();
+  a.dbg = dbg;
   const int nqt = sh_round_tiles((a.Lq + 15) / 16), nkt = sh_round_tiles((a.Lk + 15) / 16);
   a.nblk = 1;
   const dim3 grid((unsigned)a.nh * a.B);
