@@ -735,7 +735,7 @@ def _ema(xs, beta=0.9):
     return np.asarray(out)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, "bf16_res32"], ids=["fp32", "bf16", "bf16_res32"])
 def test_100_step_loss_curve_overlaps_the_reference(env, dtype):
     """north_star: "loss curves overlapping for 100 steps".  The golden curve was produced by the REFERENCE's model,
     AdamW, schedule and loop body (tests/golden/make_golden.py --curve, dropout disabled); the product trains the same
@@ -751,7 +751,8 @@ def test_100_step_loss_curve_overlaps_the_reference(env, dtype):
     model = GlocalTextPathCMTPreTraining(cfg)
     model.load_state_dict(weights.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
     model.tie_weights()
-    arena = model.finalize(DEV, dtype)
+    # "bf16_res32": bf16 GEMMs / attention with the residual stream in fp32 -- the mode bench.py measures by default
+    arena = model.finalize(DEV, torch.bfloat16, residual=torch.float32) if dtype == "bf16_res32" else model.finalize(DEV, dtype)
     model.train()
     model.set_dropout(0.0)
     sampler = TaskSampler("mlm.5.sap.5.masksem.1", seed=int(g["sampler_seed"]))

@@ -39,6 +39,10 @@ GMAP_PAD = 4            # global-map width G (batch max of the node counts) is r
 # text to TXT_PAD tokens (beyond txt_lens: masked like the reference's own padding), panoramas to PANO_PAD dummy
 # panoramas of ONE zero view (no segment of the global-map aggregation refers to them and their outputs feed nothing, so
 # they contribute exact zeros to every gradient; one valid view keeps their softmax finite), views to VIEW_PAD.
+# Dropout masks are a hash of (seed, launch counter, row-major element index): a padded axis moves the indices, so a padded
+# batch draws DIFFERENT (equally distributed) masks than the same batch unpadded or than a run of rounds 1-4 with the same
+# seed -- run-to-run reproducibility holds for a fixed set of pads, not across pad settings (all three = 1 restores the
+# unpadded indices).  With dropout off the two are the same step (test_static_batch_step_equals_the_reference_api_step).
 _env_int = lambda k, d: int(__import__("os").environ.get(k, d))
 TXT_PAD = _env_int("BEVBERT_TXT_PAD", 16)
 PANO_PAD = _env_int("BEVBERT_PANO_PAD", 32)

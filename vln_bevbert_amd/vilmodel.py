@@ -578,6 +578,10 @@ class ImageEmbeddings(nn.Module):
         e, _ = self.embed(traj_view_img_fts, traj_loc_fts, traj_nav_types, traj_vp_view_lens, type_embed_layer,
                           traj_obj_img_fts, traj_vp_obj_lens, traj_view_dep_fts)
         lens = traj_vp_view_lens if traj_obj_img_fts is None else traj_vp_view_lens + traj_vp_obj_lens
+        if e.shape[0] != sum(traj_step_lens):
+            # a static_step.StaticBatch appends dummy panoramas (PANO_PAD) that only the flat embed() / _traj() path may see
+            raise ValueError(f"{e.shape[0]} panoramas for step lengths summing to {sum(traj_step_lens)}: per-trajectory "
+                             "splits need the unpadded batch (reference API), not a StaticBatch")
         return torch.split(e, traj_step_lens, 0), torch.split(lens, traj_step_lens, 0)
 
 
