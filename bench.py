@@ -456,6 +456,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     value = a.steps * a.batch * world / dt
+    resident_events = None
+    if os.environ.get("BEVBERT_STEP_EVENTS") == "1":        # diagnosis (after the timed region): device time per step + gaps
+        marks = []
+        for _ in range(3 * len(cycle)):
+            t = cycle[counter[0] % len(cycle)]
+            marks.append((t, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            marks[-1][1].record()
+            run(1)
+            marks[-1][2].record()
+        barrier()
+        resident_events = _step_event_digest(marks)
+        log(f"step events, resident: {resident_events}")
     whole = None
     if a.steps % len(cycle):
         # K is not a whole number of 11-step task cycles (the driver's --steps 20): the K steps above are the contract's
@@ -498,6 +510,8 @@ def main():
     }
     if whole is not None:
         out["whole_cycles"] = whole
+    if resident_events is not None:
+        out["step_events_resident"] = resident_events
 
     # ---- forward ms/batch (the second half of BASELINE.json's metric; reference: train_r2r.py:256-260): the training
     # forward (dropout on, tape recorded) issued eagerly, and the same batch's inference forward replayed from a graph
@@ -770,9 +784,18 @@ def main():
                        "--no-cpu-baseline", "--no-kernel-pass", "--no-fwd", "--config", a.config, "--batch", str(a.batch),
                        "--txt-len", str(a.txt_len), "--txt-len-min", str(a.txt_len_min), "--stream-steps", str(a.stream_steps),
                        "--dtype", a.dtype, "--residual", a.residual]
-                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                child_detail = os.path.splitext(a.detail)[0] + "_ragged_child.json"
+                pr = subprocess.run(cmd + ["--detail", child_detail], capture_output=True, text=True, timeout=600)
                 d = json.loads([ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")][-1])
                 out["sustained_ragged"] = d.get("sustained")
+                try:                # the full block (loader timings, captures, waits) from the child's detail record
+                    with open(child_detail) as f:
+                        full = json.load(f)
+                    if isinstance(full.get("sustained"), dict):
+                        out["sustained_ragged"] = dict(full["sustained"], resident_ms_per_step_of_the_child=full.get("ms_per_step"))
+                    os.remove(child_detail)
+                except (OSError, ValueError):
+                    pass
             except Exception as e:      # noqa: BLE001
                 out["sustained_ragged"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -922,11 +945,12 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     for t in tasks:
         synthetic.collate(samples[:a.batch] if len(samples) >= a.batch else (samples * a.batch)[:a.batch], cfg, t, rng, sems_as="ids")
     collate_ms = 1000.0 * (time.perf_counter() - t0) / len(tasks)
-    # with a live loader the gradient-arena fill stays in line at the start of the step: beside the loader's host->device
-    # copies the side-stream fill costs what it hides (round 6, same box: sustained 17.92 in line vs 18.14 ms beside the forward;
-    # resident batches 17.89 vs 17.58).  The buffer sets of this run are captured with the setting in force here.
+    # BEVBERT_OVERLAP_ZERO_SUSTAINED=0: the gradient-arena fill in line at the start of the step (A/B knob).  Until the
+    # loader's copy stream was moved off the compute stream's hardware queue (loader.pick_copy_stream) the side-stream fill
+    # cost a live-loader run what it hid (18.14 vs 17.92 ms); with it: 18.06 beside the forward vs 18.36 in line (r06z).
+    # The buffer sets of this run are captured with the setting in force here.
     overlap_zero_was = trainer.overlap_zero
-    trainer.overlap_zero = os.environ.get("BEVBERT_OVERLAP_ZERO_SUSTAINED", "0") == "1" and overlap_zero_was
+    trainer.overlap_zero = os.environ.get("BEVBERT_OVERLAP_ZERO_SUSTAINED", "1") == "1" and overlap_zero_was
     mgr = BucketManager(cfg, dev, depth=2, max_buckets=64, grid_store=store)
     # warm-up: every (bucket, buffer set) has to be seen GRAPH_WARMUP + 1 times before its step is a replay
     per_task_uses = {t: max(1, cycle.count(t)) for t in tasks}
@@ -949,6 +973,7 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     replayed = eager = 0
     t0 = None
     stats0 = None
+    marks = [] if os.environ.get("BEVBERT_STEP_EVENTS") == "1" else None     # diagnosis: device time of every step + gaps
     for i in range(n_total):
         if i == n_warm:
             torch.cuda.synchronize()
@@ -957,7 +982,12 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
             t0 = time.perf_counter()
         task, sb = next(it)
         was_graph = sb.graph is not None
+        if marks is not None and i >= n_warm:
+            marks.append((task, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            marks[-1][1].record()
         trainer.step(task, sb)
+        if marks is not None and i >= n_warm:
+            marks[-1][2].record()
         loader.release(sb)
         replayed += was_graph
         eager += not was_graph
@@ -986,9 +1016,25 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     if plans0 is not None:
         res["gemm_plans_added"] = ops.gemm_plan_count() - plans0
     res["arena_fill"] = "beside the forward (side stream)" if trainer.overlap_zero else "in line"
+    res["copy_stream_probe"] = mgr.copy_stream_probe
+    if marks:
+        res["step_events"] = _step_event_digest(marks)
     trainer.overlap_zero = overlap_zero_was
     del store
     return res
+
+
+def _step_event_digest(marks):
+    """marks: (task, start event, end event) per step, recorded on the compute stream around trainer.step -> device time of
+    the steps by task and the idle time between the end of one step and the start of the next."""
+    by, gaps = {}, []
+    for j, (t, e0, e1) in enumerate(marks):
+        by.setdefault(t, []).append(e0.elapsed_time(e1))
+        if j:
+            gaps.append(marks[j - 1][2].elapsed_time(e0))
+    return {"device_ms_by_task": {t: round(sum(v) / len(v), 3) for t, v in by.items()},
+            "device_ms_per_step": round(sum(sum(v) for v in by.values()) / len(marks), 3),
+            "gap_ms_per_step": round(sum(gaps) / max(1, len(gaps)), 3), "gap_ms_max": round(max(gaps or [0.0]), 3)}
 
 
 def cpu_baseline(cfg, a):

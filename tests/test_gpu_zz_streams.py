@@ -524,3 +524,19 @@ def test_streaming_loader_single_task_stream_reuses_one_bucket_safely(env, graph
     assert len(set(np.round(d0, 5))) > 6, d0                      # the batches are distinguishable by their loss
     assert np.allclose(d0, s0, rtol=1e-5, atol=1e-6), (d0, s0)
     assert max(len(b["sets"]) for b in mgr.buckets.values()) == 2 and mgr.stats["refills"] >= 4
+
+
+def test_loader_copy_stream_is_off_the_compute_streams_hardware_queue(env):
+    """A process has four in-order hardware queues and its streams are dealt onto them: a refill enqueued on a copy stream
+    that shares the compute stream's queue runs behind the whole step in flight, and the next step starts one copy time
+    late (0.54 ms idle per step, r06w).  BucketManager probes a few fresh streams and keeps one whose work overtakes work
+    queued earlier on the compute stream."""
+    from vln_bevbert_amd.loader import BucketManager, shares_hw_queue
+    dev = torch.device("cuda", torch.cuda.current_device())
+    main = torch.cuda.current_stream(dev)
+    assert shares_hw_queue(main, main, dev)                      # the probe sees serialisation when there is some
+    mgr = BucketManager(BevBertConfig.tiny(), dev)
+    probe = mgr.copy_stream_probe
+    assert probe is not None and probe["picked"] is not None, probe
+    assert probe["shares_compute_queue"][-1] is False and all(probe["shares_compute_queue"][:-1]), probe
+    assert not shares_hw_queue(mgr.copy_stream, main, dev)       # and the answer is stable for the stream's lifetime
