@@ -288,7 +288,7 @@ def compact_line(out, detail_path=None):
             line["side_configs"][name] = short
     rc = out.get("rccl")
     if isinstance(rc, dict):
-        line["rccl"] = {x: rc[x] for x in ("ranks", "backend", "exchange", "allreduce_bytes_per_step", "allreduce_alone_ms",
+        line["rccl"] = {x: rc[x] for x in ("ranks", "backend", "exchange", "collectives_wait_behind_compute", "allreduce_bytes_per_step", "allreduce_alone_ms",
                                           "allreduce_alone_GBps", "eager_ms_per_step_by_exchange", "first_collective_at_fraction_of_backward",
                                           "error") if x in rc}
     if detail_path:
@@ -622,8 +622,12 @@ def main():
                         digest.append(ln.strip()[-160:])
         except Exception as e:      # noqa: BLE001
             digest = [f"no RCCL debug file: {e!r}"[:160]]
+        qr = trainer.reducer.queue_report or {}
+        behind = (qr.get("own_group") or qr).get("waits_behind_compute")
         out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
                        "exchange": trainer.reducer.exchange, "region_timeline": regions,
+                       # False = the collective stream has a hardware queue other than the compute stream's (hwqueues.py)
+                       "collectives_wait_behind_compute": behind, "collective_queue_report": qr,
                        "debug_digest": digest[:40], "debug_lines": len(digest),
                        "allreduce_bytes_per_step": int(arena.numel) * 4,
                        "phase_a_bytes": int(arena.numel - trainer.reducer.split) * 4,

@@ -540,3 +540,29 @@ def test_loader_copy_stream_is_off_the_compute_streams_hardware_queue(env):
     assert probe is not None and probe["picked"] is not None, probe
     assert probe["shares_compute_queue"][-1] is False and all(probe["shares_compute_queue"][:-1]), probe
     assert not shares_hw_queue(mgr.copy_stream, main, dev)       # and the answer is stable for the stream's lifetime
+
+
+def test_gradient_exchange_runs_off_the_compute_streams_hardware_queue(one_rank_group):
+    """The collective library issues on the next stream of torch's pool; one in four of those shares the compute stream's
+    in-order hardware queue, and an all-reduce there waits behind the backward kernels enqueued before it and holds up the
+    ones after it.  GradReducer.settle_collective_queue steers the pool before the group's first collective (or moves the
+    exchange to a group of its own) and reports what it found; afterwards a collective overtakes work queued earlier on
+    the compute stream."""
+    from vln_bevbert_amd.hwqueues import steer_stream_pool, shares_hw_queue
+    from vln_bevbert_amd.train import GradReducer
+    dev = torch.device("cuda", torch.cuda.current_device())
+    flat = torch.zeros(1 << 16, device=dev)
+    red = GradReducer(flat, 1 << 15, force=True)
+    rep = red.settle_collective_queue()
+    final = rep.get("own_group") or rep
+    assert final["waits_behind_compute"] is False, rep
+    assert red.collectives_wait_behind_compute() is False
+    assert not shares_hw_queue(red.stream, torch.cuda.current_stream(dev), dev)
+    # a second reducer of the process reuses the outcome
+    red2 = GradReducer(flat, 1 << 15, force=True)
+    assert red2.settle_collective_queue() is rep and red2.group is red.group
+    # the pool walk itself: 32 streams, cyclic, one in four on the compute stream's queue
+    st = steer_stream_pool(dev)
+    assert st["pool"] == 32 and 20 <= sum(st["wanted"]) <= 28 and st["next"] is not None, st
+    nxt = torch.cuda.Stream(dev)
+    assert not shares_hw_queue(nxt, torch.cuda.current_stream(dev), dev)

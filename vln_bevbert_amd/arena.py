@@ -252,7 +252,8 @@ class ParamArena:
             ops.RT.scratch.reset()        # partial-sum addresses repeat from step to step (ops.ReduceQueue caches on them)
             if overlap:
                 if getattr(self, "_zero_stream", None) is None:
-                    self._zero_stream = torch.cuda.Stream(self.device)
+                    from .hwqueues import side_stream
+                    self._zero_stream = side_stream(self.device)
                 self._zero_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self._zero_stream):
                     if _ZERO_KERNEL:

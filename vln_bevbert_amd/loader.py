@@ -27,60 +27,8 @@ import time
 
 import torch
 
+from .hwqueues import pick_copy_stream, shares_hw_queue  # noqa: F401 (re-exported)
 from .static_step import StaticBatch
-
-
-def shares_hw_queue(stream, main, device, busy_ms=3.0):
-    """True when work enqueued on ``stream`` waits behind work enqueued earlier on ``main``: the two HIP streams are served
-    by the same in-order hardware queue (a process has GPU_MAX_HW_QUEUES = 4 of them, streams are dealt onto them in
-    creation order).  Probe: ~busy_ms of fills on ``main``, then a 1 KB host->device copy on ``stream``; which finishes
-    first, seen from the host."""
-    busy = torch.empty(64 << 20, dtype=torch.float32, device=device)
-    src = torch.empty(1024, dtype=torch.uint8).pin_memory()
-    dst = torch.empty(1024, dtype=torch.uint8, device=device)
-    with torch.cuda.stream(stream):
-        dst.copy_(src, non_blocking=True)              # first use of the stream (queue acquisition) outside the probe
-    torch.cuda.synchronize(device)
-    reps = max(4, int(busy_ms / 0.06))                 # a 256 MB fill takes ~0.06 ms at 4-5 TB/s
-    m1, c1 = torch.cuda.Event(), torch.cuda.Event()
-    with torch.cuda.stream(main):
-        for _ in range(reps):
-            busy.fill_(1.0)
-        m1.record(main)
-    with torch.cuda.stream(stream):
-        dst.copy_(src, non_blocking=True)
-        c1.record(stream)
-    while not c1.query():
-        pass
-    shared = m1.query()                                # the copy came out only after everything on `main` had run
-    torch.cuda.synchronize(device)
-    return shared
-
-
-def pick_copy_stream(device, owner=None, candidates=6):
-    """The loader's copy stream: the first of a few fresh streams that does NOT sit on the compute stream's hardware queue.
-    A refill enqueued during step k on a stream that shares the compute stream's queue executes behind ALL of step k's
-    packets in that queue, i.e. after AdamW, and step k + 1 -- which waits for it -- starts one copy time late (round 6,
-    `BEVBERT_STEP_EVENTS=1 python bench.py`: 0.54 - 0.59 ms idle in front of every step, 3 % of the step).  On any other
-    queue the copy lands behind a side branch of the captured step (weight gradients, row sums), which is finished before
-    the clip + AdamW tail starts, and the copy hides under that tail.  A stream of its own priority level would get a
-    hardware queue of its own -- and a fifth active queue slows the whole step by 4 ms (same measurement, also
-    GPU_MAX_HW_QUEUES = 5, 6, 8: 23.1, 24.2, 27.5 ms against 17.6).  BEVBERT_COPY_STREAM_PROBE=0: first stream, unprobed."""
-    main = torch.cuda.current_stream(device)
-    if os.environ.get("BEVBERT_COPY_STREAM_PROBE", "1") != "1":
-        return torch.cuda.Stream(device)
-    tried = []
-    keep = []                                           # rejected candidates stay alive while probing: the next stream
-    for _ in range(candidates):                         # must not be handed the queue slot of a released one
-        st = torch.cuda.Stream(device)
-        keep.append(st)
-        shared = shares_hw_queue(st, main, device)
-        tried.append(bool(shared))
-        if not shared:
-            break
-    if owner is not None:
-        owner.copy_stream_probe = {"shares_compute_queue": tried, "picked": len(tried) - 1 if not tried[-1] else None}
-    return keep[-1] if not tried[-1] else keep[0]
 
 
 class BucketManager:

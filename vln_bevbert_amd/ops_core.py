@@ -134,7 +134,8 @@ class _AttnBitsPlanner:
             return
         dev = torch.cuda.current_device()
         if self.stream is None:
-            self.stream = torch.cuda.Stream(dev)
+            from .hwqueues import side_stream
+            self.stream = side_stream(torch.device("cuda", dev))
         cur = torch.cuda.current_stream(dev)
         self.stream.wait_stream(cur)             # after the salt fill (and, in a capture, part of the captured graph)
         ready = []
@@ -197,7 +198,8 @@ class Branches:
         if self.on:
             key = device.index
             if key not in Branches._streams:
-                Branches._streams[key] = torch.cuda.Stream(device)
+                from .hwqueues import side_stream
+                Branches._streams[key] = side_stream(device)
             self.stream = Branches._streams[key]
             self.main = torch.cuda.current_stream(device)
 

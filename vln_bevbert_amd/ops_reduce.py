@@ -97,12 +97,13 @@ class WgradStream:
             return
         if cls.stream is None:
             shared = Branches._streams.get(producer.device.index) if Branches.enabled and not cls.OWN_STREAM else None
-            cls.stream = shared if shared is not None else torch.cuda.Stream(producer.device)
+            from .hwqueues import side_stream
+            cls.stream = shared if shared is not None else side_stream(producer.device)
             Branches._streams["wgrad"] = cls.stream       # joined by ParamArena.sync / GradReducer like the branches
             cls._events = [torch.cuda.Event() for _ in range(64)]
             cls.streams = [cls.stream]
             for i in range(1, cls.NSTREAMS):              # further streams: batches of deferred work go round robin
-                st = torch.cuda.Stream(producer.device)
+                st = side_stream(producer.device)
                 Branches._streams[f"wgrad{i}"] = st
                 cls.streams.append(st)
         if final or len(cls.streams) == 1:

@@ -16,6 +16,7 @@ simply contribute zeros (the semantics of find_unused_parameters=True without th
 each step is drawn from a generator seeded identically on every rank, so the reference's per-step task-id broadcast
 (pretrain_src/data/loader.py:56-59) needs no collective at all.
 """
+import os
 import random
 
 import torch
@@ -88,13 +89,81 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         self.cuda = flat_grads.is_cuda
-        self.stream = torch.cuda.Stream() if (self.cuda and self.active) else None
+        self.stream = None
+        if self.cuda and self.active:
+            from .hwqueues import side_stream
+            self.stream = side_stream(flat_grads.device)
+        self.queue_report = None     # where the collectives run relative to the compute stream (_settle_collective_queue)
         self._works = []
         self._phase_a_done = False
         self._done = []          # [lo, hi) regions already issued in this step
         self.occupied = None     # sorted (start, end) of the tensors in the buffer (set_occupied): padding gaps are skipped
         self.timeline = None     # set to [] to collect (lo, hi, start event, end event) per region (bench.py's rccl block);
                                  # both events sit on the reducer's stream, the end one right behind its own collective
+
+    _settled = {}        # (device index, id of the group asked for) -> (group used, report): once per process
+
+    def settle_collective_queue(self):
+        """Once, before the first step (every rank, same point of the program): if the group's collectives wait behind the
+        compute stream's work (collectives_wait_behind_compute), and the group is the default one, move the gradient
+        exchange to a group of its own whose communicator takes a stream off the compute stream's hardware queue
+        (hwqueues.steer_stream_pool, then new_group).  BEVBERT_COLLECTIVE_QUEUE_CHECK=0 skips the whole check."""
+        if self.queue_report is not None or not (self.cuda and self.active) or \
+                os.environ.get("BEVBERT_COLLECTIVE_QUEUE_CHECK", "1") != "1":
+            return self.queue_report
+        settled = GradReducer._settled.get((self.flat.device.index, id(self.group)))
+        if settled is not None:                               # an earlier reducer of this process did the work
+            self.group, self.queue_report = settled
+            return self.queue_report
+        key = (self.flat.device.index, id(self.group))
+        from .hwqueues import steer_stream_pool
+        # the communicator of a group whose first collective is still to come takes the NEXT pool stream: make that one a
+        # stream on the reducer's own queue (the reducer's stream carries only the event edges of the same collectives;
+        # the other side streams -- deferred weight gradients, keep bits -- are dealt onto the remaining queues)
+        st = steer_stream_pool(self.flat.device, like=self.stream)
+        rep = {"steered": st and {"pool": st["pool"], "next": st["next"], "wanted": sum(st["wanted"])},
+               "waits_behind_compute": self.collectives_wait_behind_compute()}
+        if rep["waits_behind_compute"] and self.group is None:
+            # the default group had its communicator (and its stream) before we came: exchange on a group of our own
+            st = steer_stream_pool(self.flat.device, like=self.stream)
+            self.group = dist.new_group(backend=dist.get_backend())
+            rep["own_group"] = {"steered": st and {"pool": st["pool"], "next": st["next"]},
+                                "waits_behind_compute": self.collectives_wait_behind_compute()}
+        self.queue_report = rep
+        GradReducer._settled[key] = (self.group, rep)
+        return rep
+
+    def collectives_wait_behind_compute(self, busy_ms=3.0):
+        """Diagnosis (all ranks call it together): does a collective issued from the reducer's stream run only after work
+        enqueued EARLIER on the compute stream -- i.e. does the collective library's stream share the compute stream's
+        in-order hardware queue (hwqueues.py)?  Then eager steps get no overlap of the exchange with backward, whatever the
+        hooks do.  ~busy_ms of fills on the compute stream, then a 1 KB all-reduce from the side stream: which finishes
+        first.  Returns True / False for the whole group (MAX over ranks: one rank whose collective waits holds everyone
+        up), None when collectives are inactive or on CPU."""
+        if not (self.cuda and self.active and self.stream is not None):
+            return None
+        dev = self.flat.device
+        main = torch.cuda.current_stream(dev)
+        busy = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+        t = torch.zeros(256, device=dev)
+        dist.all_reduce(t, group=self.group)                  # communicator and its stream exist from here on
+        dist.barrier(group=self.group)
+        torch.cuda.synchronize(dev)
+        from .hwqueues import pick_copy_stream
+        issue = pick_copy_stream(dev)                         # a stream known to be off the compute stream's queue: the
+        m1, c1 = torch.cuda.Event(), torch.cuda.Event()       # collective's stream waits for an event on the issuing one
+        for _ in range(max(4, int(busy_ms / 0.06))):
+            busy.fill_(1.0)
+        m1.record(main)
+        with torch.cuda.stream(issue):                        # no wait on `main`: the probe asks about queues, not events
+            dist.all_reduce(t, group=self.group, async_op=True).wait()
+            c1.record(issue)
+        while not c1.query():
+            pass
+        waited = torch.tensor([1.0 if m1.query() else 0.0], device=dev)
+        torch.cuda.synchronize(dev)
+        dist.all_reduce(waited, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(waited.item() > 0)
 
     def drop_pending(self):
         """Forget the collectives of an aborted step (failed graph capture): the step is issued again eagerly."""
@@ -241,6 +310,7 @@ class PretrainTrainer:
         # the arena keeps registration order: embeddings, lang_encoder, img_embeddings come before the map encoders
         self.reducer = GradReducer(arena.grads, first_map, force=force_collectives)
         self.reducer.set_occupied(arena.slices.values())
+        self.reducer.settle_collective_queue()
         self.overlap = overlap and self.reducer.active
         # RCCL 2.26's all-to-all under stream capture takes the process down (segmentation fault on the MI355X box,
         # one-rank group, gpurun_out r03w) while all-reduce, reduce-scatter and all-gather capture fine: only steps with
