@@ -24,7 +24,7 @@ from .config import BevBertConfig
 
 LN_EPS = 1e-12
 # captured steps (a side stream exists): the text-independent front of the map / BEV branches runs beside the text encoder
-EARLY_BEV = __import__("os").environ.get("BEVBERT_EARLY_BEV", "0") == "1"     # measured SLOWER (18.39 vs 18.23 ms): off
+EARLY_BEV = __import__("os").environ.get("BEVBERT_EARLY_BEV", "0") == "1"     # measured SLOWER (round 4: 18.39 vs 18.23 ms; round 6: 18.45 vs 17.98 - 18.31): off
 
 
 def gen_seq_masks(seq_lens, max_len):
