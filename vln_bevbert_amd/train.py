@@ -111,6 +111,9 @@ class GradReducer:
         if self.queue_report is not None or not (self.cuda and self.active) or \
                 os.environ.get("BEVBERT_COLLECTIVE_QUEUE_CHECK", "1") != "1":
             return self.queue_report
+        if dist.get_backend(self.group) != "nccl":          # gloo moves device tensors through the host: no stream to place
+            self.queue_report = {"backend": dist.get_backend(self.group), "checked": False}
+            return self.queue_report
         settled = GradReducer._settled.get((self.flat.device.index, id(self.group)))
         if settled is not None:                               # an earlier reducer of this process did the work
             self.group, self.queue_report = settled
@@ -316,6 +319,8 @@ class PretrainTrainer:
         # one-rank group, gpurun_out r03w) while all-reduce, reduce-scatter and all-gather capture fine: only steps with
         # the all-to-all form of the bf16 exchange are issued eagerly
         self.capture_ok = not (self.reducer.active and self.reducer.exchange == "bf16_a2a")
+        if self.reducer.active and dist.get_backend(self.reducer.group) != "nccl":
+            self.capture_ok = False      # a host-staged exchange (gloo on device tensors) is not stream work: eager steps
         if self.reducer.active:
             self.broadcast_state()             # replicas start from rank 0's weights, as under DistributedDataParallel
         # Without collectives the same moment of backward -- d loss / d text-embeddings complete: every kernel of the two
