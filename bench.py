@@ -220,7 +220,7 @@ def spawn_ranks(a):
     node (the reference starts its ranks the same way, scripts/pt_r2r.bash:8-10 `python -m torch.distributed.launch
     --nproc_per_node`).  The ranks inherit stdout / stderr; rank 0 prints the line."""
     import socket
-    if not a.dry_launch and torch.cuda.device_count() < a.gpus:
+    if not a.dry_launch and torch.cuda.device_count() < a.gpus and os.environ.get("BEVBERT_BENCH_SHARE_GPU") != "1":
         sys.exit(f"bench.py: --gpus {a.gpus}, but {torch.cuda.device_count()} GPUs are visible")
     with socket.socket() as sk:             # a free port for the rendezvous (two benches on one node must not collide)
         sk.bind(("127.0.0.1", 0))
@@ -322,6 +322,11 @@ def main():
         return
     if not torch.cuda.is_available():
         sys.exit("bench.py measures the MI355X path; no GPU is visible")
+    # BEVBERT_BENCH_SHARE_GPU=1: a REHEARSAL of the multi-rank code path on a one-GPU box -- every rank uses GPU 0 and the
+    # ranks exchange over gloo (RCCL refuses two ranks on one device).  Not a measurement: the line says so in "data".
+    share_gpu = world > 1 and os.environ.get("BEVBERT_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} wants GPU {local_rank}, but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
@@ -340,7 +345,10 @@ def main():
         os.environ.setdefault("NCCL_DEBUG_FILE", nccl_log)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from vln_bevbert_amd import lib, ops, synthetic
     from vln_bevbert_amd.static_step import StaticBatch
@@ -491,7 +499,8 @@ def main():
     out = {
         "metric": "pretrain_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype + ("+fp32-residual" if a.residual == "fp32" and a.dtype == "bf16" else ""), "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype + ("+fp32-residual" if a.residual == "fp32" and a.dtype == "bf16" else ""),
+        "data": "synthetic" if not share_gpu else "synthetic; REHEARSAL: all ranks share GPU 0 and exchange over gloo -- not a measurement",
         "config": {"workload": f"{a.config.upper()} pre-train step (lift+splat, fwd, bwd, all-reduce, clip, AdamW), "
                                "scripts/pt_r2r.bash shapes: 36 views x 512, 5-step paths, 2352 grid points x 768 -> "
                                f"{cfg.bev_dim}x{cfg.bev_dim} BEV, {a.txt_len}-token text, task cycle "

@@ -139,3 +139,34 @@ def test_two_ranks_on_one_gpu_train_like_one_process_summing_both_batches():
     torch.cuda.synchronize()
     err = float((arena.params.detach().cpu() - end0).abs().max())
     assert err <= 1e-6, err
+
+
+def test_bench_multi_rank_path_rehearsed_with_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` end to end -- self-launched ranks, trainer with world_size 2, barriers, maximum over
+    ranks, the `rccl` block with its region timeline, ONE line from rank 0 -- with both ranks on GPU 0 and gloo underneath
+    (BEVBERT_BENCH_SHARE_GPU=1).  Not a measurement (the line says so); the first run on a multi-GPU node must not be the
+    first run of this code."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BEVBERT_BENCH_SHARE_GPU="1", BEVBERT_BENCH_WATCHDOG_S="600")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    detail = os.path.join(root, "gpurun_out", "bench_detail_rehearsal.json")
+    os.makedirs(os.path.dirname(detail), exist_ok=True)
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "11", "--warmup", "2",
+                         "--launch", "eager", "--no-side", "--no-stream", "--no-cpu-baseline", "--no-fwd", "--no-kernel-pass",
+                         "--detail", detail], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    line = pr.stdout.strip().splitlines()[-1]
+    d = json.loads(line)
+    assert len(line) < 6144
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+    assert d["steps"] == 11 and d["value"] > 0 and abs(d["value"] - 11 * 128 / (11 * d["ms_per_step"] / 1e3)) < 0.01 * d["value"]
+    assert "REHEARSAL" in d["data"] and d["scaling"] == "weak"
+    assert d["rccl"]["ranks"] == 2 and d["rccl"]["backend"] == "gloo" and d["rccl"]["allreduce_bytes_per_step"] > 9e8
+    full = json.load(open(detail))
+    assert len(full["rccl"]["region_timeline"]) >= 1
