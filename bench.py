@@ -987,13 +987,29 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     t0 = None
     stats0 = None
     marks = [] if os.environ.get("BEVBERT_STEP_EVENTS") == "1" else None     # diagnosis: device time of every step + gaps
+    host_log, gc_log = [], []
+    if marks is not None:
+        import gc
+        mgr.trace = []
+
+        def _gc_cb(phase, info, _t=[0.0]):
+            if phase == "start":
+                _t[0] = time.perf_counter()
+            else:
+                gc_log.append((_t[0], time.perf_counter() - _t[0], info.get("generation")))
+        gc.callbacks.append(_gc_cb)
     for i in range(n_total):
         if i == n_warm:
             torch.cuda.synchronize()
+            if os.environ.get("BEVBERT_QUIET_GC", "1") == "1":
+                from vln_bevbert_amd.loader import quiet_gc
+                quiet_gc()                       # an 85 ms generation-2 pass in the timed region costs 1 - 6 % of 33 steps
             stats0 = dict(mgr.stats)
             replayed = eager = 0
             t0 = time.perf_counter()
+        t_a = time.perf_counter()
         task, sb = next(it)
+        t_b = time.perf_counter()
         was_graph = sb.graph is not None
         if marks is not None and i >= n_warm:
             marks.append((task, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
@@ -1001,6 +1017,7 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
         trainer.step(task, sb)
         if marks is not None and i >= n_warm:
             marks[-1][2].record()
+            host_log.append((t_a, t_b, time.perf_counter(), task))
         loader.release(sb)
         replayed += was_graph
         eager += not was_graph
@@ -1031,7 +1048,22 @@ def sustained(cfg, a, trainer, cycle, tasks, dev, resident_ms):
     res["arena_fill"] = "beside the forward (side stream)" if trainer.overlap_zero else "in line"
     res["copy_stream_probe"] = mgr.copy_stream_probe
     if marks:
+        import gc
+        gc.callbacks[:] = [c for c in gc.callbacks if getattr(c, "__name__", "") != "_gc_cb"]
         res["step_events"] = _step_event_digest(marks)
+        gaps = [marks[j - 1][2].elapsed_time(marks[j][1]) for j in range(1, len(marks))]
+        j = max(range(len(gaps)), key=gaps.__getitem__) + 1            # the step that started late
+        if gaps[j - 1] > 2.0:
+            ms = lambda t: round(1000.0 * (t - t0), 2)
+            lo_t, hi_t = host_log[max(0, j - 4)][0], host_log[min(len(host_log) - 1, j + 1)][2]
+            res["step_events"]["worst_gap"] = {
+                "ms": round(gaps[j - 1], 2), "before_step": j,
+                "consumer_next_wait_step_ms": [(k, hl[3], ms(hl[0]), round(1000 * (hl[1] - hl[0]), 2), round(1000 * (hl[2] - hl[1]), 2))
+                                               for k, hl in enumerate(host_log) if max(0, j - 4) <= k <= j + 1],
+                "producer_enter_wait_total_ms": [(ms(tr[0]), round(1000 * (tr[1] - (mgr.trace[q - 1][1] if q else 0.0)), 2),
+                                                  round(1000 * (tr[2] - tr[0]), 2), tr[3])
+                                                 for q, tr in enumerate(mgr.trace) if lo_t - 0.05 <= tr[0] <= hi_t],
+                "gc_start_ms_dur_ms_gen": [(ms(g[0]), round(1000 * g[1], 2), g[2]) for g in gc_log if lo_t - 0.05 <= g[0] <= hi_t and g[1] > 0.002]}
     trainer.overlap_zero = overlap_zero_was
     del store
     return res

@@ -52,6 +52,7 @@ class BucketManager:
         self.copy_stream_probe = None
         self.copy_stream = pick_copy_stream(self.device, self) if self.device.type == "cuda" else None
         self.stats = collections.Counter()
+        self.trace = None               # set to [] to collect (t_enter, wait for the buffer set [s], t_exit, signature) per acquire
         self._cv = threading.Condition()
         self.stopped = False            # set by stop(): a producer waiting for a buffer set gives up promptly
 
@@ -117,6 +118,8 @@ class BucketManager:
         self.stats["bytes_h2d"] += sum(v.numel() * v.element_size() for k, v in batch.items()
                                        if torch.is_tensor(v) and not (self.grid_store is not None and k in ("rgbs", "depths", "sems")))
         self.stats["loader_s"] += time.perf_counter() - t0
+        if self.trace is not None:
+            self.trace.append((t0, self.stats["wait_s"], time.perf_counter(), hash(sig) & 0xffff))
         return sb
 
     def _record(self):
@@ -152,6 +155,18 @@ class BucketManager:
 
     def captured_graphs(self):
         return sum(sb.graph is not None for b in self.buckets.values() for sb in b["sets"])
+
+
+def quiet_gc():
+    """Call once after warm-up (model built, buffer sets allocated, steps captured).  Python's cyclic collector stops every
+    thread of the process; a generation-2 pass over the objects a training process has by then (modules, parameters, captured
+    graphs, task tables, plans) takes 80 - 90 ms (measured, round 6: `gc.callbacks` around the worst idle gaps of a
+    live-loader run), i.e. four to five steps during which the producer thread builds nothing -- more than the two buffer
+    sets per bucket can hide.  ``gc.freeze()`` moves everything alive now out of the collector's reach; what later steps
+    allocate is still collected, in passes that take microseconds."""
+    import gc
+    gc.collect()
+    gc.freeze()
 
 
 class LoaderStopped(RuntimeError):
