@@ -46,7 +46,7 @@ def timeit(fn):
 
 def main():
     dev = "cuda"
-    ws_floats = 512 * 3 * 3072          # bevbert_colsum_workspace_floats(3 * 3072)
+    ws_floats = int(__import__("vln_bevbert_amd.lib", fromlist=["load"]).load().bevbert_colsum_workspace_floats(3 * 3072))
     ws = torch.empty(ws_floats, device=dev)
     for rows in [int(r) for r in os.environ.get("ROWOPS_ROWS", "5120,28224").split(",")]:
         x = torch.randn(rows, H, device=dev).bfloat16()

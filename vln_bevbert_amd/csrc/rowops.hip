@@ -1200,15 +1200,23 @@ BEVBERT_API int bevbert_embed_sum_layernorm_fwd(const int64_t* ids, const void* 
 }
 
 // row groups of the column kernels (and of the LayerNorm backward, whose partial rows go through the same second stage):
-// enough blocks to fill the chip, <= 512 partial rows.  Rows per block: 16 from 8 192 rows up (the 28 224-row BEV
-// problems: 512 blocks); below that the kernels are latency-bound -- a wave walks its rows one after the other, every row
+// enough blocks to fill the chip, <= 1024 partial rows (BEVBERT_COLWISE_MAX_BLOCKS).  Rows per block: 16 from 8 192 rows
+// up, i.e. the cap for the 28 224-row BEV problems: 1 024 blocks = four waves per SIMD.  Until round 6 the cap was 512 (two
+// waves per SIMD): the fp32-stream LayerNorm backward, three input streams of 2 + 4 + 4 bytes per element and a reduction
+// between its loads and its stores, ran at 4.1 TB/s; with 1 024 blocks 5.15 TB/s (84.3 -> 67.4 us; 768: 70.3, 1 280: 78.6 --
+// an uneven last round --, 2 048: 69.2), the bf16 LayerNorm backward and the GELU backward do not care (31.4 -> 30.0,
+// 105.4 -> 104.1 us), the bare column sums lose 0.8 us (r06al).  Below 8 192 rows the kernels are latency-bound -- a wave walks its rows one after the other, every row
 // a dependent load -> reduce -> store chain -- and 10 rows per block (two or three per wave; 512 blocks for the 5 120 text
 // rows instead of 320) shortens that chain.  BEVBERT_ROWS_PER_BLOCK overrides (A/B measurements).
+static int colwise_max_blocks() {
+  static const int cap = [] { const char* v = getenv("BEVBERT_COLWISE_MAX_BLOCKS"); const int c = v ? atoi(v) : 0; return c > 0 ? c : 1024; }();
+  return cap;
+}
 static int colwise_blocks(int rows) {
   static const int env = [] { const char* v = getenv("BEVBERT_ROWS_PER_BLOCK"); return v ? atoi(v) : 0; }();
   const int per = env > 0 ? env : (rows >= 8192 ? 16 : 10);
   int nb = (rows + per - 1) / per;
-  if (nb > 512) nb = 512;
+  if (nb > colwise_max_blocks()) nb = colwise_max_blocks();
   return nb < 1 ? 1 : nb;
 }
 static int partial_blocks(int rows, int) { return colwise_blocks(rows); }
@@ -1221,7 +1229,7 @@ static int elementwise_row_groups(int rows) {
 }
 
 // workspace: >= bevbert_colsum_workspace_floats(3*H) floats
-BEVBERT_API int64_t bevbert_colsum_workspace_floats(int total_cols) { return (int64_t)512 * total_cols; }
+BEVBERT_API int64_t bevbert_colsum_workspace_floats(int total_cols) { return (int64_t)colwise_max_blocks() * total_cols; }
 
 // Two-stage column reductions, split: layernorm_bwd / bias_gelu_bwd called with NULL parameter-gradient outputs leave
 // their per-block partial sums in `workspace` ([bevbert_colsum_partial_rows(rows)][nwhich][C] floats); this entry is the

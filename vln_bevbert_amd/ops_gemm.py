@@ -249,7 +249,7 @@ def _param_grads(w_sink, b_sink, dyc, xc):
             call("bevbert_colsum_partials", ptr(dyc), part, dyc.shape[0], C, dtype_code(dyc), stream())
             ReduceQueue.add(part, nb, 1, C, (ptr(b_sink), None, None))
         else:
-            ws = RT.workspace(dyc.device, 512 * C)
+            ws = RT.workspace(dyc.device, lib.load().bevbert_colsum_workspace_floats(C))
             call("bevbert_colsum", ptr(dyc), ptr(b_sink), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 1, stream())
 
 
@@ -299,7 +299,7 @@ class _Linear(torch.autograd.Function):
                 else:
                     gb = dy2.float().sum(0).to(bias.dtype)
             else:
-                ws = RT.workspace(dy.device, 512 * C)
+                ws = RT.workspace(dy.device, lib.load().bevbert_colsum_workspace_floats(C))
                 dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
                 t = torch.empty(C, dtype=torch.float32, device=dy.device)
                 call("bevbert_colsum", ptr(dyc), ptr(t), ptr(ws), dyc.shape[0], C, dtype_code(dyc), 0, stream())

@@ -436,7 +436,7 @@ class _BiasGelu(torch.autograd.Function):
         rows = x.numel() // C
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
-        ws = RT.workspace(dy.device, 512 * C)
+        ws = RT.workspace(dy.device, lib.load().bevbert_colsum_workspace_floats(C))
         sink = _sink(bias)
         if sink is not None:
             _mark_touched(bias)
@@ -614,7 +614,7 @@ class _EmbedLN(torch.autograd.Function):
         rows = B * L
         dy = dy.contiguous()
         dz = torch.empty_like(dy)
-        ws = RT.workspace(dy.device, 512 * 3 * H)
+        ws = RT.workspace(dy.device, lib.load().bevbert_colsum_workspace_floats(3 * H))
         sg, sb = _sink(gamma), _sink(beta)
         assert (sg is None) == (sb is None)
         # the broadcast token-type row: its gradient is the column sum of dz = the kernel's third (dbias) output, through
