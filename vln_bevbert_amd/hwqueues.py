@@ -20,14 +20,21 @@ import os
 import torch
 
 
+_PROBE_BUFFERS = {}
+
+
 def shares_hw_queue(stream, main, device, busy_ms=3.0):
     """True when work enqueued on ``stream`` waits behind work enqueued earlier on ``main``: the two HIP streams are served
     by the same in-order hardware queue (a process has GPU_MAX_HW_QUEUES = 4 of them, streams are dealt onto them in
     creation order).  Probe: ~busy_ms of fills on ``main``, then a 1 KB host->device copy on ``stream``; which finishes
     first, seen from the host."""
-    busy = torch.empty(64 << 20, dtype=torch.float32, device=device)
-    src = torch.empty(1024, dtype=torch.uint8).pin_memory()
-    dst = torch.empty(1024, dtype=torch.uint8, device=device)
+    device = torch.device(device)
+    bufs = _PROBE_BUFFERS.get(device.index)
+    if bufs is None:                                   # one pinned source for all probes (pinning synchronises the device)
+        bufs = _PROBE_BUFFERS[device.index] = (torch.empty(1024, dtype=torch.uint8).pin_memory(),
+                                               torch.empty(1024, dtype=torch.uint8, device=device))
+    src, dst = bufs
+    busy = torch.empty(64 << 20, dtype=torch.float32, device=device)      # 256 MB from the caching allocator, returned below
     with torch.cuda.stream(stream):
         dst.copy_(src, non_blocking=True)              # first use of the stream (queue acquisition) outside the probe
     torch.cuda.synchronize(device)
@@ -57,7 +64,7 @@ def pick_copy_stream(device, owner=None, candidates=6):
     hardware queue of its own -- and a fifth active queue slows the whole step by 4 ms (same measurement, also
     GPU_MAX_HW_QUEUES = 5, 6, 8: 23.1, 24.2, 27.5 ms against 17.6).  BEVBERT_COPY_STREAM_PROBE=0: first stream, unprobed."""
     main = torch.cuda.current_stream(device)
-    if os.environ.get("BEVBERT_COPY_STREAM_PROBE", "1") != "1":
+    if os.environ.get("BEVBERT_COPY_STREAM_PROBE", "1") != "1" or torch.cuda.is_current_stream_capturing():
         return torch.cuda.Stream(device)
     tried = []
     keep = []                                           # rejected candidates stay alive while probing: the next stream
@@ -115,7 +122,7 @@ def steer_stream_pool(device, like=None, limit=64):
     queue.  Returns {"pool": n, "wanted": [...], "next": j} (None off-GPU or with BEVBERT_STEER_POOL=0).
     Verify with train.GradReducer.collectives_wait_behind_compute()."""
     device = torch.device(device)
-    if device.type != "cuda" or os.environ.get("BEVBERT_STEER_POOL", "1") != "1":
+    if device.type != "cuda" or os.environ.get("BEVBERT_STEER_POOL", "1") != "1" or torch.cuda.is_current_stream_capturing():
         return None
     main = torch.cuda.current_stream(device)
 
