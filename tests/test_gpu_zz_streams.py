@@ -566,3 +566,30 @@ def test_gradient_exchange_runs_off_the_compute_streams_hardware_queue(one_rank_
     assert st["pool"] == 32 and 20 <= sum(st["wanted"]) <= 28 and st["next"] is not None, st
     nxt = torch.cuda.Stream(dev)
     assert not shares_hw_queue(nxt, torch.cuda.current_stream(dev), dev)
+
+
+def test_gradient_exchange_moves_to_a_group_of_its_own_when_the_default_group_waits_behind_compute(one_rank_group, monkeypatch):
+    """The other branch of GradReducer.settle_collective_queue: the default group's communicator was bound to a stream on
+    the compute stream's queue before the trainer came (here: the first check is made to say so) -> the pool is steered, the
+    exchange moves to a new_group(), the new group is checked for real, and regions reduce through it."""
+    from vln_bevbert_amd.train import GradReducer
+    dev = torch.device("cuda", torch.cuda.current_device())
+    monkeypatch.setattr(GradReducer, "_settled", {})
+    real = GradReducer.collectives_wait_behind_compute
+    calls = []
+
+    def first_says_yes(self, *a, **k):
+        calls.append(1)
+        return True if len(calls) == 1 else real(self, *a, **k)
+    monkeypatch.setattr(GradReducer, "collectives_wait_behind_compute", first_says_yes)
+    flat = torch.arange(1 << 16, device=dev, dtype=torch.float32)
+    red = GradReducer(flat, 1 << 15, force=True)
+    assert red.group is None
+    rep = red.settle_collective_queue()
+    assert rep["waits_behind_compute"] is True and rep["own_group"]["waits_behind_compute"] is False, rep
+    assert red.group is not None and len(calls) == 2
+    want = flat.clone()
+    red.launch_region(1 << 15, 1 << 16)
+    red.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(flat, want)                 # one rank: the sum over ranks is the tensor itself
