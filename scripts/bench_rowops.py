@@ -85,6 +85,11 @@ def main():
         print(json.dumps({"kernel": "gelu_fwd", "rows": rows, "us": round(t, 2), "bytes": rows * C * 4, "mark": _mark_idx[0], "GBps": round(rows * C * 4 / t / 1e3, 1)}), flush=True)
         t = timeit(lambda: call("bevbert_bias_gelu_bwd", ptr(dyi), ptr(xi), ptr(bi), ptr(dxi), None, ptr(ws), rows, C, BF16, 0, stream()))
         print(json.dumps({"kernel": "gelu_bwd", "rows": rows, "us": round(t, 2), "bytes": rows * C * 6, "mark": _mark_idx[0], "GBps": round(rows * C * 6 / t / 1e3, 1)}), flush=True)
+        # the same traffic with a trivial activation gradient: what the erf-GELU arithmetic costs on top of the memory pipeline
+        t = timeit(lambda: call("bevbert_bias_relu_bwd", ptr(dyi), ptr(xi), ptr(bi), ptr(dxi), None, ptr(ws), rows, C, BF16, 0, stream()))
+        print(json.dumps({"kernel": "relu_bwd", "rows": rows, "us": round(t, 2), "bytes": rows * C * 6, "mark": _mark_idx[0], "GBps": round(rows * C * 6 / t / 1e3, 1)}), flush=True)
+        t = timeit(lambda: call("bevbert_bias_relu_fwd", ptr(xi), ptr(bi), ptr(yi), rows, C, BF16, stream()))
+        print(json.dumps({"kernel": "relu_fwd", "rows": rows, "us": round(t, 2), "bytes": rows * C * 4, "mark": _mark_idx[0], "GBps": round(rows * C * 4 / t / 1e3, 1)}), flush=True)
         for Cc in (768, 2304):
             d = torch.randn(rows, Cc, device=dev).bfloat16()
             t = timeit(lambda: call("bevbert_colsum_partials", ptr(d), ptr(ws), rows, Cc, BF16, stream()))
